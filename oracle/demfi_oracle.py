@@ -1,0 +1,422 @@
+"""CPU restatement of the DeMFI-Net_rb inference forward  --  TEST INFRASTRUCTURE ONLY.
+
+This file is the *oracle* of the repo: a functional, CPU, fp32 restatement of the algorithm in
+/root/reference/DeMFInet.py (read-only upstream).  It is never imported by the product package
+``demfi_amd``; only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
+leg may use it, and only as the checker / the timed non-optimised baseline.
+
+Pinning: the reference ships no tests or golden vectors, so the pin is made by this
+project: ``tools/make_goldens.py`` imports the reference in the build container, runs it on
+synthetic weights/inputs and freezes its outputs under ``tests/golden/``; ``tests/test_oracle.py``
+checks every function here against those fixtures (the reference itself cannot travel to the GPU
+box).  Dense arithmetic uses torch CPU ops (conv2d / grid_sample -- the same ATen ops the reference
+reaches); the index-bearing pieces (forward splat, backward warp) are additionally restated
+step by step in numpy fp32 so that the integer index / validity maps exist as data.
+
+Every function cites the reference lines it follows.  Weights come in as a plain ``state_dict``
+(name -> tensor) with the reference's key names.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+f32 = np.float32
+
+
+# --------------------------------------------------------------------------------------------
+# small helpers
+# --------------------------------------------------------------------------------------------
+def conv(sd, name, x, stride=1):
+    """nn.Conv2d / nn.Conv3d(kernel (1,k,k)) with 'same' padding; Conv3d on [B,C,T,H,W] is a per-frame
+    2-D conv (DeMFInet.py:30-34, 532-533), so 5-D weights are squeezed and applied on a batch."""
+    w = sd[name + '.weight']
+    if w.dim() == 5:
+        w = w[:, :, 0]
+    kh, kw = w.shape[2], w.shape[3]
+    if stride == 1:
+        pad = (kh // 2, kw // 2)
+    else:                       # UNet encoders: 4x4, stride 2, padding 1 (DeMFInet.py:575-577)
+        pad = (1, 1)
+    return F.conv2d(x, w, sd[name + '.bias'], stride=stride, padding=pad)
+
+
+def space_to_depth(x, r=2):
+    """pixel_reshuffle (DeMFInet.py:290-316): out[b, c*r*r + ry*r + rx, h, w] = x[b, c, h*r+ry, w*r+rx]."""
+    b, c, h, w = x.shape
+    x = x.reshape(b, c, h // r, r, w // r, r)
+    return x.permute(0, 1, 3, 5, 2, 4).reshape(b, c * r * r, h // r, w // r)
+
+
+def resblock(sd, name, x):
+    """ResidualBlock_noBN(_3D) (DeMFInet.py:524-563): x + conv2(relu(conv1(x)))."""
+    return x + conv(sd, name + '.conv2', F.relu(conv(sd, name + '.conv1', x)))
+
+
+# --------------------------------------------------------------------------------------------
+# Stage I pieces
+# --------------------------------------------------------------------------------------------
+def ff_rdb(sd, B0, B1, Bm1, B2, nf=64, num_rdb=12, n_conv=4):
+    """FF_RDB.forward (DeMFInet.py:233-253) with RDB / RDB_Conv (256-287)."""
+    p = 'FF_RDB_Module.'
+    f1 = conv(sd, p + 'SFENet1', space_to_depth(torch.cat((B0, B1, Bm1, B2), 1), 2))
+    x = conv(sd, p + 'SFENet2', f1)
+    outs = []
+    for i in range(num_rdb):
+        y = x
+        for c in range(n_conv):
+            y = torch.cat((y, F.relu(conv(sd, p + 'RDBs.%d.convs.%d.conv.0' % (i, c), y))), 1)
+        x = conv(sd, p + 'RDBs.%d.LFF' % i, y) + x
+        outs.append(x)
+    x = conv(sd, p + 'GFF.1', conv(sd, p + 'GFF.0', torch.cat(outs, 1))) + f1
+    s = conv(sd, p + 'UPNet.2', F.pixel_shuffle(conv(sd, p + 'UPNet.0', x), 2))
+    feats = torch.tanh(s[:, :2 * nf])
+    return (feats[:, :nf], feats[:, nf:], s[:, 2 * nf:2 * nf + 2], s[:, 2 * nf + 2:2 * nf + 4],
+            s[:, 2 * nf + 4:2 * nf + 5])
+
+
+def splat_maps(flo, H, W):
+    """Integer maps of sample_one (DeMFInet.py:712-719) for the four corners of fwarp (653-657).
+
+    flo: numpy [2,H,W] fp32 displacement (ch0 -> column offset "y", ch1 -> row offset "x", 647-648).
+    Returns a list of 4 dicts in the reference's corner order (x1,y1),(x1,y2),(x2,y1),(x2,y2) with
+    int64 'row','col' target coordinates, bool 'mask' (716) and fp32 'w' (674-680)."""
+    y = flo[0].astype(f32)
+    x = flo[1].astype(f32)
+    x1 = np.floor(x)
+    x2 = x1 + f32(1)
+    y1 = np.floor(y)
+    y2 = y1 + f32(1)
+    rows = np.arange(H, dtype=np.int64)[:, None]
+    cols = np.arange(W, dtype=np.int64)[None, :]
+    out = []
+    for xs, ys in ((x1, y1), (x1, y2), (x2, y1), (x2, y2)):
+        dx = (x - xs).astype(f32)
+        dy = (y - ys).astype(f32)
+        # exp through torch (sleef) -- numpy's float32 exp differs in the last ulp for ~40% of inputs
+        w = torch.exp(torch.from_numpy(-((dx * dx).astype(f32) + (dy * dy).astype(f32)).astype(f32))).numpy()
+        r = xs.astype(np.int64) + rows          # .long() truncation of an integral float (712)
+        c = ys.astype(np.int64) + cols
+        m = (r >= 0) & (r < H) & (c >= 0) & (c < W)
+        out.append(dict(row=r, col=c, mask=m, w=w))
+    return out
+
+
+def forward_splat(img, flo):
+    """fwarp (DeMFInet.py:625-671) + sample_one (683-729) for batch 1.
+
+    img, flo: torch [1,C,H,W] / [1,2,H,W].  Per corner the weighted values are accumulated in
+    raster order into a zero buffer (put_(accumulate=True) on CPU is sequential), then the four
+    corner buffers are summed ((11+12)+21)+22 (668-669).  np.add.at keeps that order in fp32."""
+    a = img[0].numpy().astype(f32)
+    C, H, W = a.shape
+    maps = splat_maps(flo[0].numpy(), H, W)
+    acc_img, acc_one = None, None
+    for m in maps:
+        ids = (m['row'] * W + m['col'])[m['mask']]
+        wv = m['w'][m['mask']]
+        one = np.zeros(H * W, f32)
+        np.add.at(one, ids, wv)
+        buf = np.zeros((C, H * W), f32)
+        for c in range(C):
+            np.add.at(buf[c], ids, (a[c] * m['w']).astype(f32)[m['mask']])
+        acc_img = buf if acc_img is None else (acc_img + buf).astype(f32)
+        acc_one = one if acc_one is None else (acc_one + one).astype(f32)
+    imgw = torch.from_numpy(acc_img.reshape(1, C, H, W))
+    o = torch.from_numpy(np.broadcast_to(acc_one.reshape(1, 1, H, W), (1, C, H, W)).copy())
+    return imgw, o
+
+
+def cfr_flow_align(flow_01, flow_10, t):
+    """CFR_flow_t_align (DeMFInet.py:606-622); t is the [B,1,1,1] tensor of DeMFInet.py:63."""
+    f01, n0 = forward_splat(flow_01, t * flow_01)
+    f10, n1 = forward_splat(flow_10, (1 - t) * flow_10)
+    ft0 = -(1 - t) * t * f01 + t * t * f10
+    ft1 = (1 - t) * (1 - t) * f01 - t * (1 - t) * f10
+    norm = (1 - t) * n0 + t * n1
+    m = (norm > 0).type(norm.type())
+    ft0 = (1 - m) * ft0 + m * (ft0 / (norm + (1 - m)))
+    ft1 = (1 - m) * ft1 + m * (ft1 / (norm + (1 - m)))
+    return ft0, ft1
+
+
+def _unnormalized_coords(px, size):
+    """fp32 round trip of bwarp / bilinear_sampler + ATen: g = 2*p/max(size-1,1) - 1 (DeMFInet.py:753-754,
+    503-504), then grid_sampler_unnormalize(align_corners=True): ((g+1)/2)*(size-1).  Every step is
+    one fp32 rounding (no FMA contraction) -- SURVEY.md F11."""
+    d = f32(max(size - 1, 1))
+    g = ((f32(2.0) * px).astype(f32) / d).astype(f32) - f32(1.0)
+    g = g.astype(f32)
+    return (((g + f32(1.0)).astype(f32) / f32(2.0)).astype(f32) * f32(size - 1)).astype(f32)
+
+
+def sample_maps(px, py, H, W):
+    """Index maps of one zero-padded bilinear grid_sample at pixel coordinates (px, py) [H',W'] fp32.
+
+    Returns ix0, iy0 (int32 floor indices), the four corner weights nw, ne, sw, se (fp32) and the
+    four in-bounds bits (bool), following ATen's grid_sampler_2d CPU kernel."""
+    ix = _unnormalized_coords(px.astype(f32), W)
+    iy = _unnormalized_coords(py.astype(f32), H)
+    x0 = np.floor(ix)
+    y0 = np.floor(iy)
+    x1 = x0 + f32(1)
+    y1 = y0 + f32(1)
+    nw = ((x1 - ix).astype(f32) * (y1 - iy).astype(f32)).astype(f32)
+    ne = ((ix - x0).astype(f32) * (y1 - iy).astype(f32)).astype(f32)
+    sw = ((x1 - ix).astype(f32) * (iy - y0).astype(f32)).astype(f32)
+    se = ((ix - x0).astype(f32) * (iy - y0).astype(f32)).astype(f32)
+    with np.errstate(invalid='ignore'):
+        x0i = np.clip(x0, -2e9, 2e9).astype(np.int64)
+        y0i = np.clip(y0, -2e9, 2e9).astype(np.int64)
+    inx0 = (x0i >= 0) & (x0i <= W - 1)
+    inx1 = (x0i + 1 >= 0) & (x0i + 1 <= W - 1)
+    iny0 = (y0i >= 0) & (y0i <= H - 1)
+    iny1 = (y0i + 1 >= 0) & (y0i + 1 <= H - 1)
+    return dict(ix0=x0i, iy0=y0i, w=(nw, ne, sw, se),
+                inb=(inx0 & iny0, inx1 & iny0, inx0 & iny1, inx1 & iny1))
+
+
+def _gather_bilinear(a, m):
+    """a: numpy [C,H,W]; m: sample_maps result -> [C,H',W'] fp32, ATen accumulation order nw,ne,sw,se."""
+    C, H, W = a.shape
+    out = np.zeros((C,) + m['ix0'].shape, f32)
+    offs = ((0, 0), (1, 0), (0, 1), (1, 1))
+    for (dx, dy), w, inb in zip(offs, m['w'], m['inb']):
+        xi = np.clip(m['ix0'] + dx, 0, W - 1)
+        yi = np.clip(m['iy0'] + dy, 0, H - 1)
+        v = a[:, yi, xi] * np.where(inb, w, f32(0))[None]
+        out = (out + v.astype(f32)).astype(f32)
+    return out
+
+
+def backward_warp_maps(flo):
+    """Index / validity maps of bwarp (DeMFInet.py:732-766) for flo numpy [2,H,W] fp32:
+    sample_maps at (col + flo[0], row + flo[1]) plus 'valid' = (sum of in-bounds weights >= 0.999)
+    (the all-ones grid_sample and the two masked_fill_ of lines 758-764)."""
+    _, H, W = flo.shape
+    px = (np.arange(W, dtype=f32)[None, :] + flo[0].astype(f32)).astype(f32)
+    py = (np.arange(H, dtype=f32)[:, None] + flo[1].astype(f32)).astype(f32)
+    m = sample_maps(px, py, H, W)
+    s = np.zeros((H, W), f32)
+    for w, inb in zip(m['w'], m['inb']):
+        s = (s + np.where(inb, w, f32(0))).astype(f32)
+    valid = ~(s < f32(0.999))
+    valid &= s > 0
+    m['valid'] = valid
+    return m
+
+
+def backward_warp_explicit(x, flo):
+    """bwarp restated with explicit gathers (batch 1) -- the index-map twin of backward_warp()."""
+    m = backward_warp_maps(flo[0].numpy())
+    out = _gather_bilinear(x[0].numpy().astype(f32), m) * m['valid'][None].astype(f32)
+    return torch.from_numpy(out[None])
+
+
+def backward_warp(x, flo):
+    """bwarp (DeMFInet.py:732-766) through the same ATen op the reference calls (fast path of the oracle)."""
+    B, C, H, W = x.shape
+    xx = torch.arange(0, W).view(1, 1, 1, W).expand(B, 1, H, W)
+    yy = torch.arange(0, H).view(1, 1, H, 1).expand(B, 1, H, W)
+    v = torch.cat((xx, yy), 1).float() + flo
+    gx = 2.0 * v[:, 0] / max(W - 1, 1) - 1.0
+    gy = 2.0 * v[:, 1] / max(H - 1, 1) - 1.0
+    grid = torch.stack((gx, gy), -1)
+    out = F.grid_sample(x, grid, mode='bilinear', padding_mode='zeros', align_corners=True)
+    ones = F.grid_sample(torch.ones_like(x), grid, mode='bilinear', padding_mode='zeros', align_corners=True)
+    mask = torch.where(ones < 0.999, torch.zeros_like(ones), ones)
+    mask = torch.where(mask > 0, torch.ones_like(mask), mask)
+    return out * mask
+
+
+def warp_blend(A, fa, Bf, fb, occ_logit, t):
+    """Eq.(2) blend of two backward warps (DeMFInet.py:66-71, 84-93, 140-149)."""
+    o0 = torch.sigmoid(occ_logit)
+    o1 = 1 - o0
+    out = (1 - t) * o0 * backward_warp(A, fa) + t * o1 * backward_warp(Bf, fb)
+    return out / ((1 - t) * o0 + t * o1)
+
+
+def fgac_sample(ref_k, flow):
+    """bilinear_sampler (DeMFInet.py:499-514) at ABSOLUTE coordinates = the flow values themselves
+    (DeMFInet.py:413-419 with rr = sr = 0: no base grid is added -- SURVEY.md F7)."""
+    H, W = ref_k.shape[-2:]
+    c = flow.permute(0, 2, 3, 1).float()
+    gx = 2 * c[..., 0:1] / (W - 1) - 1
+    gy = 2 * c[..., 1:2] / (H - 1) - 1
+    return F.grid_sample(ref_k, torch.cat([gx, gy], -1), mode='bilinear', padding_mode='zeros', align_corners=True)
+
+
+def fgac_sample_explicit(ref_k, flow):
+    """Explicit-gather twin of fgac_sample (batch 1)."""
+    a = ref_k[0].numpy().astype(f32)
+    _, H, W = a.shape
+    fl = flow[0].numpy().astype(f32)
+    m = sample_maps(fl[0], fl[1], H, W)
+    return torch.from_numpy(_gather_bilinear(a, m)[None]), m
+
+
+def fgac(sd, name, ref, source, flow):
+    """FGAC.forward (DeMFInet.py:386-452) with rr = sr = 0: correlation window of one element, softmax == 1,
+    avg_pool / unfold identities; conv_source_k has no effect on any output."""
+    e = conv(sd, name + '.fusion', fgac_sample(conv(sd, name + '.conv_ref_k', ref), flow))
+    w = torch.sigmoid(conv(sd, name + '.w_gen_2', F.relu(conv(sd, name + '.w_gen', torch.cat([source, e], 1)))))
+    return w * source + (1 - w) * e, w
+
+
+def fac_fb(sd, F0, F1, flow_10, flow_01, n_res=5, shared=True):
+    """FAC_FB.forward (DeMFInet.py:335-358): shared encoder on both frames, then FGAC both ways."""
+    p = 'FAC_FB_Module.'
+    enc = F.relu(conv(sd, p + 'conv_first', torch.cat([F0, F1], 0)))
+    for i in range(n_res):
+        enc = resblock(sd, p + 'feature_extraction.%d' % i, enc)
+    e0, e1 = enc[0:1], enc[1:2]
+    n0 = p + ('shared_FGAC' if shared else 'FGAC_F1toF0')
+    n1 = p + ('shared_FGAC' if shared else 'FGAC_F0toF1')
+    a0, w0 = fgac(sd, n0, e1, e0, flow_01)
+    a1, w1 = fgac(sd, n1, e0, e1, flow_10)
+    return a0, a1, enc, (w0, w1)
+
+
+def unet(sd, x):
+    """UNet.forward (DeMFInet.py:586-603)."""
+    p = 'Refine_Module.'
+    e1 = F.relu(conv(sd, p + 'enc1', x, 2))
+    e2 = F.relu(conv(sd, p + 'enc2', e1, 2))
+    o = F.relu(conv(sd, p + 'enc3', e2, 2))
+    o = F.relu(conv(sd, p + 'dec0', o))
+    up = lambda z: F.interpolate(z, scale_factor=2, mode='nearest')
+    o = F.relu(conv(sd, p + 'dec1', torch.cat((up(o), e2), 1)))
+    o = F.relu(conv(sd, p + 'dec2', torch.cat((up(o), e1), 1)))
+    return conv(sd, p + 'dec3', up(o))
+
+
+def decoder(sd, x, suffix='', n_res=5):
+    """D1 (suffix '') on a batch of frames (DeMFInet.py:95-98) / D2 (suffix '_2') (158-160)."""
+    o = F.relu(conv(sd, 'Dec_first' + suffix, x))
+    for i in range(n_res):
+        o = resblock(sd, 'Decoder_res%s.%d' % (suffix, i), o)
+    o = F.relu(conv(sd, 'Dec_last1' + suffix, o))
+    return conv(sd, 'Dec_last2' + suffix, o)
+
+
+# --------------------------------------------------------------------------------------------
+# Stage II pieces
+# --------------------------------------------------------------------------------------------
+def mixer(sd, ref_list, delta_list):
+    """Mixer.forward (DeMFInet.py:810-824)."""
+    p = 'Booster_Module.Mixer.'
+    r = F.relu(conv(sd, p + 'conv_ref2', F.relu(conv(sd, p + 'conv_ref1', torch.cat(ref_list, 1)))))
+    d = F.relu(conv(sd, p + 'conv_delta2', F.relu(conv(sd, p + 'conv_delta1', torch.cat(delta_list, 1)))))
+    b = F.relu(conv(sd, p + 'conv_blend1', torch.cat([r, d], 1)))
+    return F.relu(conv(sd, p + 'conv_blend2', b))
+
+
+def sep_conv_gru(sd, h, x):
+    """SepConvGRU.forward (DeMFInet.py:838-857): horizontal (1x5) then vertical (5x1) GRU update."""
+    p = 'Booster_Module.GB.'
+    for s in ('1', '2'):
+        hx = torch.cat([h, x], 1)
+        z = torch.sigmoid(conv(sd, p + 'convz' + s, hx))
+        r = torch.sigmoid(conv(sd, p + 'convr' + s, hx))
+        q = torch.tanh(conv(sd, p + 'convq' + s, torch.cat([r * h, x], 1)))
+        h = (1 - z) * h + z * q
+    return h
+
+
+def booster(sd, F_rec, ref_list, delta_list):
+    """Booster.forward (DeMFInet.py:779-793) with FlowOcc (867-868)."""
+    h = sep_conv_gru(sd, F_rec, mixer(sd, ref_list, delta_list))
+    p = 'Booster_Module.flow_occ.'
+    d = conv(sd, p + 'conv2', F.relu(conv(sd, p + 'conv1', h)))
+    return h, d[:, :4], d[:, 4:5]
+
+
+# --------------------------------------------------------------------------------------------
+# full forward
+# --------------------------------------------------------------------------------------------
+def forward(sd, x, t_value, num_update=None, nf=64, shared_fgac=True, return_stages=False):
+    """DeMFInet.forward, inference branch (DeMFInet.py:46-179).
+
+    x [B,3,4,H,W] fp32 (frame order B0,B1,B-1,B2: 52-55), t_value [B,1].  Batch 1 only (the harness
+    always uses batch 1, utils.py:369,374; the splat restatement above is written for it).
+    Returns the reference's 5-tuple; with return_stages also a dict of intermediate tensors."""
+    assert x.shape[0] == 1
+    B0, B1, Bm1, B2 = x[:, :, 0], x[:, :, 1], x[:, :, 2], x[:, :, 3]
+    st = {}
+    F0, F1, flow_01, flow_10, occ_logit = ff_rdb(sd, B0, B1, Bm1, B2, nf)
+    t = t_value.reshape(-1, 1, 1, 1)
+    flow_t0, flow_t1 = cfr_flow_align(flow_01, flow_10, t)
+    Ft = warp_blend(F0, flow_t0, F1, flow_t1, occ_logit, t)
+    aF0, aF1, enc, gates = fac_fb(sd, F0, F1, flow_10, flow_01, shared=shared_fgac)
+    agg = torch.cat([aF0, aF1, Ft, flow_t0, flow_t1, flow_01, flow_10, occ_logit], 1)
+    agg = unet(sd, agg) + torch.cat([flow_t0, flow_t1, occ_logit, aF0, aF1], 1)
+    rflow_t0, rflow_t1, occ_logit1 = agg[:, 0:2], agg[:, 2:4], agg[:, 4:5]
+    rF0 = torch.tanh(agg[:, 5:5 + nf])
+    rF1 = torch.tanh(agg[:, 5 + nf:5 + 2 * nf])
+    rFt = warp_blend(rF0, rflow_t0, rF1, rflow_t1, occ_logit1, t)
+    d1 = decoder(sd, torch.cat([rF0, rF1, rFt], 0))
+    S0p, S1p, Stp = d1[0:1], d1[1:2], d1[2:3]
+    occ_0 = torch.sigmoid(occ_logit1)
+    flows = [torch.cat((rflow_t0, rflow_t1), 1)]
+    occs = [occ_0]
+    F_rec = torch.tanh(conv(sd, 'Ch_Reducer', torch.cat((rF0, rF1, rFt), 1)))
+    ref_list = [torch.cat((S0p, S1p, Stp, B0, B1, Bm1, B2), 1), torch.cat((flow_10, flow_01), 1),
+                torch.cat((flows[0], occ_logit1), 1)]
+    delta = [flows[0], occ_logit1]
+    if return_stages:
+        st.update(F0=F0, F1=F1, flow_01=flow_01, flow_10=flow_10, occ_logit=occ_logit, flow_t0=flow_t0,
+                  flow_t1=flow_t1, Ft=Ft, enc=enc, aF0=aF0, aF1=aF1, gate0=gates[0], gate1=gates[1],
+                  rF0=rF0, rF1=rF1, rFt=rFt, F_rec0=F_rec)
+    finals = []
+    n = 1 if num_update is None else num_update          # DeMFInet.py:126-128
+    for it in range(n):
+        F_rec, dflow, docc = booster(sd, F_rec, ref_list, delta)
+        delta = [delta[0] + dflow, delta[1] + docc]
+        ft0, ft1 = delta[0][:, 0:2], delta[0][:, 2:4]
+        occ_f = torch.sigmoid(delta[1])
+        occs.append(occ_f)
+        flows.append(torch.cat((ft0, ft1), 1))
+        St_new = warp_blend(S0p, ft0, S1p, ft1, delta[1], t)
+        agg3 = torch.cat([S0p, S1p, St_new, F_rec, occ_0, rflow_t0, rflow_t1, flow_10, flow_01, ft0, ft1, occ_f,
+                          B0, B1, Bm1, B2], 1)
+        o = decoder(sd, agg3, '_2')
+        finals.append([o[:, 0:3] + S0p, o[:, 3:6] + S1p, o[:, 6:9] + St_new])
+        if return_stages:
+            st['F_rec%d' % (it + 1)] = F_rec
+            st['St_new%d' % (it + 1)] = St_new
+    out = ([S0p, S1p, Stp], finals, flows, occs, torch.mean(x[:, :, 0:2], dim=2))
+    return (out, st) if return_stages else out
+
+
+# --------------------------------------------------------------------------------------------
+# harness + metric (the boundary caller and the acceptance metric)
+# --------------------------------------------------------------------------------------------
+def pad_forward_crop(sd, x, t_value, num_update, multiple=32):
+    """Working subset of patch_forward_DeFInet_itr (utils.py:1339-1477, patch (1,1)): reflect-pad bottom/right
+    to a multiple of 32 (1351-1365), forward, crop every map back (1452-1476)."""
+    B, C, T, h, w = x.shape
+    ph = (multiple - h % multiple) % multiple
+    pw = (multiple - w % multiple) % multiple
+    xp = F.pad(x.reshape(B, C * T, h, w), [0, pw, 0, ph], mode='reflect').reshape(B, C, T, h + ph, w + pw)
+    d1, fin, flows, occs, ov = forward(sd, xp, t_value, num_update)
+    cr = lambda z: z[..., :h, :w]
+    return ([cr(z) for z in d1], [[cr(z) for z in f] for f in fin], [cr(z) for z in flows],
+            [cr(z) for z in occs], cr(ov))
+
+
+def denorm255(x):
+    """denorm255_np (utils.py:718-721)."""
+    return np.clip((np.asarray(x, np.float64) + 1) / 2, 0, 1) * 255
+
+
+def psnr(a, b):
+    """psnr (utils.py:652-660) on np.around(denorm255(.)) frames as in main.py:763."""
+    a = np.around(denorm255(a))
+    b = np.around(denorm255(b))
+    mse = np.mean((a - b) ** 2)
+    return float('inf') if mse == 0 else 20 * np.log10(255.0 / np.sqrt(mse))
+
+
+def t_schedule(M):
+    """t values of a x M window (utils.py:558): linspace(1/M, 1-1/M, M-1) as float32."""
+    return np.linspace(1 / M, 1 - 1 / M, M - 1).astype(np.float32)
