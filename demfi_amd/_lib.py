@@ -1,0 +1,115 @@
+"""ctypes binding of libdemfi_hip.so (include/demfi_hip.h).
+
+The HIP library is the product; there is no CPU fallback.  ``load()`` raises ``RuntimeError`` when the
+shared object is missing, and every call that returns a negative status raises with the library's message.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libdemfi_hip.so')
+
+F16, F32 = 0, 1
+ACT_NONE, ACT_RELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3
+MODE_STORE, MODE_MUL, MODE_GRU = 0, 1, 2
+MAX_PIECES, MAX_CHUNKS, MAX_SEGS, MAX_OCTS = 48, 40, 8, 32
+
+
+class View(C.Structure):
+    _fields_ = [('ptr', C.c_void_p), ('sx', C.c_int64), ('sy', C.c_int64), ('sc', C.c_int64), ('sb', C.c_int64),
+                ('is_f32', C.c_int32), ('_pad', C.c_int32)]
+
+
+class Piece(C.Structure):
+    _fields_ = [('v', View), ('nch', C.c_int32), ('lds_ch', C.c_int32), ('up_shift', C.c_int32), ('fat', C.c_int32)]
+
+
+class Chunk(C.Structure):
+    _fields_ = [('first_piece', C.c_int32), ('n_pieces', C.c_int32), ('nks', C.c_int32), ('_pad', C.c_int32),
+                ('w_off', C.c_int64)]
+
+
+class Seg(C.Structure):
+    _fields_ = [('dst', View), ('res', View), ('aux', View), ('act', C.c_int32), ('mode', C.c_int32),
+                ('scale', C.c_int32), ('dy', C.c_int32), ('dx', C.c_int32), ('_pad', C.c_int32)]
+
+
+class Conv(C.Structure):
+    _fields_ = [('dtype', C.c_int32), ('H', C.c_int32), ('W', C.c_int32), ('inH', C.c_int32), ('inW', C.c_int32),
+                ('kh', C.c_int32), ('kw', C.c_int32), ('stride', C.c_int32), ('pad_y', C.c_int32),
+                ('pad_x', C.c_int32), ('batch', C.c_int32), ('cout_pad', C.c_int32), ('nco', C.c_int32),
+                ('rec_bytes', C.c_int32), ('n_chunks', C.c_int32), ('n_pieces', C.c_int32), ('n_segs', C.c_int32),
+                ('_pad', C.c_int32), ('w_blk_stride', C.c_int64), ('wpack', C.c_void_p), ('bias', C.c_void_p),
+                ('chunks', Chunk * MAX_CHUNKS), ('pieces', Piece * MAX_PIECES), ('segs', Seg * MAX_SEGS),
+                ('oct_seg', C.c_int32 * MAX_OCTS), ('oct_n', C.c_int32 * MAX_OCTS), ('oct_ch', C.c_int32 * MAX_OCTS),
+                ('lw_magic', C.c_uint32), ('_pad2', C.c_uint32)]
+
+
+_SIGS = {
+    'demfi_abi_version': (C.c_int, []),
+    'demfi_last_error': (C.c_char_p, []),
+    'demfi_device_info': (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
+    'demfi_pack_conv_weights': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                          C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                          C.POINTER(C.c_int64)]),
+    'demfi_conv_lds_bytes': (C.c_int64, [C.POINTER(Conv)]),
+    'demfi_conv2d': (C.c_int, [C.POINTER(Conv), C.c_void_p, C.c_void_p]),
+    'demfi_space_to_depth': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    'demfi_reflect_pad': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    'demfi_overlay_mean': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    'demfi_cfr_flow_align': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p]),
+    'demfi_warp_blend': (C.c_int, [C.POINTER(View), C.c_void_p, C.POINTER(View), C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.POINTER(View), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'demfi_fgac_gather': (C.c_int, [C.POINTER(View), C.c_void_p, C.POINTER(View), C.c_int, C.c_int, C.c_int,
+                                    C.c_void_p, C.c_void_p]),
+    'demfi_gate_blend': (C.c_int, [C.c_void_p, C.POINTER(View), C.POINTER(View), C.POINTER(View), C.c_int, C.c_int,
+                                   C.c_int, C.c_void_p]),
+    'demfi_graph_begin': (C.c_int, [C.c_void_p]),
+    'demfi_graph_end': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    'demfi_graph_launch': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'demfi_graph_destroy': (C.c_int, [C.c_void_p]),
+}
+
+EXPORTS = tuple(_SIGS)
+_lib = None
+
+
+class DemfiError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libdemfi_hip.so (once).  Fails loudly: the HIP extension IS the forward path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError('demfi_amd: %s not found -- build it with demfi_amd/csrc/build.sh (or '
+                           '__graft_entry__.build()); there is no CPU/PyTorch fallback for the forward path'
+                           % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)          # AttributeError if the library lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if lib.demfi_abi_version() != 1:
+        raise RuntimeError('demfi_amd: ABI version mismatch')
+    _lib = lib
+    return lib
+
+
+def check(status, what=''):
+    if status < 0:
+        raise DemfiError('%s failed (%d): %s' % (what or 'libdemfi_hip call', status,
+                                                 load().demfi_last_error().decode(errors='replace')))
+    return status
+
+
+def device_info():
+    lib = load()
+    name = C.create_string_buffer(64)
+    ncu = C.c_int(0)
+    mem = C.c_int64(0)
+    st = lib.demfi_device_info(name, 64, C.byref(ncu), C.byref(mem))
+    return st, name.value.decode(), ncu.value, mem.value

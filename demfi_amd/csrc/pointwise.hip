@@ -1,0 +1,446 @@
+// Memory-bound kernels of the DeMFI-Net_rb forward path for gfx950: space-to-depth, reflect pad, the
+// complementary-flow-reversal splat, backward warp + occlusion blend, FGAC gather and the Eq.(4) gate blend.
+// Built with -ffp-contract=off: the coordinate arithmetic must round exactly like the reference's
+// step-by-step fp32 tensor ops so that the integer index / validity maps are bit-identical.
+#include "common.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+inline unsigned blocks_for(int64_t n) { return (unsigned)((n + NT - 1) / NT); }
+
+// ------------------------------------------------------------------------------------------------------
+// pixel_reshuffle(cat(B0,B1,B-1,B2), 2)  (DeMFInet.py:234-235, 290-316)
+// thread = (plane fc = frame*3 + c, h, w): reads the 2x2 block of one plane, writes 4 adjacent channels.
+template <typename T>
+__global__ void s2d_kernel(const float* __restrict__ x, T* __restrict__ out, int H, int W)
+{
+    const int H2 = H >> 1, W2 = W >> 1;
+    const int64_t n = (int64_t)12 * H2 * W2;
+    const int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x;
+    if (i >= n) return;
+    const int w = (int)(i % W2);
+    const int h = (int)((i / W2) % H2);
+    const int fc = (int)(i / ((int64_t)W2 * H2));
+    const int f = fc / 3, c = fc - f * 3;
+    const float* p = x + ((int64_t)(c * 4 + f) * H + 2 * h) * W + 2 * w;     // x is [3,4,H,W]
+    const float2 r0 = *(const float2*)p;
+    const float2 r1 = *(const float2*)(p + W);
+    T* o = out + ((int64_t)h * W2 + w) * 48 + fc * 4;
+    o[0] = (T)r0.x; o[1] = (T)r0.y; o[2] = (T)r1.x; o[3] = (T)r1.y;
+}
+
+// F.pad(mode="reflect") bottom/right (utils.py:1363)
+__global__ void reflect_pad_kernel(const float* __restrict__ x, float* __restrict__ out, int planes, int h, int w,
+                                   int H, int W)
+{
+    const int64_t n = (int64_t)planes * H * W;
+    const int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x;
+    if (i >= n) return;
+    const int X = (int)(i % W);
+    const int Y = (int)((i / W) % H);
+    const int p = (int)(i / ((int64_t)W * H));
+    const int sx = X < w ? X : 2 * (w - 1) - X;
+    const int sy = Y < h ? Y : 2 * (h - 1) - Y;
+    out[i] = x[((int64_t)p * h + sy) * w + sx];
+}
+
+// torch.mean(x[:, :, 0:2], dim=2)  (DeMFInet.py:178)
+__global__ void overlay_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t hw)
+{
+    const int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x;
+    if (i >= 3 * hw) return;
+    const int c = (int)(i / hw);
+    const int64_t r = i - c * hw;
+    out[i] = (x[(int64_t)(c * 4) * hw + r] + x[(int64_t)(c * 4 + 1) * hw + r]) / 2.0f;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Forward splat of CFR (fwarp / sample_one, DeMFInet.py:625-729).  One thread per SOURCE pixel and flow.
+// acc layout: [flow k][3 = img0, img1, weight][H*W] int64, 2^-32 fixed point -> order-independent sums.
+constexpr double FIX = 4294967296.0;
+
+__global__ void cfr_splat_kernel(const float* __restrict__ flow01, const float* __restrict__ flow10,
+                                 const float* __restrict__ tptr, int H, int W, long long* __restrict__ acc,
+                                 int* __restrict__ dbg)
+{
+    const int64_t hw = (int64_t)H * W;
+    const int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x;
+    if (i >= 2 * hw) return;
+    const int k = (int)(i / hw);
+    const int64_t pix = i - k * hw;
+    const int y = (int)(pix / W), x = (int)(pix - (int64_t)y * W);
+    const float t = *tptr;
+    const float sc = k == 0 ? t : 1.0f - t;                 // fwarp(flow_01, t*flow_01), fwarp(flow_10, (1-t)*flow_10)
+    const float* fl = k == 0 ? flow01 : flow10;
+    const float v0 = fl[pix], v1 = fl[hw + pix];
+    const float fy = sc * v0;                               // "y": column displacement (flo[:,0], 647)
+    const float fx = sc * v1;                               // "x": row displacement    (flo[:,1], 648)
+    const float x1 = floorf(fx), y1 = floorf(fy);
+    long long* a = acc + (int64_t)k * 3 * hw;
+#pragma unroll
+    for (int cidx = 0; cidx < 4; ++cidx) {                  // (x1,y1) (x1,y2) (x2,y1) (x2,y2): 663-666
+        const float xs = x1 + (float)(cidx >> 1), ys = y1 + (float)(cidx & 1);
+        const float dx = fx - xs, dy = fy - ys;
+        const float w = expf(-(dx * dx + dy * dy));         // get_gaussian_weights, 674-680
+        int flat = -1;
+        if (fabsf(xs) < 1.0e9f && fabsf(ys) < 1.0e9f) {
+            const long long r = (long long)xs + y, c = (long long)ys + x;     // idxx / idxy, 712-713
+            if (r >= 0 && r < H && c >= 0 && c < W) flat = (int)(r * W + c);  // mask, 716
+        }
+        if (dbg) dbg[((int64_t)k * 4 + cidx) * hw + pix] = flat;
+        if (flat >= 0) {
+            const float p0 = v0 * w, p1 = v1 * w;           // flat_img * flat_weight (fp32), 724
+            atomicAdd((unsigned long long*)(a + flat), (unsigned long long)__double2ll_rn((double)p0 * FIX));
+            atomicAdd((unsigned long long*)(a + hw + flat), (unsigned long long)__double2ll_rn((double)p1 * FIX));
+            atomicAdd((unsigned long long*)(a + 2 * hw + flat), (unsigned long long)__double2ll_rn((double)w * FIX));
+        }
+    }
+}
+
+// Linear combination + normalisation of CFR (DeMFInet.py:614-620), every op one fp32 rounding.
+__global__ void cfr_finish_kernel(const long long* __restrict__ acc, const float* __restrict__ tptr, int64_t hw,
+                                  float* __restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x;
+    if (i >= hw) return;
+    const float t = *tptr;
+    const float omt = 1.0f - t;
+    const double inv = 1.0 / FIX;
+    float f01[2], f10[2];
+    f01[0] = (float)((double)acc[i] * inv);
+    f01[1] = (float)((double)acc[hw + i] * inv);
+    const float n0 = (float)((double)acc[2 * hw + i] * inv);
+    f10[0] = (float)((double)acc[3 * hw + i] * inv);
+    f10[1] = (float)((double)acc[4 * hw + i] * inv);
+    const float n1 = (float)((double)acc[5 * hw + i] * inv);
+    const float norm = omt * n0 + t * n1;                                   // 617
+    const float m = norm > 0.0f ? 1.0f : 0.0f;                              // 618
+    const float ca = (-omt) * t, cb = t * t, cc = omt * omt, cd = t * omt;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        float ft0 = ca * f01[c] + cb * f10[c];                              // 614
+        float ft1 = cc * f01[c] - cd * f10[c];                              // 615
+        ft0 = (1.0f - m) * ft0 + m * (ft0 / (norm + (1.0f - m)));           // 619
+        ft1 = (1.0f - m) * ft1 + m * (ft1 / (norm + (1.0f - m)));           // 620
+        out[(int64_t)c * hw + i] = ft0;
+        out[(int64_t)(2 + c) * hw + i] = ft1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// bwarp coordinates of one pixel (DeMFInet.py:744-754 + ATen unnormalize) -> SampleMap + validity bit.
+__device__ __forceinline__ SampleMap bwarp_map(int x, int y, float fx, float fy, int H, int W, bool& valid)
+{
+    const float px = (float)x + fx, py = (float)y + fy;
+    const float ix = unnormalized_coord(px, (float)max(W - 1, 1), (float)(W - 1));
+    const float iy = unnormalized_coord(py, (float)max(H - 1, 1), (float)(H - 1));
+    SampleMap m = make_sample_map(ix, iy, H, W);
+    const float s = ((m.w[0] + m.w[1]) + m.w[2]) + m.w[3];      // grid_sample of the all-ones image (758-759)
+    valid = !(s < 0.999f) && s > 0.0f;                          // masked_fill_ x2 (763-764)
+    return m;
+}
+
+__device__ __forceinline__ void dbg_store(int* dbg, int which, int64_t hw, int64_t pix, const SampleMap& m, bool valid)
+{
+    int* d = dbg + (int64_t)which * 3 * hw;
+    d[pix] = m.x0;
+    d[hw + pix] = m.y0;
+    d[2 * hw + pix] = m.inb | (valid ? 16 : 0);
+}
+
+template <typename T> struct Vec16;
+template <> struct Vec16<half_t> { static constexpr int N = 8; };
+template <> struct Vec16<float> { static constexpr int N = 4; };
+
+template <typename T>
+__device__ __forceinline__ void gather4(const char* base, int64_t sx, int64_t sy, const SampleMap& m, float* o)
+{
+    constexpr int N = Vec16<T>::N;
+#pragma unroll
+    for (int j = 0; j < N; ++j) o[j] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (m.inb & (1 << k)) {
+            const char* p = base + (int64_t)(m.y0 + (k >> 1)) * sy + (int64_t)(m.x0 + (k & 1)) * sx;
+            const uint4 raw = *(const uint4*)p;
+            if constexpr (sizeof(T) == 2) {
+                const h8_t v = __builtin_bit_cast(h8_t, raw);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = o[j] + (float)v[j] * m.w[k];
+            } else {
+                const f4_t v = __builtin_bit_cast(f4_t, raw);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = o[j] + v[j] * m.w[k];
+            }
+        }
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ void store16(char* p, const float* v)
+{
+    if constexpr (sizeof(T) == 2) {
+        h8_t o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (half_t)v[j];
+        *(uint4*)p = __builtin_bit_cast(uint4, o);
+    } else {
+        f4_t o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = v[j];
+        *(uint4*)p = __builtin_bit_cast(uint4, o);
+    }
+}
+
+// Fat (NHWC) warp+blend: LPP = C*sizeof(T)/16 consecutive lanes share one pixel, each owns 16 bytes of channels.
+template <typename T>
+__global__ void warp_blend_fat_kernel(demfi_view A, const float* __restrict__ fa, demfi_view B,
+                                      const float* __restrict__ fb, const float* __restrict__ logit,
+                                      const float* __restrict__ tptr, demfi_view O, int lpp_shift, int H, int W,
+                                      float* __restrict__ occ_out, int* __restrict__ dbg)
+{
+    constexpr int N = Vec16<T>::N;
+    const int64_t hw = (int64_t)H * W;
+    const int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x;
+    const int64_t pix = i >> lpp_shift;
+    if (pix >= hw) return;
+    const int part = (int)(i & ((1 << lpp_shift) - 1));
+    const int y = (int)(pix / W), x = (int)(pix - (int64_t)y * W);
+    bool va, vb;
+    const SampleMap ma = bwarp_map(x, y, fa[pix], fa[hw + pix], H, W, va);
+    const SampleMap mb = bwarp_map(x, y, fb[pix], fb[hw + pix], H, W, vb);
+    const float t = *tptr;
+    const float o0 = sigmoidf_(logit[pix]);
+    const float o1 = 1.0f - o0;
+    if (part == 0) {
+        if (occ_out) occ_out[pix] = o0;
+        if (dbg) { dbg_store(dbg, 0, hw, pix, ma, va); dbg_store(dbg, 1, hw, pix, mb, vb); }
+    }
+    float wa[N], wb[N], r[N];
+    gather4<T>((const char*)A.ptr + part * 16, A.sx * sizeof(T), A.sy * sizeof(T), ma, wa);
+    gather4<T>((const char*)B.ptr + part * 16, B.sx * sizeof(T), B.sy * sizeof(T), mb, wb);
+    const float ka = (1.0f - t) * o0, kb = t * o1;
+    const float den = ka + kb;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        const float a = va ? wa[j] : 0.0f, b = vb ? wb[j] : 0.0f;       // output * mask (766)
+        r[j] = (ka * a + kb * b) / den;                                  // Eq.(2)
+    }
+    store16<T>((char*)O.ptr + ((int64_t)y * O.sy + (int64_t)x * O.sx) * sizeof(T) + part * 16, r);
+}
+
+// Thin (any strides) warp+blend, one thread per pixel, loops over C channels (C = 3 frames).
+__global__ void warp_blend_thin_kernel(demfi_view A, const float* __restrict__ fa, demfi_view B,
+                                       const float* __restrict__ fb, const float* __restrict__ logit,
+                                       const float* __restrict__ tptr, demfi_view O, int C, int H, int W,
+                                       float* __restrict__ occ_out, int* __restrict__ dbg)
+{
+    const int64_t hw = (int64_t)H * W;
+    const int64_t pix = (int64_t)blockIdx.x * NT + threadIdx.x;
+    if (pix >= hw) return;
+    const int y = (int)(pix / W), x = (int)(pix - (int64_t)y * W);
+    bool va, vb;
+    const SampleMap ma = bwarp_map(x, y, fa[pix], fa[hw + pix], H, W, va);
+    const SampleMap mb = bwarp_map(x, y, fb[pix], fb[hw + pix], H, W, vb);
+    const float t = *tptr;
+    const float o0 = sigmoidf_(logit[pix]);
+    const float o1 = 1.0f - o0;
+    if (occ_out) occ_out[pix] = o0;
+    if (dbg) { dbg_store(dbg, 0, hw, pix, ma, va); dbg_store(dbg, 1, hw, pix, mb, vb); }
+    const float ka = (1.0f - t) * o0, kb = t * o1;
+    const float den = ka + kb;
+    for (int c = 0; c < C; ++c) {
+        float a = 0.0f, b = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (ma.inb & (1 << k))
+                a = a + view_load(A, (int64_t)c * A.sc + (int64_t)(ma.y0 + (k >> 1)) * A.sy + (int64_t)(ma.x0 + (k & 1)) * A.sx) * ma.w[k];
+            if (mb.inb & (1 << k))
+                b = b + view_load(B, (int64_t)c * B.sc + (int64_t)(mb.y0 + (k >> 1)) * B.sy + (int64_t)(mb.x0 + (k & 1)) * B.sx) * mb.w[k];
+        }
+        a = va ? a : 0.0f;
+        b = vb ? b : 0.0f;
+        view_store(O, (int64_t)c * O.sc + (int64_t)y * O.sy + (int64_t)x * O.sx, (ka * a + kb * b) / den);
+    }
+}
+
+// FGAC sampling at absolute coordinates (DeMFInet.py:413-419, 499-508): one bilinear gather, no validity mask.
+template <typename T>
+__global__ void fgac_gather_kernel(demfi_view S, const float* __restrict__ flow, demfi_view O, int lpp_shift, int H,
+                                   int W, int* __restrict__ dbg)
+{
+    constexpr int N = Vec16<T>::N;
+    const int64_t hw = (int64_t)H * W;
+    const int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x;
+    const int64_t pix = i >> lpp_shift;
+    if (pix >= hw) return;
+    const int part = (int)(i & ((1 << lpp_shift) - 1));
+    const int y = (int)(pix / W), x = (int)(pix - (int64_t)y * W);
+    const float ix = unnormalized_coord(flow[pix], (float)(W - 1), (float)(W - 1));
+    const float iy = unnormalized_coord(flow[hw + pix], (float)(H - 1), (float)(H - 1));
+    const SampleMap m = make_sample_map(ix, iy, H, W);
+    if (dbg && part == 0) dbg_store(dbg, 0, hw, pix, m, true);
+    float r[N];
+    gather4<T>((const char*)S.ptr + part * 16, S.sx * sizeof(T), S.sy * sizeof(T), m, r);
+    store16<T>((char*)O.ptr + ((int64_t)y * O.sy + (int64_t)x * O.sx) * sizeof(T) + part * 16, r);
+}
+
+// Eq.(4): out = w*source + (1-w)*e  (DeMFInet.py:452)
+template <typename T>
+__global__ void gate_blend_kernel(const float* __restrict__ w, demfi_view S, demfi_view E, demfi_view O, int lpp_shift,
+                                  int H, int W)
+{
+    constexpr int N = Vec16<T>::N;
+    const int64_t hw = (int64_t)H * W;
+    const int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x;
+    const int64_t pix = i >> lpp_shift;
+    if (pix >= hw) return;
+    const int part = (int)(i & ((1 << lpp_shift) - 1));
+    const int y = (int)(pix / W), x = (int)(pix - (int64_t)y * W);
+    const float g = w[pix];
+    const uint4 sr = *(const uint4*)((const char*)S.ptr + ((int64_t)y * S.sy + (int64_t)x * S.sx) * sizeof(T) + part * 16);
+    const uint4 er = *(const uint4*)((const char*)E.ptr + ((int64_t)y * E.sy + (int64_t)x * E.sx) * sizeof(T) + part * 16);
+    float r[N];
+    if constexpr (sizeof(T) == 2) {
+        const h8_t s = __builtin_bit_cast(h8_t, sr), e = __builtin_bit_cast(h8_t, er);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = g * (float)s[j] + (1.0f - g) * (float)e[j];
+    } else {
+        const f4_t s = __builtin_bit_cast(f4_t, sr), e = __builtin_bit_cast(f4_t, er);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[j] = g * s[j] + (1.0f - g) * e[j];
+    }
+    store16<T>((char*)O.ptr + ((int64_t)y * O.sy + (int64_t)x * O.sx) * sizeof(T) + part * 16, r);
+}
+
+// A fat view usable by the 16-byte-per-lane kernels: NHWC (sc == 1), C*elt a power-of-two multiple of 16 B.
+int fat_lpp_shift(const demfi_view* v, int C, const char* who, int* is_f32)
+{
+    if (!v || !v->ptr || v->sc != 1) return demfi_set_error(DEMFI_ERR_ARG, "%s: view is not NHWC", who);
+    const int bytes = C * (v->is_f32 ? 4 : 2);
+    const int lpp = bytes / 16;
+    if (bytes % 16 || lpp < 1 || (lpp & (lpp - 1))) return demfi_set_error(DEMFI_ERR_ARG, "%s: C=%d not vectorisable", who, C);
+    *is_f32 = v->is_f32;
+    int s = 0;
+    while ((1 << s) < lpp) ++s;
+    return s;
+}
+
+}  // namespace
+
+extern "C" int demfi_space_to_depth(const float* x, void* out, int dtype, int H, int W, void* stream)
+{
+    if (!x || !out || H <= 0 || W <= 0 || (H & 1) || (W & 1)) return demfi_set_error(DEMFI_ERR_ARG, "demfi_space_to_depth: bad args");
+    const int64_t n = (int64_t)12 * (H / 2) * (W / 2);
+    if (dtype == DEMFI_F16)
+        hipLaunchKernelGGL(s2d_kernel<half_t>, dim3(blocks_for(n)), dim3(NT), 0, (hipStream_t)stream, x, (half_t*)out, H, W);
+    else if (dtype == DEMFI_F32)
+        hipLaunchKernelGGL(s2d_kernel<float>, dim3(blocks_for(n)), dim3(NT), 0, (hipStream_t)stream, x, (float*)out, H, W);
+    else
+        return demfi_set_error(DEMFI_ERR_ARG, "demfi_space_to_depth: dtype");
+    DEMFI_HIP_CHECK(hipGetLastError());
+    return DEMFI_OK;
+}
+
+extern "C" int demfi_reflect_pad(const float* x, float* out, int planes, int h, int w, int H, int W, void* stream)
+{
+    if (!x || !out || planes <= 0 || h < 2 || w < 2 || H < h || W < w || H - h >= h || W - w >= w)
+        return demfi_set_error(DEMFI_ERR_ARG, "demfi_reflect_pad: bad sizes %dx%d -> %dx%d", h, w, H, W);
+    hipLaunchKernelGGL(reflect_pad_kernel, dim3(blocks_for((int64_t)planes * H * W)), dim3(NT), 0, (hipStream_t)stream,
+                       x, out, planes, h, w, H, W);
+    DEMFI_HIP_CHECK(hipGetLastError());
+    return DEMFI_OK;
+}
+
+extern "C" int demfi_overlay_mean(const float* x, float* out, int H, int W, void* stream)
+{
+    if (!x || !out || H <= 0 || W <= 0) return demfi_set_error(DEMFI_ERR_ARG, "demfi_overlay_mean: bad args");
+    hipLaunchKernelGGL(overlay_kernel, dim3(blocks_for((int64_t)3 * H * W)), dim3(NT), 0, (hipStream_t)stream, x, out,
+                       (int64_t)H * W);
+    DEMFI_HIP_CHECK(hipGetLastError());
+    return DEMFI_OK;
+}
+
+extern "C" int demfi_cfr_flow_align(const float* flow01, const float* flow10, const float* t, int H, int W,
+                                    int64_t* acc, float* out, int32_t* dbg_idx, void* stream)
+{
+    if (!flow01 || !flow10 || !t || !acc || !out || H <= 0 || W <= 0 || (int64_t)H * W >= (1ll << 31))
+        return demfi_set_error(DEMFI_ERR_ARG, "demfi_cfr_flow_align: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t hw = (int64_t)H * W;
+    DEMFI_HIP_CHECK(hipMemsetAsync(acc, 0, sizeof(int64_t) * 6 * hw, st));
+    hipLaunchKernelGGL(cfr_splat_kernel, dim3(blocks_for(2 * hw)), dim3(NT), 0, st, flow01, flow10, t, H, W,
+                       (long long*)acc, dbg_idx);
+    hipLaunchKernelGGL(cfr_finish_kernel, dim3(blocks_for(hw)), dim3(NT), 0, st, (const long long*)acc, t, hw, out);
+    DEMFI_HIP_CHECK(hipGetLastError());
+    return DEMFI_OK;
+}
+
+extern "C" int demfi_warp_blend(const demfi_view* A, const float* fa, const demfi_view* B, const float* fb,
+                                const float* logit, const float* t, const demfi_view* out, int C, int H, int W,
+                                float* occ_out, int32_t* dbg_maps, void* stream)
+{
+    if (!A || !B || !out || !A->ptr || !B->ptr || !out->ptr || !fa || !fb || !logit || !t || C <= 0 || H <= 0 || W <= 0)
+        return demfi_set_error(DEMFI_ERR_ARG, "demfi_warp_blend: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t hw = (int64_t)H * W;
+    const bool fat = A->sc == 1 && B->sc == 1 && out->sc == 1 && A->is_f32 == B->is_f32 && A->is_f32 == out->is_f32
+                     && (C * (A->is_f32 ? 4 : 2)) % 16 == 0;
+    if (fat) {
+        int f32 = 0;
+        const int sh = fat_lpp_shift(A, C, "demfi_warp_blend", &f32);
+        if (sh < 0) return sh;
+        const int64_t n = hw << sh;
+        if (f32)
+            hipLaunchKernelGGL(warp_blend_fat_kernel<float>, dim3(blocks_for(n)), dim3(NT), 0, st, *A, fa, *B, fb, logit, t,
+                               *out, sh, H, W, occ_out, dbg_maps);
+        else
+            hipLaunchKernelGGL(warp_blend_fat_kernel<half_t>, dim3(blocks_for(n)), dim3(NT), 0, st, *A, fa, *B, fb, logit,
+                               t, *out, sh, H, W, occ_out, dbg_maps);
+    } else {
+        hipLaunchKernelGGL(warp_blend_thin_kernel, dim3(blocks_for(hw)), dim3(NT), 0, st, *A, fa, *B, fb, logit, t, *out, C,
+                           H, W, occ_out, dbg_maps);
+    }
+    DEMFI_HIP_CHECK(hipGetLastError());
+    return DEMFI_OK;
+}
+
+extern "C" int demfi_fgac_gather(const demfi_view* src, const float* flow, const demfi_view* out, int C, int H, int W,
+                                 int32_t* dbg_maps, void* stream)
+{
+    if (!src || !out || !flow || H <= 1 || W <= 1) return demfi_set_error(DEMFI_ERR_ARG, "demfi_fgac_gather: bad args");
+    int f32 = 0, f32o = 0;
+    const int sh = fat_lpp_shift(src, C, "demfi_fgac_gather", &f32);
+    if (sh < 0) return sh;
+    if (fat_lpp_shift(out, C, "demfi_fgac_gather", &f32o) != sh || f32o != f32)
+        return demfi_set_error(DEMFI_ERR_ARG, "demfi_fgac_gather: src/out type mismatch");
+    const int64_t n = ((int64_t)H * W) << sh;
+    hipStream_t st = (hipStream_t)stream;
+    if (f32)
+        hipLaunchKernelGGL(fgac_gather_kernel<float>, dim3(blocks_for(n)), dim3(NT), 0, st, *src, flow, *out, sh, H, W, dbg_maps);
+    else
+        hipLaunchKernelGGL(fgac_gather_kernel<half_t>, dim3(blocks_for(n)), dim3(NT), 0, st, *src, flow, *out, sh, H, W, dbg_maps);
+    DEMFI_HIP_CHECK(hipGetLastError());
+    return DEMFI_OK;
+}
+
+extern "C" int demfi_gate_blend(const float* w, const demfi_view* source, const demfi_view* e, const demfi_view* out,
+                                int C, int H, int W, void* stream)
+{
+    if (!w || !source || !e || !out) return demfi_set_error(DEMFI_ERR_ARG, "demfi_gate_blend: bad args");
+    int f32 = 0, f2 = 0, f3 = 0;
+    const int sh = fat_lpp_shift(source, C, "demfi_gate_blend", &f32);
+    if (sh < 0) return sh;
+    if (fat_lpp_shift(e, C, "demfi_gate_blend", &f2) != sh || fat_lpp_shift(out, C, "demfi_gate_blend", &f3) != sh || f2 != f32 || f3 != f32)
+        return demfi_set_error(DEMFI_ERR_ARG, "demfi_gate_blend: view type mismatch");
+    const int64_t n = ((int64_t)H * W) << sh;
+    hipStream_t st = (hipStream_t)stream;
+    if (f32)
+        hipLaunchKernelGGL(gate_blend_kernel<float>, dim3(blocks_for(n)), dim3(NT), 0, st, w, *source, *e, *out, sh, H, W);
+    else
+        hipLaunchKernelGGL(gate_blend_kernel<half_t>, dim3(blocks_for(n)), dim3(NT), 0, st, w, *source, *e, *out, sh, H, W);
+    DEMFI_HIP_CHECK(hipGetLastError());
+    return DEMFI_OK;
+}

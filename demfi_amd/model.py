@@ -1,0 +1,132 @@
+"""``DeMFInet`` -- the nn.Module surface of the reference on top of the HIP engine.
+
+Drop-in for /root/reference/DeMFInet.py:13-179 at inference: same constructor arguments (``args.gpu, nf,
+scale_factor, num_ResB_FACFB, num_ResB_Dec, shared_FGAC_flag, visualization_flag``), the same 260
+``state_dict`` keys / shapes so ``load_state_dict(ckpt['state_dict_Model'])``
+(main.py:316,351) works unchanged, the same ``forward(x, t_value, num_update=None, is_training=None)``
+signature and the same 5-tuple return structure (DeMFInet.py:178).  The body is not PyTorch: forward
+hands ``x`` to ``demfi_amd.engine.Engine`` which launches the gfx950 kernels of ``libdemfi_hip.so``.
+There is no CPU / eager fallback: without a GPU or without the built library forward raises.
+
+Additions over the reference surface:
+  * ``dtype`` (torch.float16 default for 720p throughput, torch.float32 for the strict-parity config);
+  * ``forward_window(x, t_values, num_update)``: one input window, several t -- the t-independent trunk
+    (FF_RDB + FAC-FB) runs once; results are identical to separate forward calls.
+"""
+import torch
+import torch.nn as nn
+
+from .spec import HyperParams, layer_table, weight_shape
+
+
+class _Node(nn.Module):
+    """Parameter container; attribute path == state_dict prefix."""
+
+
+def _register(root, dotted, tensor):
+    parts = dotted.split('.')
+    m = root
+    for p in parts[:-1]:
+        if p not in m._modules:
+            m.add_module(p, _Node())
+        m = m._modules[p]
+    m.register_parameter(parts[-1], nn.Parameter(tensor, requires_grad=False))
+
+
+class DeMFInet(nn.Module):
+    def __init__(self, args=None, dtype=torch.float16):
+        super().__init__()
+        args = args or HyperParams()
+        self.args = args
+        self.hp = HyperParams(getattr(args, 'gpu', 0), args.nf, args.scale_factor, args.num_ResB_FACFB,
+                              args.num_ResB_Dec, args.shared_FGAC_flag, getattr(args, 'visualization_flag', False))
+        self.device = torch.device('cuda:' + str(self.hp.gpu) if torch.cuda.is_available() else 'cpu')
+        self.nf = self.hp.nf
+        self.scale_factor = self.hp.scale_factor
+        self.path_dtype = dtype
+        for name, e in layer_table(self.hp).items():
+            _register(self, name + '.weight', torch.zeros(weight_shape(e)))
+            _register(self, name + '.bias', torch.zeros(e[0]))
+        self._engines = {}
+        self._weights_version = 0
+
+    # any state_dict load invalidates the repacked weights
+    def load_state_dict(self, *a, **k):
+        r = super().load_state_dict(*a, **k)
+        self._engines = {}
+        self._weights_version += 1
+        return r
+
+    def engine(self, H, W, num_update):
+        """Engine for a frame size (built on first use: weight repack + buffer allocation)."""
+        from .engine import Engine
+        if not torch.cuda.is_available():
+            raise RuntimeError('demfi_amd.DeMFInet.forward needs an MI355X: the forward path is HIP-only '
+                               '(no CPU fallback)')
+        key = (H, W, self.path_dtype)
+        eng = self._engines.get(key)
+        if eng is None or eng.N < num_update:
+            sd = {k: v.detach() for k, v in self.state_dict().items()}
+            eng = Engine(sd, H, W, self.path_dtype, self.device, max(num_update, 3), self.hp)
+            self._engines[key] = eng
+        return eng
+
+    def _collect(self, eng, n, clone):
+        c = (lambda z: z.clone()) if clone else (lambda z: z)
+        H, W = eng.H, eng.W
+        d1 = [c(eng.sharp1[3 * i:3 * i + 3].unsqueeze(0)) for i in range(3)]
+        fin = [[c(eng.finals[it, i].unsqueeze(0)) for i in range(3)] for it in range(n)]
+        flows = [c(eng.delta[i, 0:4].unsqueeze(0)) for i in range(n + 1)]
+        occs = [c(eng.occ[i:i + 1].unsqueeze(0)) for i in range(n + 1)]
+        return d1, fin, flows, occs, c(eng.overlay.unsqueeze(0))
+
+    def _check_input(self, x, t_value):
+        if x.dim() != 5 or x.shape[1] != 3 or x.shape[2] != 4:
+            raise ValueError('x must be [B,3,4,H,W], got %s' % (tuple(x.shape),))
+        if not x.is_cuda:
+            raise RuntimeError('demfi_amd.DeMFInet: input must live on the GPU (HIP-only path)')
+
+    @torch.no_grad()
+    def forward(self, x, t_value, num_update=None, is_training=None, clone_outputs=True):
+        """x [B,3,4,H,W] fp32 in [-1,1], frame order (B0,B1,B-1,B2); t_value [B,1] in (0,1)."""
+        if is_training:
+            raise NotImplementedError('training branch (DeMFInet.py:170-172) is outside the inference hot path')
+        if self.hp.visualization_flag:
+            raise NotImplementedError('visualization outputs (DeMFInet.py:174-176) are outside the hot path')
+        self._check_input(x, t_value)
+        n = 1 if num_update is None else int(num_update)          # DeMFInet.py:126-128
+        B, _, _, H, W = x.shape
+        eng = self.engine(H, W, n)
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        outs = []
+        for b in range(B):
+            eng.x.copy_(x[b].to(torch.float32), non_blocking=True)
+            eng.t_dev.copy_(t_value[b].reshape(-1)[:1].to(torch.float32), non_blocking=True)
+            eng.run_trunk(stream)
+            eng.run_t(stream, n)
+            outs.append(self._collect(eng, n, clone_outputs or B > 1))
+        if B == 1:
+            return outs[0]
+        cat = lambda xs: torch.cat(xs, 0)
+        return ([cat([o[0][i] for o in outs]) for i in range(3)],
+                [[cat([o[1][it][i] for o in outs]) for i in range(3)] for it in range(n)],
+                [cat([o[2][i] for o in outs]) for i in range(n + 1)],
+                [cat([o[3][i] for o in outs]) for i in range(n + 1)],
+                cat([o[4] for o in outs]))
+
+    @torch.no_grad()
+    def forward_window(self, x, t_values, num_update):
+        """One input window x [1,3,4,H,W], several time instants: trunk once, per-t segment per value.
+        Returns a list of the reference's 5-tuples (cloned)."""
+        self._check_input(x, None)
+        n = int(num_update)
+        eng = self.engine(x.shape[3], x.shape[4], n)
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        eng.x.copy_(x[0].to(torch.float32), non_blocking=True)
+        eng.run_trunk(stream)
+        res = []
+        for tv in t_values:
+            eng.t_dev.fill_(float(tv))
+            eng.run_t(stream, n)
+            res.append(self._collect(eng, n, True))
+        return res

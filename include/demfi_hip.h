@@ -1,0 +1,211 @@
+/*
+ * demfi_hip.h -- C ABI of libdemfi_hip.so: the MI355X (gfx950) kernels of the DeMFI-Net_rb forward path.
+ *
+ * The upstream reference (JihyongOh/DeMFI) has NO native / FFI boundary: its hot path is the Python
+ * nn.Module DeMFInet.forward (DeMFInet.py:46-179) calling stock ATen ops.  This header therefore defines
+ * the boundary a host binds instead of those ATen call sites.  Each entry
+ * point names the reference lines it replaces.  Rules of the ABI:
+ *   - extern "C", plain pointers + sizes, no torch / C++ types;
+ *   - every function returns 0 on success, a negative demfi_status otherwise, never throws;
+ *     demfi_last_error() returns a thread-local message for the last failure;
+ *   - the caller owns every buffer (device pointers unless stated otherwise); nothing is allocated
+ *     behind the caller's back except the hipGraph objects of demfi_graph_*;
+ *   - all launches go to the hipStream_t the caller passes (as void*), nothing synchronises.
+ *
+ * Data layouts
+ *   "fat"  tensors : NHWC, element type = the path dtype (DEMFI_F16 or DEMFI_F32), described by strides;
+ *   "thin" tensors : planar fp32 (the NCHW tensors the PyTorch host hands over / gets back:
+ *                    flows, occlusion logits, 3-channel frames).
+ * Both are described by demfi_view (element strides, so channel slices of wider buffers are views).
+ */
+#ifndef DEMFI_HIP_H
+#define DEMFI_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DEMFI_ABI_VERSION 1
+
+enum demfi_dtype { DEMFI_F16 = 0, DEMFI_F32 = 1 };
+
+enum demfi_status {
+    DEMFI_OK = 0,
+    DEMFI_ERR_ARG = -1,      /* malformed descriptor / unsupported shape */
+    DEMFI_ERR_HIP = -2,      /* a HIP runtime call failed (message holds hipGetErrorString) */
+    DEMFI_ERR_NODEV = -3     /* no gfx950 device visible */
+};
+
+enum demfi_act { DEMFI_ACT_NONE = 0, DEMFI_ACT_RELU = 1, DEMFI_ACT_TANH = 2, DEMFI_ACT_SIGMOID = 3 };
+
+/* Output modes of a convolution segment (v = conv + bias):
+ *   STORE : dst = act(v + res)                                  (res optional)
+ *   MUL   : dst = sigmoid(v) * res                              (GRU reset gate: r*h, DeMFInet.py:846-847)
+ *   GRU   : dst = (1 - aux) * res + aux * tanh(v)               (GRU update, aux = z, res = h; 847-848)      */
+enum demfi_mode { DEMFI_MODE_STORE = 0, DEMFI_MODE_MUL = 1, DEMFI_MODE_GRU = 2 };
+
+/* A strided 4-D view.  Strides are in ELEMENTS of the view's own type.  ptr already points at the
+ * first channel of the slice.  A NULL ptr means "absent" (or "zeros" for an input piece). */
+typedef struct demfi_view {
+    void*   ptr;
+    int64_t sx;        /* x -> x+1        */
+    int64_t sy;        /* y -> y+1        */
+    int64_t sc;        /* channel -> +1   (1 for NHWC fat views) */
+    int64_t sb;        /* batch image -> +1 */
+    int32_t is_f32;    /* element type of ptr: 1 = fp32, 0 = fp16 */
+    int32_t _pad;
+} demfi_view;
+
+/* One piece of a convolution's logical input-channel concatenation (replaces torch.cat). */
+typedef struct demfi_piece {
+    demfi_view v;
+    int32_t nch;       /* channels taken from v (v.ptr == NULL: nch zero channels)               */
+    int32_t lds_ch;    /* first channel of this piece inside its chunk                           */
+    int32_t up_shift;  /* 1: the piece is read through a nearest-neighbour x2 upsample
+                          (UNet decoder, DeMFInet.py:592,597,601), 0: direct                      */
+    int32_t fat;       /* 1: NHWC view of the path dtype, nch*elt % 16 == 0, 16-byte vector loads;
+                          0: generic element-wise loads (any strides, fp16 or fp32)               */
+} demfi_piece;
+
+#define DEMFI_MAX_PIECES 48
+#define DEMFI_MAX_CHUNKS 40
+#define DEMFI_MAX_SEGS    8
+#define DEMFI_MAX_OCTS   32     /* cout_pad / 8, cout_pad <= 256 */
+
+/* Input channels are consumed in chunks staged through LDS; a chunk is <= rec_bytes of channel data
+ * per pixel (a multiple of one MFMA k-step = 32 bytes = 16 fp16 or 8 fp32 channels). */
+typedef struct demfi_chunk {
+    int32_t first_piece;
+    int32_t n_pieces;
+    int32_t nks;        /* k-steps in this chunk (32 bytes of channel data each)                  */
+    int32_t _pad;
+    int64_t w_off;      /* offset of this chunk's packed weights, in 16-byte units, cout block 0  */
+} demfi_chunk;
+
+typedef struct demfi_seg {
+    demfi_view dst;
+    demfi_view res;     /* optional */
+    demfi_view aux;     /* optional */
+    int32_t act;        /* demfi_act, STORE mode only */
+    int32_t mode;       /* demfi_mode */
+    int32_t scale;      /* 1, or 2 = PixelShuffle(2) store (DeMFInet.py:229): dst pixel (2y+dy, 2x+dx) */
+    int32_t dy, dx;
+    int32_t _pad;
+} demfi_seg;
+
+/* Implicit-GEMM convolution on the matrix cores (replaces every nn.Conv2d / nn.Conv3d(1,k,k) call site
+ * of DeMFInet.py, SURVEY.md section 2.2 C1/C6-C12, together with the torch.cat / PixelShuffle /
+ * UpsamplingNearest2d / activation / residual ops around them). */
+typedef struct demfi_conv {
+    int32_t dtype;              /* path dtype (type of fat views and packed weights)               */
+    int32_t H, W;               /* OUTPUT height / width                                           */
+    int32_t inH, inW;           /* input height / width as the convolution sees it (after up_shift) */
+    int32_t kh, kw;
+    int32_t stride;             /* 1 or 2                                                          */
+    int32_t pad_y, pad_x;
+    int32_t batch;              /* images sharing weights (Conv3d depth of D1 / the two FAC-FB frames) */
+    int32_t cout_pad;           /* packed output channels, multiple of 32                          */
+    int32_t nco;                /* 32-cout subtiles per workgroup (1..5), cout_pad % (32*nco) == 0 */
+    int32_t rec_bytes;          /* LDS bytes of channel data per pixel per chunk (32/64/128)        */
+    int32_t n_chunks;
+    int32_t n_pieces;
+    int32_t n_segs;
+    int32_t _pad;
+    int64_t w_blk_stride;       /* packed-weight stride between cout blocks, 16-byte units         */
+    const void*  wpack;         /* packed weights, see demfi_pack_conv_weights                     */
+    const float* bias;          /* [cout_pad] fp32 in packed cout order                            */
+    demfi_chunk chunks[DEMFI_MAX_CHUNKS];
+    demfi_piece pieces[DEMFI_MAX_PIECES];
+    demfi_seg   segs[DEMFI_MAX_SEGS];
+    /* packed cout octet o = couts [8o, 8o+8): which segment, first channel inside the segment's views,
+     * number of valid channels (0 = padding octet, nothing stored). */
+    int32_t oct_seg[DEMFI_MAX_OCTS];
+    int32_t oct_n[DEMFI_MAX_OCTS];
+    int32_t oct_ch[DEMFI_MAX_OCTS];
+    /* magic = ceil(2^32 / LW), LW = (32-1)*stride + kw: exact px / LW for px < 2^16 (filled by host) */
+    uint32_t lw_magic;
+    uint32_t _pad2;
+} demfi_conv;
+
+/* ---- library / device ------------------------------------------------------------------------- */
+int         demfi_abi_version(void);
+const char* demfi_last_error(void);
+/* Fills name[len] with the device's gcnArchName; returns DEMFI_ERR_NODEV without a GPU. */
+int         demfi_device_info(char* name, int len, int* n_cu, int64_t* hbm_bytes);
+
+/* ---- weight repack (host memory in, host memory out) -------------------------------------------
+ * w_oihw : fp32 [cout, cin, kh, kw] (the state_dict tensor; Conv3d weights are passed squeezed).
+ * cin_map[n_k]   : original input channel feeding packed k index (chunk-concatenated order, every
+ *                  chunk padded to its k-step multiple), -1 = zero.
+ * chunk_nks[n_chunks] : k-steps per chunk (sum * chans_per_kstep == n_k).
+ * cout_map[cout_pad] : original output channel of packed cout, -1 = zero.
+ * Packed order: [cout_blk][chunk][tap = ky*kw+kx][kstep][subtile < nco][lane < 64][16 bytes]; lane l of
+ * a k-step holds, for cout = blk*32*nco + subtile*32 + (l & 31), the 8 fp16 (4 fp32) weights of packed
+ * channels kstep*16 + 8*(l>>5) + j (kstep*8 + 4*(l>>5) + j) -- the A fragment of
+ * v_mfma_f32_32x32x16_f16 (4 x v_mfma_f32_32x32x2_f32).
+ * Returns the packed size in bytes through out_bytes (call with out == NULL to size the buffer). */
+int demfi_pack_conv_weights(const float* w_oihw, int cout, int cin, int kh, int kw,
+                            const int32_t* cin_map, int n_k, const int32_t* chunk_nks, int n_chunks,
+                            const int32_t* cout_map, int cout_pad, int nco, int dtype,
+                            void* out, int64_t* out_bytes);
+
+/* LDS bytes one workgroup of demfi_conv2d needs for this descriptor (host-side helper). */
+int64_t demfi_conv_lds_bytes(const demfi_conv* host_desc);
+
+/* ---- kernels ----------------------------------------------------------------------------------- */
+/* host_desc: descriptor in host memory (grid sizing / validation); dev_desc: the same bytes in device
+ * memory (the kernel reads it through the scalar cache). */
+int demfi_conv2d(const demfi_conv* host_desc, const demfi_conv* dev_desc, void* stream);
+
+/* pixel_reshuffle(cat(B0,B1,B-1,B2), 2) (DeMFInet.py:234-235, 290-316): x fp32 [3,4,H,W] (C,T order of the
+ * module input, batch 1) -> fat NHWC [H/2, W/2, 48], channel = (frame*3 + c)*4 + ry*2 + rx. */
+int demfi_space_to_depth(const float* x, void* out, int dtype, int H, int W, void* stream);
+
+/* Reflect padding of the harness (utils.py:1360-1365): x [planes,h,w] -> out [planes,H,W], bottom/right. */
+int demfi_reflect_pad(const float* x, float* out, int planes, int h, int w, int H, int W, void* stream);
+
+/* torch.mean(x[:, :, 0:2], dim=2) (DeMFInet.py:178): x [3,4,H,W] -> out [3,H,W]. */
+int demfi_overlay_mean(const float* x, float* out, int H, int W, void* stream);
+
+/* CFR_flow_t_align (DeMFInet.py:606-622) = two forward splats (fwarp 625-671, sample_one 683-729) +
+ * the linear combination / normalisation.  flow01, flow10: planar fp32 [2,H,W]; t: device pointer to
+ * one fp32; acc: caller workspace of 6*H*W int64 (zeroed by this call); out: planar fp32 [4,H,W] =
+ * (flow_t0, flow_t1).  The splat accumulates in 64-bit fixed point (2^-32 resolution) so the result
+ * does not depend on the order of the atomic adds.  dbg_idx (optional, may be NULL): int32
+ * [2 flows][4 corners][H*W] flat target index of every source pixel, -1 where masked off
+ * (sample_one's ids / mask, DeMFInet.py:712-719) for the index-parity tests. */
+int demfi_cfr_flow_align(const float* flow01, const float* flow10, const float* t, int H, int W,
+                         int64_t* acc, float* out, int32_t* dbg_idx, void* stream);
+
+/* Eq.(2): two backward warps (bwarp, DeMFInet.py:732-766) blended with the occlusion map
+ * (DeMFInet.py:66-71, 90-93, 146-149):
+ *   o0 = sigmoid(logit); out = ((1-t) o0 bwarp(A,fa) + t (1-o0) bwarp(B,fb)) / ((1-t) o0 + t (1-o0)).
+ * A, B, out: views with C channels (fat NHWC of the path dtype, or thin planar fp32); fa, fb: planar
+ * fp32 [2,H,W]; logit: planar fp32 [H,W]; t: device fp32.  occ_out (optional): sigmoid(logit) [H,W].
+ * dbg_maps (optional): int32 [2 warps][3][H*W] = floor x index, floor y index, bit0-3 in-bounds of
+ * (nw,ne,sw,se) | bit4 validity mask -- the integer maps of grid_sample for the index-parity tests. */
+int demfi_warp_blend(const demfi_view* A, const float* fa, const demfi_view* B, const float* fb,
+                     const float* logit, const float* t, const demfi_view* out, int C, int H, int W,
+                     float* occ_out, int32_t* dbg_maps, void* stream);
+
+/* bilinear_sampler at ABSOLUTE flow coordinates (FGAC, DeMFInet.py:413-419, 499-514; rr = sr = 0):
+ * src, out fat views with C channels; flow planar fp32 [2,H,W]. */
+int demfi_fgac_gather(const demfi_view* src, const float* flow, const demfi_view* out, int C, int H,
+                      int W, int32_t* dbg_maps, void* stream);
+
+/* Eq.(4) gate blend (DeMFInet.py:452): out = w*source + (1-w)*e; w planar fp32 [H,W]. */
+int demfi_gate_blend(const float* w, const demfi_view* source, const demfi_view* e, const demfi_view* out,
+                     int C, int H, int W, void* stream);
+
+/* ---- hipGraph capture of a launch sequence ------------------------------------------------------ */
+int demfi_graph_begin(void* stream);
+int demfi_graph_end(void* stream, void** graph_exec_out);
+int demfi_graph_launch(void* graph_exec, void* stream);
+int demfi_graph_destroy(void* graph_exec);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEMFI_HIP_H */

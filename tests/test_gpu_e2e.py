@@ -1,0 +1,124 @@
+"""End-to-end parity of the HIP forward on a real MI355X against the fixtures frozen from the upstream
+reference (tests/golden, fp32: |dPSNR| <= 1e-3 dB, the north star's tolerance) and against the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from demfi_amd import DeMFInet, HyperParams, synthetic_state_dict, synthetic_window   # noqa: E402
+from demfi_amd.harness import pad_forward_crop                                        # noqa: E402
+from oracle import demfi_oracle as O                                                  # noqa: E402
+
+DEV = 'cuda:0'
+E2E = ['e2e_64x96_t0500_n3', 'e2e_64x96_t0125_n1', 'e2e_64x96_t0875_n2', 'e2e_32x64_t0375_n5']
+
+
+def _model(dtype, sd=None):
+    m = DeMFInet(HyperParams(), dtype=dtype)
+    m.load_state_dict(sd or synthetic_state_dict(0))
+    return m.to(DEV).eval()
+
+
+@pytest.fixture(scope='module')
+def model32():
+    return _model(torch.float32)
+
+
+@pytest.fixture(scope='module')
+def model16():
+    return _model(torch.float16)
+
+
+def test_fp32_matches_reference_goldens(golden_dir, model32):
+    for name in E2E:
+        g = np.load(os.path.join(golden_dir, name + '.npz'))
+        N = int(g['N'])
+        x = synthetic_window(int(g['H']), int(g['W']), int(g['seed']))
+        d1, fin, flows, occs, ov = model32(x.to(DEV), torch.tensor([[float(g['t'])]], device=DEV), N)
+        assert len(fin) == N and len(flows) == N + 1 and len(occs) == N + 1
+        gt = x[0, :, 0].numpy()
+        for i in range(3):
+            assert tuple(d1[i].shape) == (1, 3, int(g['H']), int(g['W']))
+            assert np.abs(d1[i][0].cpu().numpy() - g['d1'][i]).max() < 2e-4, name
+            for it in range(N):
+                got = fin[it][i][0].cpu().numpy()
+                assert np.abs(got - g['finals'][it, i]).max() < 3e-4, (name, it, i)
+                assert abs(O.psnr(got, gt) - O.psnr(g['finals'][it, i], gt)) <= 1e-3      # north-star criterion
+                assert O.psnr(got, g['finals'][it, i]) > 80.0
+        for i in range(N + 1):
+            assert np.abs(flows[i][0].cpu().numpy() - g['flows'][i]).max() < 5e-4, name
+            assert np.abs(occs[i][0].cpu().numpy() - g['occs'][i]).max() < 2e-4, name
+        assert np.array_equal(ov[0].cpu().numpy(), g['overlay'])
+
+
+def test_harness_pad_crop(golden_dir, model32):
+    g = np.load(os.path.join(golden_dir, 'harness_50x70_t0625_n1.npz'))
+    x = synthetic_window(50, 70, 5)
+    d1, fin, flows, occs, ov = pad_forward_crop(model32, x.to(DEV), torch.tensor([[0.625]], device=DEV), 1)
+    assert tuple(fin[0][2].shape) == (1, 3, 50, 70)
+    for i in range(3):
+        assert np.abs(fin[0][i][0].cpu().numpy() - g['finals'][0, i]).max() < 3e-4
+    assert np.abs(flows[1][0].cpu().numpy() - g['flows'][1]).max() < 5e-4
+
+
+def test_fp32_vs_oracle_larger_frame_and_determinism(model32):
+    sd = synthetic_state_dict(0)
+    H, W, N = 96, 160, 3
+    x = synthetic_window(H, W, 7)
+    t = torch.tensor([[0.25]])
+    a = model32(x.to(DEV), t.to(DEV), N)
+    b = model32(x.to(DEV), t.to(DEV), N)
+    with torch.no_grad():
+        ref = O.forward(sd, x, t, N)
+    gt = x[0, :, 1].numpy()
+    for i in range(3):
+        assert torch.equal(a[1][N - 1][i], b[1][N - 1][i])                      # run-to-run bit identical
+        got = a[1][N - 1][i][0].cpu().numpy()
+        assert abs(O.psnr(got, gt) - O.psnr(ref[1][N - 1][i][0].numpy(), gt)) <= 1e-3
+    assert (a[2][N][0].cpu() - ref[2][N][0]).abs().max() < 2e-3
+
+
+def test_forward_window_equals_forward(model32):
+    H, W, N = 64, 64, 2
+    x = synthetic_window(H, W, 8).to(DEV)
+    ts = [0.125, 0.5, 0.875]
+    win = model32.forward_window(x, ts, N)
+    for tv, w in zip(ts, win):
+        single = model32(x, torch.tensor([[tv]], device=DEV), N)
+        for i in range(3):
+            assert torch.equal(w[1][N - 1][i], single[1][N - 1][i])
+        assert torch.equal(w[2][N], single[2][N])
+
+
+def test_batch_of_two_and_non_shared_fgac():
+    hp = HyperParams(shared_FGAC_flag=False)
+    sd = synthetic_state_dict(3, hp)
+    m = DeMFInet(hp, dtype=torch.float32)
+    m.load_state_dict(sd)
+    m = m.to(DEV).eval()
+    x = torch.cat([synthetic_window(32, 32, 6), synthetic_window(32, 32, 16)], 0)
+    t = torch.tensor([[0.5], [0.25]])
+    out = m(x.to(DEV), t.to(DEV), 1)
+    assert tuple(out[1][0][2].shape) == (2, 3, 32, 32)
+    with torch.no_grad():
+        for b in range(2):
+            ref = O.forward(sd, x[b:b + 1], t[b:b + 1], 1, shared_fgac=False)
+            assert (out[1][0][2][b].cpu() - ref[1][0][2][0]).abs().max() < 3e-4
+
+
+def test_fp16_psnr_against_fp32_reference(golden_dir, model16):
+    """No fp16 oracle exists (the reference crashes under .half()): fp16 is stated against the fp32
+    reference fixtures.  With synthetic random weights the network is chaotic around floor() decisions of the
+    splat, so the bound is loose; the number itself is printed for the record."""
+    for name in E2E[:2]:
+        g = np.load(os.path.join(golden_dir, name + '.npz'))
+        N = int(g['N'])
+        x = synthetic_window(int(g['H']), int(g['W']), int(g['seed']))
+        d1, fin, flows, occs, ov = model16(x.to(DEV), torch.tensor([[float(g['t'])]], device=DEV), N)
+        ps = [O.psnr(fin[N - 1][i][0].cpu().numpy(), g['finals'][N - 1, i]) for i in range(3)]
+        print('fp16 vs fp32-reference PSNR (S0,S1,St) %s: %.2f %.2f %.2f dB' % (name, *ps))
+        assert all(torch.isfinite(z).all() for z in fin[N - 1])
+        assert min(ps) > 30.0

@@ -1,0 +1,336 @@
+"""Kernel-level parity on a real MI355X, every call through the C ABI of libdemfi_hip.so.
+
+Comparisons: the oracle (oracle/demfi_oracle.py) and the fixtures frozen from the upstream reference
+(tests/golden).  Integer maps (splat target indices, grid-sample floor indices / in-bounds bits / validity)
+must be BIT-IDENTICAL; floating-point values are compared with the tolerance written in each test."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from demfi_amd import _lib as L                      # noqa: E402
+from demfi_amd.engine import Plan, _Dst              # noqa: E402
+from oracle import demfi_oracle as O                 # noqa: E402
+
+DEV = 'cuda:0'
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _view_planar(t, c0=0):
+    Ct, h, w = t.shape
+    return L.View(t.data_ptr() + c0 * h * w * 4, 1, w, h * w, 0, 1, 0)
+
+
+def _view_nhwc(t):
+    h, w, c = t.shape
+    return L.View(t.data_ptr(), c, w * c, 1, 0, 1 if t.dtype == torch.float32 else 0, 0)
+
+
+def test_device_is_gfx950():
+    st, name, ncu, mem = L.device_info()
+    assert st == 0, name
+    assert name.startswith('gfx950') and ncu == 256
+
+
+# ------------------------------------------------------------------------------------------------------
+# convolution
+# ------------------------------------------------------------------------------------------------------
+CONV_CASES = [
+    # cin, cout, kh, kw, stride, H, W (output), act, res
+    (64, 64, 3, 3, 1, 16, 64, L.ACT_RELU, True),
+    (64, 64, 3, 3, 1, 13, 45, L.ACT_NONE, False),      # ragged tile edges
+    (48, 96, 5, 5, 1, 16, 32, L.ACT_NONE, False),
+    (96, 32, 3, 3, 1, 8, 32, L.ACT_RELU, False),
+    (224, 96, 1, 1, 1, 8, 40, L.ACT_NONE, True),
+    (192, 64, 7, 7, 1, 16, 32, L.ACT_TANH, False),
+    (128, 64, 1, 5, 1, 9, 33, L.ACT_SIGMOID, False),
+    (128, 64, 5, 1, 1, 9, 33, L.ACT_NONE, False),
+    (64, 128, 4, 4, 2, 8, 32, L.ACT_RELU, False),
+    (96, 256, 3, 3, 1, 8, 32, L.ACT_NONE, False),      # two cout blocks
+    (64, 133, 3, 3, 1, 8, 32, L.ACT_NONE, False),      # nco = 5, ragged cout
+    (32, 5, 3, 3, 1, 8, 32, L.ACT_NONE, False),
+]
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16])
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv_vs_torch(case, dtype):
+    cin, cout, kh, kw, stride, H, W, act, with_res = case
+    torch.manual_seed(cin * 1000 + cout + kh)
+    inH, inW = H * stride, W * stride
+    pl = Plan(H, W, dtype, DEV)
+    x = pl._fat(inH, inW, cin)
+    x.copy_(torch.randn(x.shape, device=DEV))
+    out = pl._fat(H, W, cout)
+    res = pl._fat(H, W, cout)
+    res.copy_(torch.randn(res.shape, device=DEV))
+    wt = torch.randn(cout, cin, kh, kw) * (1.0 / (cin * kh * kw) ** 0.5)
+    bs = torch.randn(cout) * 0.1
+    seg = []
+    pl.conv(seg, 'case', [pl.fsrc(x, 0)], [_Dst(pl.fview(out), range(cout), act, res=pl.fview(res) if with_res else None)],
+            H, W, stride=stride, weight=wt, bias=bs)
+    pl._upload()
+    pl.launch_conv(0, _stream())
+    torch.cuda.synchronize()
+    xin = x[0].permute(2, 0, 1).float().cpu()[None]
+    wq = wt.half().float() if dtype == torch.float16 else wt
+    pad = (1, 1) if stride == 2 else (kh // 2, kw // 2)
+    ref = torch.nn.functional.conv2d(xin.double(), wq.double(), bs.double(), stride=stride, padding=pad)[0]
+    if with_res:
+        ref = ref + res[0].permute(2, 0, 1).double().cpu()
+    ref = {L.ACT_NONE: lambda z: z, L.ACT_RELU: torch.relu, L.ACT_TANH: torch.tanh, L.ACT_SIGMOID: torch.sigmoid}[act](ref)
+    got = out[0].permute(2, 0, 1).double().cpu()
+    # fp32 path: exact-fp32 MFMA, only summation order differs from the fp64 reference;
+    # fp16 path: inputs/weights identical fp16 values, fp32 accumulate, fp16 rounding of the stored result.
+    tol = 2e-5 if dtype == torch.float32 else 4e-3
+    err = (got - ref).abs().max().item()
+    assert err < tol * max(1.0, ref.abs().max().item()), (case, err)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16])
+def test_conv_multi_piece_routing_upsample_shuffle(dtype):
+    """Mixed fat/thin/upsampled inputs, PixelShuffle store, planar outputs with residual, GRU modes."""
+    torch.manual_seed(5)
+    H, W = 16, 32
+    pl = Plan(H, W, dtype, DEV)
+    a = pl._fat(H, W, 32)
+    lo = pl._fat(H // 2, W // 2, 16)
+    th = pl._thin(5)
+    for t in (a, lo, th):
+        t.copy_(torch.randn(t.shape, device=DEV))
+    o_fat = pl._fat(H, W, 24)
+    o_thin = pl._thin(3)
+    r_thin = pl._thin(3)
+    r_thin.copy_(torch.randn(r_thin.shape, device=DEV))
+    wt = torch.randn(27, 53, 3, 3) * 0.05
+    bs = torch.randn(27) * 0.1
+    seg = []
+    pl.conv(seg, 'mix', [pl.fsrc(a, 0), pl.tsrc(th, range(32, 37)), pl.fsrc(lo, 37, up=1)],
+            [_Dst(pl.fview(o_fat), range(3, 27), L.ACT_TANH), _Dst(pl.tview(o_thin), range(0, 3), res=pl.tview(r_thin))],
+            H, W, weight=wt, bias=bs)
+    # PixelShuffle: 64 couts at HxW -> 16 channels at 2Hx2W
+    ps_out = pl._fat(2 * H, 2 * W, 16)
+    w2 = torch.randn(64, 32, 3, 3) * 0.05
+    b2 = torch.randn(64) * 0.1
+    pl.conv(seg, 'ps', [pl.fsrc(a, 0)],
+            [_Dst(pl.fview(ps_out), [c * 4 + i * 2 + j for c in range(16)], scale=2, dy=i, dx=j) for i in range(2) for j in range(2)],
+            H, W, weight=w2, bias=b2)
+    # GRU pieces
+    h = pl._fat(H, W, 64)
+    xx = pl._fat(H, W, 64)
+    h.copy_(torch.tanh(torch.randn(h.shape, device=DEV)))
+    xx.copy_(torch.randn(xx.shape, device=DEV))
+    zb, rh, hn = pl._fat(H, W, 64), pl._fat(H, W, 64), pl._fat(H, W, 64)
+    wzr = torch.randn(128, 128, 1, 5) * 0.05
+    bzr = torch.randn(128) * 0.1
+    wq = torch.randn(64, 128, 1, 5) * 0.05
+    bq = torch.randn(64) * 0.1
+    pl.conv(seg, 'zr', [pl.fsrc(h, 0), pl.fsrc(xx, 64)],
+            [_Dst(pl.fview(zb), range(0, 64), L.ACT_SIGMOID), _Dst(pl.fview(rh), range(64, 128), mode=L.MODE_MUL, res=pl.fview(h))],
+            H, W, weight=wzr, bias=bzr)
+    pl.conv(seg, 'q', [pl.fsrc(rh, 0), pl.fsrc(xx, 64)],
+            [_Dst(pl.fview(hn), range(64), mode=L.MODE_GRU, res=pl.fview(h), aux=pl.fview(zb))], H, W, weight=wq, bias=bq)
+    pl._upload()
+    for i in range(4):
+        pl.launch_conv(i, _stream())
+    torch.cuda.synchronize()
+    q = (lambda z: z.half().float()) if dtype == torch.float16 else (lambda z: z)
+    tol = 1e-4 if dtype == torch.float32 else 1e-2
+    F = torch.nn.functional
+    nchw = lambda t: t[0].permute(2, 0, 1).float().cpu()[None]
+    xin = torch.cat([nchw(a), q(th.cpu())[None], F.interpolate(nchw(lo), scale_factor=2, mode='nearest')], 1)
+    ref = F.conv2d(xin, q(wt), bs, padding=1)[0]
+    assert (o_thin.cpu() - (ref[0:3] + r_thin.cpu())).abs().max() < tol
+    assert (nchw(o_fat)[0] - torch.tanh(ref[3:27])).abs().max() < tol
+    ref2 = F.pixel_shuffle(F.conv2d(nchw(a), q(w2), b2, padding=1), 2)[0]
+    assert (nchw(ps_out)[0] - ref2).abs().max() < tol
+    hx = torch.cat([nchw(h), nchw(xx)], 1)
+    zr = F.conv2d(hx, q(wzr), bzr, padding=(0, 2))
+    z, r = torch.sigmoid(zr[:, :64]), torch.sigmoid(zr[:, 64:])
+    assert (nchw(zb) - z).abs().max() < tol
+    assert (nchw(rh) - r * nchw(h)).abs().max() < tol
+    qv = torch.tanh(F.conv2d(torch.cat([nchw(rh), nchw(xx)], 1), q(wq), bq, padding=(0, 2)))
+    assert (nchw(hn) - ((1 - nchw(zb)) * nchw(h) + nchw(zb) * qv)).abs().max() < tol
+
+
+# ------------------------------------------------------------------------------------------------------
+# warps: fixtures from the reference + bit-identical integer maps
+# ------------------------------------------------------------------------------------------------------
+FAMS = ['zeros', 'ints', 'halves', 'smooth', 'large', 'edges', 'collide']
+
+
+def _gold(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + '.npz'))
+
+
+def _warp_maps_expected(flo, H, W):
+    m = O.backward_warp_maps(flo)
+    inb = sum((m['inb'][k].astype(np.int32) << k) for k in range(4)) | (m['valid'].astype(np.int32) << 4)
+    x0 = np.clip(m['ix0'], -4, W + 4).astype(np.int32)
+    y0 = np.clip(m['iy0'], -4, H + 4).astype(np.int32)
+    return x0, y0, inb
+
+
+def test_warp_blend_thin_vs_reference_goldens(golden_dir):
+    g = _gold(golden_dir, 'warps_24x40')
+    H, W = 24, 40
+    lib = L.load()
+    img = torch.from_numpy(g['img3']).to(DEV)
+    t = torch.tensor([0.375], device=DEV)
+    for fa_name, fb_name in zip(FAMS, FAMS[1:] + FAMS[:1]):
+        fa = torch.from_numpy(g['flo_' + fa_name]).to(DEV)
+        fb = torch.from_numpy(g['flo_' + fb_name]).to(DEV)
+        logit = (torch.arange(H * W, device=DEV).float().view(H, W) % 7 - 3.0).contiguous()
+        out = torch.zeros(3, H, W, device=DEV)
+        occ = torch.zeros(H, W, device=DEV)
+        dbg = torch.zeros(2, 3, H * W, dtype=torch.int32, device=DEV)
+        A, B, Ov = _view_planar(img), _view_planar(img), _view_planar(out)
+        L.check(lib.demfi_warp_blend(C.byref(A), fa.data_ptr(), C.byref(B), fb.data_ptr(), logit.data_ptr(), t.data_ptr(),
+                                     C.byref(Ov), 3, H, W, occ.data_ptr(), dbg.data_ptr(), _stream()))
+        torch.cuda.synchronize()
+        # values: Eq.(2) of the reference bwarp outputs
+        wa = torch.from_numpy(g['bwarp3_' + fa_name])
+        wb = torch.from_numpy(g['bwarp3_' + fb_name])
+        o0 = torch.sigmoid(logit.cpu())
+        ref = (0.625 * o0 * wa + 0.375 * (1 - o0) * wb) / (0.625 * o0 + 0.375 * (1 - o0))
+        assert (out.cpu() - ref).abs().max() < 2e-6
+        assert (occ.cpu() - o0).abs().max() < 1e-6
+        # integer maps: bit-identical to the step-by-step fp32 emulation that equals torch
+        for which, nm in ((0, fa_name), (1, fb_name)):
+            x0, y0, inb = _warp_maps_expected(g['flo_' + nm], H, W)
+            got = dbg[which].cpu().numpy().reshape(3, H, W)
+            assert np.array_equal(got[2], inb), nm
+            anyin = (inb & 15) != 0
+            assert np.array_equal(got[0][anyin], x0[anyin]) and np.array_equal(got[1][anyin], y0[anyin]), nm
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16])
+def test_warp_blend_fat_vs_oracle(dtype):
+    torch.manual_seed(3)
+    H, W, Cc = 40, 72, 64
+    lib = L.load()
+    A = torch.tanh(torch.randn(H, W, Cc, device=DEV)).to(dtype)
+    B = torch.tanh(torch.randn(H, W, Cc, device=DEV)).to(dtype)
+    fl = (torch.randn(4, H, W, device=DEV) * 6).contiguous()
+    logit = torch.randn(H, W, device=DEV) * 3
+    t = torch.tensor([0.25], device=DEV)
+    out = torch.zeros(H, W, Cc, device=DEV, dtype=dtype)
+    dbg = torch.zeros(2, 3, H * W, dtype=torch.int32, device=DEV)
+    va, vb, vo = _view_nhwc(A), _view_nhwc(B), _view_nhwc(out)
+    L.check(lib.demfi_warp_blend(C.byref(va), fl.data_ptr(), C.byref(vb), fl[2:].data_ptr(), logit.data_ptr(), t.data_ptr(),
+                                 C.byref(vo), Cc, H, W, None, dbg.data_ptr(), _stream()))
+    torch.cuda.synchronize()
+    nchw = lambda z: z.permute(2, 0, 1).float().cpu()[None]
+    ref = O.warp_blend(nchw(A), fl[None, 0:2].cpu(), nchw(B), fl[None, 2:4].cpu(), logit.cpu()[None, None], t.cpu().view(1, 1, 1, 1))
+    tol = 3e-6 if dtype == torch.float32 else 2e-3
+    assert (nchw(out) - ref).abs().max() < tol
+    for which in range(2):
+        x0, y0, inb = _warp_maps_expected(fl[2 * which:2 * which + 2].cpu().numpy(), H, W)
+        got = dbg[which].cpu().numpy().reshape(3, H, W)
+        assert np.array_equal(got[2], inb)
+
+
+def test_cfr_vs_reference_goldens(golden_dir):
+    g = _gold(golden_dir, 'warps_24x40')
+    H, W = 24, 40
+    lib = L.load()
+    for i in range(4):
+        f01 = torch.from_numpy(g['cfr%d_f01' % i]).to(DEV)
+        f10 = torch.from_numpy(g['cfr%d_f10' % i]).to(DEV)
+        tv = float(g['cfr%d_t' % i])
+        t = torch.tensor([tv], device=DEV)
+        acc = torch.zeros(6 * H * W, dtype=torch.int64, device=DEV)
+        out = torch.zeros(4, H, W, device=DEV)
+        dbg = torch.zeros(2, 4, H * W, dtype=torch.int32, device=DEV)
+        L.check(lib.demfi_cfr_flow_align(f01.data_ptr(), f10.data_ptr(), t.data_ptr(), H, W, acc.data_ptr(), out.data_ptr(),
+                                         dbg.data_ptr(), _stream()))
+        torch.cuda.synchronize()
+        ref = np.concatenate([g['cfr%d_ft0' % i], g['cfr%d_ft1' % i]], 0)
+        scale = max(1.0, np.abs(ref).max())
+        assert np.abs(out.cpu().numpy() - ref).max() < 2e-5 * scale, i
+        # splat target indices: bit-identical to sample_one's idxx/idxy/mask
+        t32 = np.float32(tv)
+        for k, (fl, s) in enumerate(((g['cfr%d_f01' % i], t32), (g['cfr%d_f10' % i], np.float32(1) - t32))):
+            maps = O.splat_maps((fl * s).astype(np.float32), H, W)
+            for c, m in enumerate(maps):
+                exp = np.where(m['mask'], m['row'] * W + m['col'], -1).astype(np.int32).reshape(-1)
+                assert np.array_equal(dbg[k, c].cpu().numpy(), exp), (i, k, c)
+
+
+def test_cfr_is_deterministic():
+    torch.manual_seed(1)
+    H, W = 96, 160
+    lib = L.load()
+    f01 = (torch.randn(2, H, W, device=DEV) * 9).contiguous()
+    f10 = (torch.randn(2, H, W, device=DEV) * 9).contiguous()
+    t = torch.tensor([0.625], device=DEV)
+    outs = []
+    for _ in range(3):
+        acc = torch.zeros(6 * H * W, dtype=torch.int64, device=DEV)
+        out = torch.zeros(4, H, W, device=DEV)
+        L.check(lib.demfi_cfr_flow_align(f01.data_ptr(), f10.data_ptr(), t.data_ptr(), H, W, acc.data_ptr(), out.data_ptr(),
+                                         None, _stream()))
+        torch.cuda.synchronize()
+        outs.append(out.cpu())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    a, b = O.cfr_flow_align(f01.cpu()[None], f10.cpu()[None], t.cpu().view(1, 1, 1, 1))
+    assert (outs[0] - torch.cat([a[0], b[0]], 0)).abs().max() < 1e-3
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16])
+def test_fgac_gather_and_gate(golden_dir, dtype):
+    g = _gold(golden_dir, 'fgac_16x24')
+    H, W, Cc = 16, 24, 64
+    lib = L.load()
+    ref = torch.from_numpy(g['ref']).to(DEV)
+    src = ref.permute(1, 2, 0).contiguous().to(dtype)
+    for name in ('inrange', 'mixed', 'beyond'):
+        fl = torch.from_numpy(g['flow_' + name]).to(DEV)
+        out = torch.zeros(H, W, Cc, device=DEV, dtype=dtype)
+        dbg = torch.zeros(3, H * W, dtype=torch.int32, device=DEV)
+        vs, vo = _view_nhwc(src), _view_nhwc(out)
+        L.check(lib.demfi_fgac_gather(C.byref(vs), fl.data_ptr(), C.byref(vo), Cc, H, W, dbg.data_ptr(), _stream()))
+        torch.cuda.synchronize()
+        exp, m = O.fgac_sample_explicit(src.permute(2, 0, 1).float().cpu()[None], fl.cpu()[None])
+        tol = 2e-6 if dtype == torch.float32 else 1e-3
+        assert (out.permute(2, 0, 1).float().cpu() - exp[0]).abs().max() < tol
+        inb = sum((m['inb'][k].astype(np.int32) << k) for k in range(4))
+        got = dbg.cpu().numpy().reshape(3, H, W)
+        assert np.array_equal(got[2] & 15, inb)
+    w = torch.rand(H, W, device=DEV)
+    e = torch.randn(H, W, Cc, device=DEV).to(dtype)
+    o = torch.zeros(H, W, Cc, device=DEV, dtype=dtype)
+    vs, ve, vo = _view_nhwc(src), _view_nhwc(e), _view_nhwc(o)
+    L.check(lib.demfi_gate_blend(w.data_ptr(), C.byref(vs), C.byref(ve), C.byref(vo), Cc, H, W, _stream()))
+    torch.cuda.synchronize()
+    exp = w[..., None] * src.float() + (1 - w[..., None]) * e.float()
+    assert (o.float() - exp).abs().max() < (1e-6 if dtype == torch.float32 else 4e-3)
+
+
+def test_s2d_reflect_overlay(golden_dir):
+    lib = L.load()
+    H, W = 16, 24
+    x = torch.randn(3, 4, H, W, device=DEV)
+    for dtype, dt in ((torch.float32, L.F32), (torch.float16, L.F16)):
+        out = torch.zeros(H // 2, W // 2, 48, device=DEV, dtype=dtype)
+        L.check(lib.demfi_space_to_depth(x.data_ptr(), out.data_ptr(), dt, H, W, _stream()))
+        torch.cuda.synchronize()
+        cat = x.permute(1, 0, 2, 3).reshape(1, 12, H, W).cpu()
+        exp = O.space_to_depth(cat, 2)[0].permute(1, 2, 0)
+        assert torch.equal(out.cpu().float(), exp.to(dtype).float())
+    ov = torch.zeros(3, H, W, device=DEV)
+    L.check(lib.demfi_overlay_mean(x.data_ptr(), ov.data_ptr(), H, W, _stream()))
+    xs = torch.randn(12, 50, 70, device=DEV)
+    xp = torch.zeros(12, 64, 96, device=DEV)
+    L.check(lib.demfi_reflect_pad(xs.data_ptr(), xp.data_ptr(), 12, 50, 70, 64, 96, _stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(ov.cpu(), torch.mean(x[:, 0:2], dim=1).cpu())
+    assert torch.equal(xp.cpu(), torch.nn.functional.pad(xs.cpu()[None], [0, 26, 0, 14], mode='reflect')[0])
+    assert lib.demfi_reflect_pad(xs.data_ptr(), xp.data_ptr(), 12, 50, 70, 128, 96, _stream()) == -1   # pad >= size

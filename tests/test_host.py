@@ -1,0 +1,138 @@
+"""CPU tests of the host side: state_dict contract, C-ABI exports, weight repack, and the launch plan
+interpreted on CPU (tests/plan_sim.py) against the oracle.  No kernel is launched here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from demfi_amd import _lib as L
+from demfi_amd.engine import Engine, Plan, _Dst
+from demfi_amd.model import DeMFInet
+from demfi_amd.spec import HyperParams, state_dict_shapes
+from demfi_amd.weights import synthetic_state_dict, synthetic_window
+from oracle import demfi_oracle as O
+from tests.plan_sim import PlanSim
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_state_dict_contract():
+    shapes = state_dict_shapes()
+    assert len(shapes) == 260
+    assert sum(int(np.prod(s)) for s in shapes.values()) == 7408284
+    m = DeMFInet(HyperParams())
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(shapes.keys())
+    assert tuple(sd['Decoder_res.3.conv1.weight'].shape) == (64, 64, 1, 3, 3)
+    assert tuple(sd['Booster_Module.GB.convq2.weight'].shape) == (64, 128, 5, 1)
+    m.load_state_dict(synthetic_state_dict(0))                                 # same keys -> strict load works
+    assert len(state_dict_shapes(HyperParams(shared_FGAC_flag=False))) == 270
+    assert sum(int(np.prod(s)) for s in state_dict_shapes(HyperParams(shared_FGAC_flag=False)).values()) == 7495133
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, 'include', 'demfi_hip.h')).read()
+    body = hdr[hdr.index('---- library / device'):]
+    declared = set(re.findall(r'\b(demfi_[a-z0-9_]+)\s*\(', body))
+    assert declared == set(L.EXPORTS), declared ^ set(L.EXPORTS)
+    lib = L.load()
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.demfi_abi_version() == 1
+    assert C.sizeof(L.View) == 48 and C.sizeof(L.Piece) == 64 and C.sizeof(L.Chunk) == 24 and C.sizeof(L.Seg) == 168
+
+
+def test_forward_fails_loudly_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    m = DeMFInet(HyperParams())
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 3, 4, 32, 32), torch.tensor([[0.5]]), 1)
+    with pytest.raises(NotImplementedError):
+        m(torch.zeros(1, 3, 4, 32, 32), torch.tensor([[0.5]]), 1, is_training=True)
+
+
+def test_pack_rejects_bad_arguments():
+    lib = L.load()
+    n = C.c_int64(0)
+    w = np.zeros((4, 4, 1, 1), np.float32)
+    cin = np.arange(16, dtype=np.int32)          # indices 4..15 exceed cin=4 -> rejected when packing
+    nks = np.asarray([1], np.int32)
+    cout = np.arange(32, dtype=np.int32)
+    cout[4:] = -1
+    st = lib.demfi_pack_conv_weights(w.ctypes.data, 4, 4, 1, 1, cin.ctypes.data, 16, nks.ctypes.data, 1, cout.ctypes.data,
+                                     32, 1, L.F16, None, C.byref(n))
+    assert st == 0 and n.value == 64 * 16
+    out = np.zeros(n.value, np.uint8)
+    st = lib.demfi_pack_conv_weights(w.ctypes.data, 4, 4, 1, 1, cin.ctypes.data, 16, nks.ctypes.data, 1, cout.ctypes.data,
+                                     32, 1, L.F16, out.ctypes.data, C.byref(n))
+    assert st == -1 and b'cin_map' in lib.demfi_last_error()
+    st = lib.demfi_pack_conv_weights(w.ctypes.data, 4, 4, 1, 1, cin.ctypes.data, 16, nks.ctypes.data, 1, cout.ctypes.data,
+                                     48, 2, L.F16, None, C.byref(n))
+    assert st == -1
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16])
+def test_weight_pack_roundtrip_and_conv_sim(dtype):
+    """demfi_pack_conv_weights -> unpack (test-side inverse) reproduces W[cout_map][cin_map]; odd channel counts,
+    mixed fat/thin inputs, split outputs."""
+    torch.manual_seed(0)
+    H, W = 8, 32
+    pl = Plan(H, W, dtype, 'cpu')
+    a = pl._fat(H, W, 24)
+    b = pl._thin(5)
+    a.copy_(torch.randn(a.shape))
+    b.copy_(torch.randn(b.shape))
+    o1 = pl._fat(H, W, 16)
+    o2 = pl._thin(3)
+    wt = torch.randn(19, 29, 3, 3) * 0.1
+    bs = torch.randn(19)
+    seg = []
+    # logical input = [thin(0..4) | fat(5..28)], outputs: couts 3..18 -> fat, 0..2 -> thin
+    pl.conv(seg, 'case', [pl.tsrc(b, range(0, 5)), pl.fsrc(a, 5)],
+            [_Dst(pl.fview(o1), range(3, 19), L.ACT_RELU), _Dst(pl.tview(o2), range(0, 3))], H, W, weight=wt, bias=bs)
+    pl._upload()
+    sim = PlanSim(pl)
+    sim.conv(pl._descs[0])
+    xin = torch.cat([b, a[0].permute(2, 0, 1).float()], 0)[None]
+    if dtype == torch.float16:
+        xin = xin.half().float()
+        wt = wt.half().float()
+    ref = torch.nn.functional.conv2d(xin, wt, bs, padding=1)[0]
+    tol = 1e-5 if dtype == torch.float32 else 2e-3
+    assert (o2 - ref[0:3]).abs().max() < tol
+    assert (o1[0].permute(2, 0, 1).float() - torch.relu(ref[3:19])).abs().max() < (tol if dtype == torch.float32 else 2e-2)
+
+
+def test_plan_matches_oracle_fp32(synthetic_sd):
+    """The whole launch plan (engine.py) interpreted on CPU == oracle forward, fp32, N=2."""
+    H, W, N = 32, 64, 2
+    eng = Engine(synthetic_sd, H, W, torch.float32, 'cpu', max_updates=N)
+    assert len(eng._descs) == 74 + 30 + 25 * N
+    x = synthetic_window(H, W, 4)
+    PlanSim(eng).forward(x, 0.375, N)
+    with torch.no_grad():
+        d1, fin, flows, occs, ov = O.forward(synthetic_sd, x, torch.tensor([[0.375]]), N)
+    for i in range(3):
+        assert (eng.sharp1[3 * i:3 * i + 3] - d1[i][0]).abs().max() < 1e-4
+        for it in range(N):
+            assert (eng.finals[it, i] - fin[it][i][0]).abs().max() < 1e-4
+    for i in range(N + 1):
+        assert (eng.delta[i, 0:4] - flows[i][0]).abs().max() < 2e-4
+        assert (eng.occ[i:i + 1] - occs[i][0]).abs().max() < 1e-4
+    assert torch.equal(eng.overlay, ov[0])
+
+
+def test_plan_non_shared_fgac():
+    hp = HyperParams(shared_FGAC_flag=False)
+    sd = synthetic_state_dict(3, hp)
+    H, W = 32, 32
+    eng = Engine(sd, H, W, torch.float32, 'cpu', max_updates=1, hp=hp)
+    x = synthetic_window(H, W, 6)
+    PlanSim(eng).forward(x, 0.5, 1)
+    with torch.no_grad():
+        out = O.forward(sd, x, torch.tensor([[0.5]]), 1, shared_fgac=False)
+    assert (eng.finals[0, 2] - out[1][0][2][0]).abs().max() < 1e-4

@@ -1,0 +1,109 @@
+"""The oracle restatement against the fixtures frozen from the upstream reference (tools/make_goldens.py)."""
+import os
+
+import numpy as np
+import torch
+
+from demfi_amd.weights import synthetic_window
+from oracle import demfi_oracle as O
+
+E2E = ['e2e_64x96_t0500_n3', 'e2e_64x96_t0125_n1', 'e2e_64x96_t0875_n2', 'e2e_32x64_t0375_n5']
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + '.npz'))
+
+
+def test_e2e_matches_reference_goldens(golden_dir, synthetic_sd):
+    for name in E2E:
+        g = _load(golden_dir, name)
+        x = synthetic_window(int(g['H']), int(g['W']), int(g['seed']))
+        with torch.no_grad():
+            d1, fin, flows, occs, ov = O.forward(synthetic_sd, x, torch.tensor([[float(g['t'])]]), int(g['N']))
+        tol = 5e-5
+        for i in range(3):
+            assert np.abs(d1[i][0].numpy() - g['d1'][i]).max() < tol
+        for it in range(int(g['N'])):
+            for i in range(3):
+                assert np.abs(fin[it][i][0].numpy() - g['finals'][it, i]).max() < tol
+                # acceptance metric of the north star: |dPSNR| <= 1e-3 dB against a fixed pseudo ground truth
+                gt = x[0, :, 0].numpy()
+                assert abs(O.psnr(fin[it][i][0].numpy(), gt) - O.psnr(g['finals'][it, i], gt)) <= 1e-3
+        for i in range(int(g['N']) + 1):
+            assert np.abs(flows[i][0].numpy() - g['flows'][i]).max() < tol
+            assert np.abs(occs[i][0].numpy() - g['occs'][i]).max() < tol
+        assert np.array_equal(ov[0].numpy(), g['overlay'])
+
+
+def test_harness_pad_forward_crop(golden_dir, synthetic_sd):
+    g = _load(golden_dir, 'harness_50x70_t0625_n1')
+    x = synthetic_window(50, 70, 5)
+    with torch.no_grad():
+        d1, fin, flows, occs, ov = O.pad_forward_crop(synthetic_sd, x, torch.tensor([[0.625]]), 1)
+    assert fin[0][2].shape[-2:] == (50, 70)
+    for i in range(3):
+        assert np.abs(fin[0][i][0].numpy() - g['finals'][0, i]).max() < 5e-5
+    assert np.abs(flows[1][0].numpy() - g['flows'][1]).max() < 5e-5
+
+
+FAMS = ['zeros', 'ints', 'halves', 'smooth', 'large', 'edges', 'collide']
+
+
+def test_backward_warp_and_maps(golden_dir):
+    g = _load(golden_dir, 'warps_24x40')
+    img3 = torch.from_numpy(g['img3'])[None]
+    img8 = torch.from_numpy(g['img8'])[None]
+    for f in FAMS:
+        flo = torch.from_numpy(g['flo_' + f])[None]
+        assert np.abs(O.backward_warp(img3, flo)[0].numpy() - g['bwarp3_' + f]).max() < 1e-6
+        assert np.abs(O.backward_warp_explicit(img3, flo)[0].numpy() - g['bwarp3_' + f]).max() < 1e-6
+        assert np.abs(O.backward_warp_explicit(img8, flo)[0].numpy() - g['bwarp8_' + f]).max() < 1e-6
+        # the validity map of the step-by-step fp32 emulation == where the reference output is non-zero
+        m = O.backward_warp_maps(g['flo_' + f])
+        ref_nonzero = np.abs(g['bwarp8_' + f]).max(0) > 0
+        assert not (ref_nonzero & ~m['valid']).any()
+
+
+def test_forward_splat_bit_exact(golden_dir):
+    g = _load(golden_dir, 'warps_24x40')
+    for f in FAMS:
+        flo = torch.from_numpy(g['flo_' + f])[None]
+        iw, io = O.forward_splat(flo, 0.375 * flo)
+        assert np.array_equal(iw[0].numpy(), g['fwarp_img_' + f])
+        assert np.array_equal(io[0].numpy(), g['fwarp_one_' + f])
+
+
+def test_cfr_bit_exact(golden_dir):
+    g = _load(golden_dir, 'warps_24x40')
+    for i in range(4):
+        t = torch.tensor(float(g['cfr%d_t' % i])).view(1, 1, 1, 1)
+        a, b = O.cfr_flow_align(torch.from_numpy(g['cfr%d_f01' % i])[None], torch.from_numpy(g['cfr%d_f10' % i])[None], t)
+        assert np.array_equal(a[0].numpy(), g['cfr%d_ft0' % i])
+        assert np.array_equal(b[0].numpy(), g['cfr%d_ft1' % i])
+
+
+def test_fgac_and_space_to_depth(golden_dir, synthetic_sd):
+    g = _load(golden_dir, 'fgac_16x24')
+    ref = torch.from_numpy(g['ref'])[None]
+    src = torch.from_numpy(g['src'])[None]
+    for name in ('inrange', 'mixed', 'beyond'):
+        fl = torch.from_numpy(g['flow_' + name])[None]
+        with torch.no_grad():
+            out, w = O.fgac(synthetic_sd, 'FAC_FB_Module.shared_FGAC', ref, src, fl)
+        assert np.abs(out[0].numpy() - g['out_' + name]).max() < 1e-6
+        assert np.abs(w[0].numpy() - g['gate_' + name]).max() < 1e-6
+        # explicit-gather twin == grid_sample path
+        rk = O.conv(synthetic_sd, 'FAC_FB_Module.shared_FGAC.conv_ref_k', ref)
+        assert (O.fgac_sample_explicit(rk, fl)[0] - O.fgac_sample(rk, fl)).abs().max() < 1e-5
+    assert np.array_equal(O.space_to_depth(torch.from_numpy(g['s2d_in'])[None], 2)[0].numpy(), g['s2d_out'])
+
+
+def test_fgac_ignores_conv_source_k(synthetic_sd):
+    """conv_source_k has no effect on the output (softmax over a singleton)."""
+    sd = dict(synthetic_sd)
+    x = synthetic_window(32, 32, 9)
+    with torch.no_grad():
+        a = O.forward(sd, x, torch.tensor([[0.5]]), 1)
+        sd['FAC_FB_Module.shared_FGAC.conv_source_k.weight'] = sd['FAC_FB_Module.shared_FGAC.conv_source_k.weight'] * 100
+        b = O.forward(sd, x, torch.tensor([[0.5]]), 1)
+    assert torch.equal(a[1][0][2], b[1][0][2])
