@@ -42,6 +42,7 @@ class Conv(C.Structure):
                 ('_pad', C.c_int32), ('w_blk_stride', C.c_int64), ('wpack', C.c_void_p), ('bias', C.c_void_p),
                 ('chunks', Chunk * MAX_CHUNKS), ('pieces', Piece * MAX_PIECES), ('segs', Seg * MAX_SEGS),
                 ('oct_seg', C.c_int32 * MAX_OCTS), ('oct_n', C.c_int32 * MAX_OCTS), ('oct_ch', C.c_int32 * MAX_OCTS),
+                ('sub_seg', C.c_int32 * (MAX_OCTS // 4)),
                 ('lw_magic', C.c_uint32), ('_pad2', C.c_uint32)]
 
 

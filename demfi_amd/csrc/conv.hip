@@ -61,6 +61,38 @@ __device__ __forceinline__ void static_for(F&& f)
     }
 }
 
+constexpr int STAGE_LD = 36;          // floats per staged pixel row: 32 couts + 4 pad (144 B, conflict-light b128)
+
+template <typename T> __device__ __forceinline__ void load8(const T* p, float* o);
+template <> __device__ __forceinline__ void load8<half_t>(const half_t* p, float* o)
+{
+    const h8_t v = *(const h8_t*)p;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (float)v[j];
+}
+template <> __device__ __forceinline__ void load8<float>(const float* p, float* o)
+{
+    const f4_t a = *(const f4_t*)p, b = *(const f4_t*)(p + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { o[j] = a[j]; o[4 + j] = b[j]; }
+}
+template <typename T> __device__ __forceinline__ void store8(T* p, const float* v);
+template <> __device__ __forceinline__ void store8<half_t>(half_t* p, const float* v)
+{
+    h8_t o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (half_t)v[j];
+    *(h8_t*)p = o;
+}
+template <> __device__ __forceinline__ void store8<float>(float* p, const float* v)
+{
+    f4_t a, b;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { a[j] = v[j]; b[j] = v[4 + j]; }
+    *(f4_t*)p = a;
+    *(f4_t*)(p + 4) = b;
+}
+
 __device__ __forceinline__ float apply_act(float v, int act)
 {
     if (act == DEMFI_ACT_RELU) return fmaxf(v, 0.0f);
@@ -69,8 +101,10 @@ __device__ __forceinline__ float apply_act(float v, int act)
     return v;
 }
 
+// second launch_bounds argument = minimum waves per SIMD: 2-3 resident workgroups per CU let one workgroup's
+// tile staging overlap another's MFMA phase.
 template <typename T, int NCO>
-__global__ __launch_bounds__(NT) void conv_kernel(const demfi_conv* __restrict__ d)
+__global__ __launch_bounds__(NT, (NCO <= 1 ? 4 : (NCO == 2 ? 3 : 2))) void conv_kernel(const demfi_conv* __restrict__ d)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -200,10 +234,82 @@ __global__ __launch_bounds__(NT) void conv_kernel(const demfi_conv* __restrict__
     // acc[s][p][r]: pixel (oy0 + 2*wave + p, ox0 + lx), packed cout (cblk*NCO+s)*32 + 8*(r>>2) + 4*hi + (r&3)
     const float* __restrict__ bias = d->bias;
     const int ox = ox0 + lx;
+
+    // ---- staged path: a 32-cout subtile whose 4 octets form one NHWC run of the path dtype goes through a
+    // wave-private LDS transpose so that every lane owns 8 consecutive channels of one pixel: residual / gate
+    // loads and the store are 16-byte (fp16) or 2x16-byte (fp32) accesses covering whole 64-byte runs per
+    // pixel, instead of 8-byte accesses at a 128-byte lane stride.
+    __syncthreads();                                   // every wave is done reading the input tile
+    float* stage = (float*)(smem + wave * (64 * STAGE_LD * 4));
+    static_for<0, NCO>([&](auto S) {
+        constexpr int s = decltype(S)::value;
+        const int sub = cblk * NCO + s;
+        const int segi = d->sub_seg[sub];
+        if (segi < 0) return;                          // uniform
+        const demfi_seg& sg = d->segs[segi];
+        const int ch0 = d->oct_ch[sub * 4];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f4_t bq = *(const f4_t*)(bias + sub * 32 + g * 8 + 4 * hi);
+                f4_t v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = acc[s][p][g * 4 + j] + bq[j];
+                *(f4_t*)(stage + (p * 32 + lx) * STAGE_LD + g * 8 + 4 * hi) = v;
+            }
+        }
+        __syncthreads();
+        const int mode = sg.mode, act = sg.act;
+        const T* resp = (const T*)sg.res.ptr;
+        const T* auxp = (const T*)sg.aux.ptr;
+        T* dstp = (T*)sg.dst.ptr;
+        const int q = lane & 3;
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const int px = pass * 16 + (lane >> 2);
+            const int oy = oy0 + wave * 2 + (px >> 5);
+            const int oxx = ox0 + (px & 31);
+            if (oy >= H || oxx >= W) continue;
+            float v[8];
+            {
+                const f4_t v0 = *(const f4_t*)(stage + px * STAGE_LD + q * 8);
+                const f4_t v1 = *(const f4_t*)(stage + px * STAGE_LD + q * 8 + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { v[j] = v0[j]; v[4 + j] = v1[j]; }
+            }
+            const int cq = ch0 + q * 8;
+            if (resp != nullptr) {
+                float r[8];
+                load8<T>(resp + (int64_t)bimg * sg.res.sb + (int64_t)oy * sg.res.sy + (int64_t)oxx * sg.res.sx + cq, r);
+                if (mode == DEMFI_MODE_STORE) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = apply_act(v[j] + r[j], act);
+                } else if (mode == DEMFI_MODE_MUL) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = sigmoidf_(v[j]) * r[j];
+                } else {
+                    float z[8];
+                    load8<T>(auxp + (int64_t)bimg * sg.aux.sb + (int64_t)oy * sg.aux.sy + (int64_t)oxx * sg.aux.sx + cq, z);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = (1.0f - z[j]) * r[j] + z[j] * tanhf(v[j]);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = apply_act(v[j], act);
+            }
+            const int dyy = oy * sg.scale + sg.dy, dxx = oxx * sg.scale + sg.dx;
+            store8<T>(dstp + (int64_t)bimg * sg.dst.sb + (int64_t)dyy * sg.dst.sy + (int64_t)dxx * sg.dst.sx + cq, v);
+        }
+        __syncthreads();
+    });
+
+    // ---- direct path (thin / planar / ragged destinations): straight from the accumulator layout ----------
     static_for<0, NCO * 4>([&](auto SG) {
         {
             constexpr int s = decltype(SG)::value >> 2;
             constexpr int g = decltype(SG)::value & 3;
+            if (d->sub_seg[cblk * NCO + s] >= 0) return;
             const int oct = (cblk * NCO + s) * 4 + g;
             const int on = d->oct_n[oct];
             if (on == 0) return;
@@ -313,7 +419,9 @@ extern "C" int64_t demfi_conv_lds_bytes(const demfi_conv* h)
 {
     const int64_t LW = (int64_t)(TW - 1) * h->stride + h->kw;
     const int64_t LH = (int64_t)(TH - 1) * h->stride + h->kh;
-    return LW * LH * (h->rec_bytes + REC_PAD);
+    const int64_t tile = LW * LH * (h->rec_bytes + REC_PAD);
+    const int64_t stage = 4 * 64 * STAGE_LD * 4;                 // 4 waves x 64 pixels x 36 floats
+    return tile > stage ? tile : stage;
 }
 
 extern "C" int demfi_conv2d(const demfi_conv* h, const demfi_conv* dev, void* stream)
@@ -330,7 +438,7 @@ extern "C" int demfi_conv2d(const demfi_conv* h, const demfi_conv* dev, void* st
     const int64_t LW = (int64_t)(TW - 1) * h->stride + h->kw;
     const int64_t lds = demfi_conv_lds_bytes(h);
     if (lds > 160 * 1024) return demfi_set_error(DEMFI_ERR_ARG, "demfi_conv2d: LDS tile %lld B > 160 KiB", (long long)lds);
-    if (lds / (h->rec_bytes + REC_PAD) >= 65536) return demfi_set_error(DEMFI_ERR_ARG, "demfi_conv2d: tile too large");
+    if (LW * ((int64_t)(TH - 1) * h->stride + h->kh) >= 65536) return demfi_set_error(DEMFI_ERR_ARG, "demfi_conv2d: tile too large");
     if (h->lw_magic != (uint32_t)((0x100000000ull + LW - 1) / LW))
         return demfi_set_error(DEMFI_ERR_ARG, "demfi_conv2d: lw_magic mismatch");
     const int esz = h->dtype == DEMFI_F16 ? 2 : 4;
@@ -349,6 +457,22 @@ extern "C" int demfi_conv2d(const demfi_conv* h, const demfi_conv* dev, void* st
             used += p.nch * esz;
         }
         if (used != ch.nks * 32) return demfi_set_error(DEMFI_ERR_ARG, "demfi_conv2d: chunk %d covers %d B, expected %d", c, used, ch.nks * 32);
+    }
+    for (int sb = 0; sb < h->cout_pad / 32; ++sb) {
+        const int sgi = h->sub_seg[sb];
+        if (sgi < 0) continue;
+        if (sgi >= h->n_segs) return demfi_set_error(DEMFI_ERR_ARG, "demfi_conv2d: sub_seg[%d]=%d", sb, sgi);
+        const demfi_seg& sg = h->segs[sgi];
+        const int f32 = h->dtype == DEMFI_F32;
+        bool ok = sg.dst.ptr && sg.dst.sc == 1 && sg.dst.is_f32 == f32;
+        if (sg.res.ptr) ok = ok && sg.res.sc == 1 && sg.res.is_f32 == f32;
+        if (sg.mode == DEMFI_MODE_GRU) ok = ok && sg.aux.ptr && sg.aux.sc == 1 && sg.aux.is_f32 == f32;
+        if (sg.mode != DEMFI_MODE_STORE) ok = ok && sg.res.ptr;
+        for (int o = 0; o < 4; ++o)
+            ok = ok && h->oct_seg[sb * 4 + o] == sgi && h->oct_n[sb * 4 + o] == 8 &&
+                 h->oct_ch[sb * 4 + o] == h->oct_ch[sb * 4] + 8 * o;
+        ok = ok && h->oct_ch[sb * 4] % 8 == 0;
+        if (!ok) return demfi_set_error(DEMFI_ERR_ARG, "demfi_conv2d: subtile %d is not eligible for the staged epilogue", sb);
     }
     hipStream_t st = (hipStream_t)stream;
     return h->dtype == DEMFI_F16 ? dispatch<half_t>(h, dev, st, (size_t)lds) : dispatch<float>(h, dev, st, (size_t)lds);

@@ -234,6 +234,23 @@ class Plan:
                               ds.dx, 0)
         for i, (si, k, o) in enumerate(octs):
             d.oct_seg[i], d.oct_n[i], d.oct_ch[i] = si, k, o
+        for sb in range(L.MAX_OCTS // 4):
+            d.sub_seg[sb] = -1
+        for sb in range(cout_pad // 32):
+            o4 = octs[sb * 4:sb * 4 + 4]
+            si = o4[0][0]
+            ds = dsts[si]
+
+            def fat_ok(v):
+                return v is not None and v.ptr and v.sc == 1 and bool(v.is_f32) == self.f32
+            ok = all(o[0] == si and o[1] == 8 and o[2] == o4[0][2] + 8 * j for j, o in enumerate(o4)) and o4[0][2] % 8 == 0
+            ok = ok and fat_ok(ds.view) and (ds.res is None or fat_ok(ds.res))
+            if ds.mode == L.MODE_GRU:
+                ok = ok and fat_ok(ds.aux)
+            if ds.mode != L.MODE_STORE:
+                ok = ok and ds.res is not None
+            if ok:
+                d.sub_seg[sb] = si
         d.lw_magic = (0x100000000 + LW - 1) // LW
         self._descs.append(d)
         self.macs[name + '#%d' % len(self._descs)] = cout * cin * taps * H * W * batch
@@ -570,6 +587,31 @@ class Engine(Plan):
         self._run(self.seg_t_head, stream)
         for it in range(n_updates):
             self._run(self.seg_iter[it], stream)
+
+    def profile(self, n_updates, reps=3):
+        """Per-launch durations (ms, best of ``reps``) of the trunk and one per-t pass, measured with HIP events on
+        the stream the kernels are launched on.  Returns a list of (segment, op kind, name, ms, macs)."""
+        stream = torch.cuda.current_stream(self.device)
+        h = stream.cuda_stream
+        segs = [('trunk', self.seg_trunk), ('t_head', self.seg_t_head)] + \
+               [('iter%d' % i, self.seg_iter[i]) for i in range(n_updates)]
+        out = []
+        for sname, ops in segs:
+            for op in ops:
+                best = 1e30
+                for _ in range(reps):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(stream)
+                    self._run([op], h)
+                    e1.record(stream)
+                    e1.synchronize()
+                    best = min(best, e0.elapsed_time(e1))
+                name = op[2] if op[0] == 'conv' else op[0]
+                macs = 0
+                if op[0] == 'conv':
+                    macs = self.macs[op[2] + '#%d' % (op[1] + 1)]
+                out.append((sname, op[0], name, best, macs))
+        return out
 
     def n_launches(self, n_updates):
         return len(self.seg_trunk), len(self.seg_t_head) + sum(len(s) for s in self.seg_iter[:n_updates])

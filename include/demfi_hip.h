@@ -124,6 +124,10 @@ typedef struct demfi_conv {
     int32_t oct_seg[DEMFI_MAX_OCTS];
     int32_t oct_n[DEMFI_MAX_OCTS];
     int32_t oct_ch[DEMFI_MAX_OCTS];
+    /* packed 32-cout subtile s: segment index when its 4 octets are one aligned run of 32 channels of an
+     * NHWC view of the path dtype (dst, and res/aux when present) -> coalesced LDS-staged epilogue;
+     * -1 -> per-octet direct epilogue (thin / planar / ragged outputs). */
+    int32_t sub_seg[DEMFI_MAX_OCTS / 4];
     /* magic = ceil(2^32 / LW), LW = (32-1)*stride + kw: exact px / LW for px < 2^16 (filled by host) */
     uint32_t lw_magic;
     uint32_t _pad2;
