@@ -14,8 +14,9 @@
 //                      [(8-1)*s+kh] x [(32-1)*s+kw] pixels is gathered from up to several source views into
 //                      LDS (record stride rec+16 B => conflict-free ds_read_b128 across 16 consecutive
 //                      pixels); every filter tap then reads its B fragments from LDS (kh*kw-fold reuse).
-//   weights          : pre-packed in A-fragment order (demfi_pack_conv_weights), read straight from
-//                      global/L2 with one coalesced 1 KiB load per wave per (tap, k-step, subtile).
+//   weights          : pre-packed in A-fragment order (demfi_pack_conv_weights); one tap's fragments are
+//                      DMA'd global->LDS (global_load_lds, 1 KiB per wave-instruction) into a 2-deep ring one
+//                      tap ahead of the MFMAs and shared by the 4 waves (one barrier per tap).
 //   epilogue         : bias + residual + activation / GRU gate math on the accumulators, routed per
 //                      8-cout octet to strided destination views (NHWC slices, planar fp32, PixelShuffle).
 //   grid             : x = spatial tiles (XCD-aware: each XCD's L2 gets a contiguous band of tiles so that
@@ -149,7 +150,18 @@ __global__ __launch_bounds__(NT, (NCO <= 1 ? 4 : (NCO == 2 ? 3 : 2))) void conv_
         for (int i = 0; i < 16; ++i) { acc[s][0][i] = 0.0f; acc[s][1][i] = 0.0f; }
     }
 
-    const uint4* __restrict__ wbase = (const uint4*)d->wpack + (int64_t)cblk * d->w_blk_stride + lane;
+    const uint4* __restrict__ wbase = (const uint4*)d->wpack + (int64_t)cblk * d->w_blk_stride;
+    const int ntaps = kh * kw;
+    const int wbuf_bytes = (d->rec_bytes >> 5) * NCO * 1024;        // one tap: nks_max x NCO fragments of 1 KiB
+    char* const wlds = smem + ((NP * rec + 1023) & ~1023);          // weight ring (2 taps) behind the input tile
+    // LDS-DMA of one tap's A fragments: piece i (1 KiB = 64 lanes x 16 B, already in fragment order) is fetched by
+    // wave i % 4 with global_load_lds (no VGPR round trip; LDS destination = uniform base + lane*16).
+    auto issue_weights = [&](const uint4* src, int buf, int nks_) {
+        char* dst = wlds + buf * wbuf_bytes;
+        for (int i = wave; i < nks_ * NCO; i += 4)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 64 + lane),
+                                             (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+    };
     // B-fragment base of this lane inside the LDS tile (pixel row 2*wave, column lx, upper half-wave = +16 B)
     const int bbase = ((wave * 2 * stride) * LW + lx * stride) * rec + hi * 16;
     const int brow = stride * LW * rec;      // second pixel row of this wave
@@ -157,7 +169,11 @@ __global__ __launch_bounds__(NT, (NCO <= 1 ? 4 : (NCO == 2 ? 3 : 2))) void conv_
     const int n_chunks = d->n_chunks;
     for (int c = 0; c < n_chunks; ++c) {
         const demfi_chunk& ch = d->chunks[c];
-        if (c > 0) __syncthreads();          // all waves done reading the previous chunk's tile
+        if (c > 0) __syncthreads();          // all waves done reading the previous chunk's tile / weight ring
+        const int nks = ch.nks;
+        const int wtap_vecs = nks * NCO * 64;                       // 16-byte vectors of one tap's weights
+        const uint4* __restrict__ wchunk = wbase + ch.w_off;
+        issue_weights(wchunk, 0, nks);                              // overlaps the tile staging below
         // ---------------- stage the haloed input tile of this chunk into LDS ----------------------------
         for (int pi = ch.first_piece; pi < ch.first_piece + ch.n_pieces; ++pi) {
             const demfi_piece& p = d->pieces[pi];
@@ -202,31 +218,29 @@ __global__ __launch_bounds__(NT, (NCO <= 1 ? 4 : (NCO == 2 ? 3 : 2))) void conv_
                 }
             }
         }
-        __syncthreads();
+        __syncthreads();                         // tile staged, tap-0 weights landed (the barrier drains vmcnt)
         // ---------------- MFMA over taps x k-steps -------------------------------------------------------
-        const int nks = ch.nks;
-        const uint4* __restrict__ wp = wbase + ch.w_off;
-        uint4 a_cur[NCO], a_nxt[NCO];
+        // A fragments come from the LDS weight ring (filled by LDS-DMA one tap ahead, shared by the 4 waves),
+        // B fragments from the staged input tile.
+        for (int tap = 0; tap < ntaps; ++tap) {
+            if (tap + 1 < ntaps) issue_weights(wchunk + (int64_t)(tap + 1) * wtap_vecs, (tap + 1) & 1, nks);
+            const char* wl = wlds + (tap & 1) * wbuf_bytes + lane * 16;
+            const int ky = tap / kw, kx = tap - ky * kw;
+            const int boff = bbase + (ky * LW + kx) * rec;
+#pragma unroll 2
+            for (int ks = 0; ks < nks; ++ks) {
+                uint4 a[NCO];
 #pragma unroll
-        for (int s = 0; s < NCO; ++s) a_cur[s] = wp[s * 64];
-        const int nsteps = kh * kw * nks;
-        int ky = 0, kx = 0, ks = 0;
-        for (int st = 0; st < nsteps; ++st) {
-            // prefetch the next step's A fragments (clamped on the last step: harmless re-read)
-            const uint4* wn = wp + (int64_t)(st + 1 < nsteps ? st + 1 : st) * (NCO * 64);
+                for (int s = 0; s < NCO; ++s) a[s] = *(const uint4*)(wl + (ks * NCO + s) * 1024);
+                const uint4 b0 = *(const uint4*)(smem + boff + ks * 32);
+                const uint4 b1 = *(const uint4*)(smem + boff + brow + ks * 32);
 #pragma unroll
-            for (int s = 0; s < NCO; ++s) a_nxt[s] = wn[s * 64];
-            const int boff = bbase + (ky * LW + kx) * rec + ks * 32;
-            const uint4 b0 = *(const uint4*)(smem + boff);
-            const uint4 b1 = *(const uint4*)(smem + boff + brow);
-#pragma unroll
-            for (int s = 0; s < NCO; ++s) {
-                Mma<T>::run(acc[s][0], a_cur[s], b0);
-                Mma<T>::run(acc[s][1], a_cur[s], b1);
+                for (int s = 0; s < NCO; ++s) {
+                    Mma<T>::run(acc[s][0], a[s], b0);
+                    Mma<T>::run(acc[s][1], a[s], b1);
+                }
             }
-#pragma unroll
-            for (int s = 0; s < NCO; ++s) a_cur[s] = a_nxt[s];
-            if (++ks == nks) { ks = 0; if (++kx == kw) { kx = 0; ++ky; } }
+            if (tap + 1 < ntaps) __syncthreads();     // next tap's weights landed; this tap's buffer is free
         }
     }
 
@@ -419,7 +433,8 @@ extern "C" int64_t demfi_conv_lds_bytes(const demfi_conv* h)
 {
     const int64_t LW = (int64_t)(TW - 1) * h->stride + h->kw;
     const int64_t LH = (int64_t)(TH - 1) * h->stride + h->kh;
-    const int64_t tile = LW * LH * (h->rec_bytes + REC_PAD);
+    const int64_t tile = ((LW * LH * (h->rec_bytes + REC_PAD) + 1023) & ~1023ll)
+                         + 2ll * (h->rec_bytes / 32) * h->nco * 1024;        // input tile + 2-tap weight ring
     const int64_t stage = 4 * 64 * STAGE_LD * 4;                 // 4 waves x 64 pixels x 36 floats
     return tile > stage ? tile : stage;
 }

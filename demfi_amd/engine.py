@@ -52,7 +52,7 @@ class Plan:
     """Descriptor builder + launcher shared by the full engine and by kernel-level tests: owns the packed
     weight blob, the descriptor array and a list of launch ops."""
 
-    LDS_BUDGET = 80 * 1024
+    LDS_BUDGET = 78 * 1024
 
     def __init__(self, H, W, dtype=torch.float16, device='cuda:0', state_dict=None):
         self.lib = L.load()
@@ -122,8 +122,12 @@ class Plan:
         esz = self.esz
         cpk = 32 // esz                                   # channels per k-step
         LH, LW = 7 * stride + kh, 31 * stride + kw
+        n_oct = sum(-(-len(ds.couts) // 8) for ds in dsts)
+        sub = -(-n_oct // 4)
+        nco = sub if sub <= 5 else 4
+        # LDS per workgroup = haloed input tile + 2-tap weight ring; keep it under the budget (2 workgroups per CU)
         rec = 128
-        while rec > 32 and LH * LW * (rec + 16) > self.LDS_BUDGET:
+        while rec > 32 and LH * LW * (rec + 16) + 2 * (rec // 32) * nco * 1024 > self.LDS_BUDGET:
             rec //= 2
         # ---- pack the input pieces into chunks of <= rec bytes (fat pieces first: 16-byte aligned) -------
         order = [s for s in srcs if s.fat] + [s for s in srcs if not s.fat]
@@ -186,8 +190,7 @@ class Plan:
                 octs.append((si, k, o))
                 cout_map.extend(ds.couts[o:o + k] + [-1] * (8 - k))
         assert sorted(c for c in cout_map if c >= 0) == list(range(cout)), '%s: outputs do not cover cout' % name
-        sub = -(-len(cout_map) // 32)
-        nco = sub if sub <= 5 else 4
+        assert sub == -(-len(cout_map) // 32)
         cout_pad = -(-sub // nco) * nco * 32
         while len(octs) < cout_pad // 8:
             octs.append((0, 0, 0))

@@ -1,0 +1,112 @@
+"""GPU-box probe: time / profile single kernels at the 720p working size through the C ABI.
+
+    python tools/conv_probe.py [case] [reps] [dtype]
+cases: c3x3 (64->64 3x3 batch 3, the D1 residual conv), c3x3res, c7x7 (192->64), c1x5 (128->128 GRU zr),
+       c1x1 (1152->96 half-res), warp (warp_blend fat C=64), cfr, all
+"""
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch                                             # noqa: E402
+
+from demfi_amd import _lib as L                          # noqa: E402
+from demfi_amd.engine import Plan, _Dst                  # noqa: E402
+
+H, W = 736, 1280
+DEV = 'cuda:0'
+
+
+def conv_case(pl, name, cin, cout, kh, kw, batch=1, res=False, h=H, w=W, act=L.ACT_RELU):
+    x = pl._fat(h, w, cin, batch)
+    x.copy_(torch.randn(x.shape, device=DEV) * 0.5)
+    out = pl._fat(h, w, cout, batch)
+    r = pl._fat(h, w, cout, batch) if res else None
+    if res:
+        r.copy_(torch.randn(r.shape, device=DEV) * 0.5)
+    wt = torch.randn(cout, cin, kh, kw) * (1.0 / (cin * kh * kw) ** 0.5)
+    seg = []
+    pl.conv(seg, name, [pl.fsrc(x, 0)], [_Dst(pl.fview(out), range(cout), act, res=pl.fview(r) if res else None)], h, w,
+            batch=batch, weight=wt, bias=torch.zeros(cout))
+    return 2.0 * cout * cin * kh * kw * h * w * batch
+
+
+def main():
+    case = sys.argv[1] if len(sys.argv) > 1 else 'all'
+    reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+    dtype = torch.float32 if len(sys.argv) > 3 and sys.argv[3] == 'fp32' else torch.float16
+    pl = Plan(H, W, dtype, DEV)
+    cases = []
+    if case in ('c3x3', 'all'):
+        cases.append(('c3x3 64->64 b3', conv_case(pl, 'c3x3', 64, 64, 3, 3, 3)))
+    if case in ('c3x3res', 'all'):
+        cases.append(('c3x3 64->64 b3 +res', conv_case(pl, 'c3x3res', 64, 64, 3, 3, 3, True, act=L.ACT_NONE)))
+    if case in ('c7x7', 'all'):
+        cases.append(('c7x7 192->64', conv_case(pl, 'c7x7', 192, 64, 7, 7, act=L.ACT_TANH)))
+    if case in ('c1x5', 'all'):
+        cases.append(('c1x5 128->128', conv_case(pl, 'c1x5', 128, 128, 1, 5, act=L.ACT_SIGMOID)))
+    if case in ('c1x1', 'all'):
+        cases.append(('c1x1 1152->96 half', conv_case(pl, 'c1x1', 1152, 96, 1, 1, h=H // 2, w=W // 2, act=L.ACT_NONE)))
+    if case in ('c3x3_32', 'all'):
+        cases.append(('c3x3 128->32 half', conv_case(pl, 'c3x3_32', 128, 32, 3, 3, h=H // 2, w=W // 2)))
+    if cases:
+        pl._upload()
+    st = torch.cuda.current_stream().cuda_stream
+    for i, (nm, fl) in enumerate(cases):
+        for _ in range(3):
+            pl.launch_conv(i, st)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            pl.launch_conv(i, st)
+        e1.record()
+        e1.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        print('%-24s %8.4f ms  %7.1f TFLOP/s' % (nm, ms, fl / ms / 1e9))
+    lib = L.load()
+    if case in ('warp', 'all'):
+        esz = 2 if dtype == torch.float16 else 4
+        A = torch.randn(H, W, 64, device=DEV).to(dtype)
+        B = torch.randn(H, W, 64, device=DEV).to(dtype)
+        O = torch.zeros(H, W, 64, device=DEV, dtype=dtype)
+        fl = (torch.randn(4, H, W, device=DEV) * 8).contiguous()
+        lg = torch.randn(H, W, device=DEV)
+        t = torch.tensor([0.375], device=DEV)
+        mk = lambda z: L.View(z.data_ptr(), 64, W * 64, 1, 0, 1 if dtype == torch.float32 else 0, 0)
+        va, vb, vo = mk(A), mk(B), mk(O)
+        run = lambda: L.check(lib.demfi_warp_blend(C.byref(va), fl.data_ptr(), C.byref(vb), fl[2:].data_ptr(), lg.data_ptr(),
+                                                   t.data_ptr(), C.byref(vo), 64, H, W, None, None, st))
+        for _ in range(3):
+            run()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            run()
+        e1.record()
+        e1.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        by = (3 * 64 * esz + 20) * H * W
+        print('%-24s %8.4f ms  %7.1f GB/s (algorithmic %d B/px)' % ('warp_blend fat C=64', ms, by / ms / 1e6, 3 * 64 * esz + 20))
+    if case in ('cfr', 'all'):
+        f01 = (torch.randn(2, H, W, device=DEV) * 8).contiguous()
+        f10 = (torch.randn(2, H, W, device=DEV) * 8).contiguous()
+        acc = torch.zeros(6 * H * W, dtype=torch.int64, device=DEV)
+        out = torch.zeros(4, H, W, device=DEV)
+        t = torch.tensor([0.375], device=DEV)
+        run = lambda: L.check(lib.demfi_cfr_flow_align(f01.data_ptr(), f10.data_ptr(), t.data_ptr(), H, W, acc.data_ptr(),
+                                                       out.data_ptr(), None, st))
+        for _ in range(3):
+            run()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            run()
+        e1.record()
+        e1.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        print('%-24s %8.4f ms  %7.1f GB/s (algorithmic 32 B/px)' % ('cfr_flow_align', ms, 32.0 * H * W / ms / 1e6))
+
+
+if __name__ == '__main__':
+    main()
