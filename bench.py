@@ -44,12 +44,12 @@ def parse():
 
 def cpu_baseline(n_tst, full_px):
     """Oracle (CPU restatement, reference semantics: one FULL forward per t, no trunk caching) on a bounded sample:
-    a 368x640 frame = 1/4 of the padded 736x1280 pixels, one t; scaled to 720p-equivalent frames/s."""
+    a 184x320 frame = 1/16 of the padded 736x1280 pixels, one t; scaled to 720p-equivalent frames/s."""
     from demfi_amd import synthetic_state_dict, synthetic_window
     from oracle import demfi_oracle as O
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))       # beyond ~32 threads MKLDNN convs of this size slow down
     sd = synthetic_state_dict(0)
-    h, w = 368, 640
+    h, w = 184, 320
     x = synthetic_window(h, w, 1)
     t = torch.tensor([[0.5]])
     with torch.no_grad():
