@@ -123,8 +123,8 @@ def main():
         tot_conv_fl = 2.0 * sum(p[4] for p in convs)
         peak = MFMA_PEAK_TF[a.dtype]
         ach = g_fl / (g_ms * 1e-3) / 1e12
-        out['roofline'] = {'kernel': 'conv_kernel<%s,NCO=2> 3x3 64->64 batch 3 (D1 residual blocks, %d launches/frame)' %
-                                     (a.dtype, len(grp)), 'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak,
+        out['roofline'] = {'kernel': '%s 3x3 64->64 batch 3 (D1 residual blocks, %d launches/frame)' %
+                                     ('conv3x3_c64_persist_kernel<2>' if a.dtype == 'fp16' else 'conv_kernel<float,2>', len(grp)), 'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak,
                            'unit': 'TFLOP/s', 'frac': round(ach / peak, 4), 'traffic': None,
                            'avg_launch_ms': round(g_ms, 4), 'flop_per_launch': g_fl,
                            'all_convs_TFLOPs': round(tot_conv_fl / (tot_conv_ms * 1e-3) / 1e12, 2),

@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libdemfi_hip.so')
+LIB_PATH = os.environ.get('DEMFI_HIP_LIB') or os.path.join(_HERE, 'csrc', 'libdemfi_hip.so')   # override: ablation builds
 
 F16, F32 = 0, 1
 ACT_NONE, ACT_RELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3
@@ -39,7 +39,7 @@ class Conv(C.Structure):
                 ('kh', C.c_int32), ('kw', C.c_int32), ('stride', C.c_int32), ('pad_y', C.c_int32),
                 ('pad_x', C.c_int32), ('batch', C.c_int32), ('cout_pad', C.c_int32), ('nco', C.c_int32),
                 ('rec_bytes', C.c_int32), ('n_chunks', C.c_int32), ('n_pieces', C.c_int32), ('n_segs', C.c_int32),
-                ('_pad', C.c_int32), ('w_blk_stride', C.c_int64), ('wpack', C.c_void_p), ('bias', C.c_void_p),
+                ('_pad', C.c_int32), ('w_blk_stride', C.c_int64), ('wpack', C.c_void_p), ('bias', C.c_void_p), ('zero_page', C.c_void_p),
                 ('chunks', Chunk * MAX_CHUNKS), ('pieces', Piece * MAX_PIECES), ('segs', Seg * MAX_SEGS),
                 ('oct_seg', C.c_int32 * MAX_OCTS), ('oct_n', C.c_int32 * MAX_OCTS), ('oct_ch', C.c_int32 * MAX_OCTS),
                 ('sub_seg', C.c_int32 * (MAX_OCTS // 4)),

@@ -20,15 +20,26 @@ int demfi_set_error(int code, const char* fmt, ...);
             return demfi_set_error(DEMFI_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e__)); \
     } while (0)
 
+// Pointers that arrive inside descriptors / views are generic to the compiler; accessing them as such emits FLAT
+// instructions (slower issue, tie up lgkmcnt as well as vmcnt, and force conservative waits around LDS traffic).
+// Every buffer of this library lives in global memory: say so.
+#define DEMFI_GLOBAL __attribute__((address_space(1)))
+template <typename T> __device__ __forceinline__ const DEMFI_GLOBAL T* gcp(const void* p) { return (const DEMFI_GLOBAL T*)p; }
+template <typename T> __device__ __forceinline__ DEMFI_GLOBAL T* gp(void* p) { return (DEMFI_GLOBAL T*)p; }
+typedef unsigned int u4_t __attribute__((ext_vector_type(4)));
+// 16-byte global load / store (HIP's uint4 is a class and cannot be accessed through an address-space pointer)
+__device__ __forceinline__ uint4 ld_global16(const void* p) { return __builtin_bit_cast(uint4, *gcp<u4_t>(p)); }
+__device__ __forceinline__ void st_global16(void* p, const uint4& v) { *gp<u4_t>(p) = __builtin_bit_cast(u4_t, v); }
+
 // ---- element access through demfi_view (device) --------------------------------------------------
 __device__ __forceinline__ float view_load(const demfi_view& v, int64_t off)
 {
-    return v.is_f32 ? ((const float*)v.ptr)[off] : (float)((const half_t*)v.ptr)[off];
+    return v.is_f32 ? gcp<float>(v.ptr)[off] : (float)gcp<half_t>(v.ptr)[off];
 }
 __device__ __forceinline__ void view_store(const demfi_view& v, int64_t off, float x)
 {
-    if (v.is_f32) ((float*)v.ptr)[off] = x;
-    else ((half_t*)v.ptr)[off] = (half_t)x;
+    if (v.is_f32) gp<float>(v.ptr)[off] = x;
+    else gp<half_t>(v.ptr)[off] = (half_t)x;
 }
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }

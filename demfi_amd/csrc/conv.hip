@@ -23,6 +23,7 @@
 //                      halos are shared inside one L2), y = cout blocks, z = batch.
 #include "common.h"
 #include <type_traits>
+#include <stdlib.h>
 
 namespace {
 
@@ -67,13 +68,13 @@ constexpr int STAGE_LD = 36;          // floats per staged pixel row: 32 couts +
 template <typename T> __device__ __forceinline__ void load8(const T* p, float* o);
 template <> __device__ __forceinline__ void load8<half_t>(const half_t* p, float* o)
 {
-    const h8_t v = *(const h8_t*)p;
+    const h8_t v = *gcp<h8_t>(p);
 #pragma unroll
     for (int j = 0; j < 8; ++j) o[j] = (float)v[j];
 }
 template <> __device__ __forceinline__ void load8<float>(const float* p, float* o)
 {
-    const f4_t a = *(const f4_t*)p, b = *(const f4_t*)(p + 4);
+    const f4_t a = *gcp<f4_t>(p), b = *gcp<f4_t>(p + 4);
 #pragma unroll
     for (int j = 0; j < 4; ++j) { o[j] = a[j]; o[4 + j] = b[j]; }
 }
@@ -83,15 +84,37 @@ template <> __device__ __forceinline__ void store8<half_t>(half_t* p, const floa
     h8_t o;
 #pragma unroll
     for (int j = 0; j < 8; ++j) o[j] = (half_t)v[j];
-    *(h8_t*)p = o;
+    *gp<h8_t>(p) = o;
 }
 template <> __device__ __forceinline__ void store8<float>(float* p, const float* v)
 {
     f4_t a, b;
 #pragma unroll
     for (int j = 0; j < 4; ++j) { a[j] = v[j]; b[j] = v[4 + j]; }
-    *(f4_t*)p = a;
-    *(f4_t*)(p + 4) = b;
+    *gp<f4_t>(p) = a;
+    *gp<f4_t>(p + 4) = b;
+}
+
+// Activation of N values behind ONE wave-uniform switch (a per-element switch compiles to a maze of scalar
+// branches: ~8 s_cbranch per element dominated the epilogue).
+template <int N>
+__device__ __forceinline__ void apply_act_n(float (&v)[N], int act)
+{
+    switch (act) {
+    case DEMFI_ACT_RELU:
+#pragma unroll
+        for (int j = 0; j < N; ++j) v[j] = fmaxf(v[j], 0.0f);
+        break;
+    case DEMFI_ACT_TANH:
+#pragma unroll
+        for (int j = 0; j < N; ++j) v[j] = tanhf(v[j]);
+        break;
+    case DEMFI_ACT_SIGMOID:
+#pragma unroll
+        for (int j = 0; j < N; ++j) v[j] = 1.0f / (1.0f + expf(-v[j]));
+        break;
+    default: break;
+    }
 }
 
 __device__ __forceinline__ float apply_act(float v, int act)
@@ -100,6 +123,169 @@ __device__ __forceinline__ float apply_act(float v, int act)
     if (act == DEMFI_ACT_TANH) return tanhf(v);
     if (act == DEMFI_ACT_SIGMOID) return sigmoidf_(v);
     return v;
+}
+
+// ---- epilogue shared by the general and the persistent kernel -------------------------------------------
+// acc[s][p][r]: pixel (oy0 + 2*wave + p, ox0 + lx), packed cout (cblk*NCO+s)*32 + 8*(r>>2) + 4*hi + (r&3).
+// 'smem' must be free for reuse (the caller has synchronised the workgroup after the last tile read).
+template <typename T, int NCO, bool BLOCK_SYNC>
+__device__ __forceinline__ void conv_epilogue(const demfi_conv* __restrict__ d, f16x_t (&acc)[NCO][2], char* smem,
+                                              int wave, int lane, int cblk, int bimg, int oy0, int ox0, int H, int W)
+{
+    const int hi = lane >> 5;
+    const int lx = lane & 31;
+    const float* __restrict__ bias = d->bias;
+    const int ox = ox0 + lx;
+
+    // ---- staged path: a 32-cout subtile whose 4 octets form one NHWC run of the path dtype goes through a
+    // wave-private LDS transpose so that every lane owns 8 consecutive channels of one pixel: residual / gate
+    // loads and the store are 16-byte (fp16) or 2x16-byte (fp32) accesses covering whole 64-byte runs per
+    // pixel, instead of 8-byte accesses at a 128-byte lane stride.
+    if constexpr (BLOCK_SYNC) __syncthreads();         // every wave is done reading the input tile
+    // The staging area is wave-private: LDS instructions of one wave execute in order, so the write -> read ->
+    // rewrite sequence below needs no workgroup barrier, only a compiler scheduling fence.
+    float* stage = (float*)(smem + wave * (64 * STAGE_LD * 4));
+    static_for<0, NCO>([&](auto S) {
+        constexpr int s = decltype(S)::value;
+        const int sub = cblk * NCO + s;
+        const int segi = d->sub_seg[sub];
+        if (segi < 0) return;                          // uniform
+        const demfi_seg& sg = d->segs[segi];
+        const int ch0 = d->oct_ch[sub * 4];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f4_t bq = *gcp<f4_t>(bias + sub * 32 + g * 8 + 4 * hi);
+                f4_t v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = acc[s][p][g * 4 + j] + bq[j];
+                *(f4_t*)(stage + (p * 32 + lx) * STAGE_LD + g * 8 + 4 * hi) = v;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int mode = sg.mode, act = sg.act;
+        const T* resp = (const T*)sg.res.ptr;
+        const T* auxp = (const T*)sg.aux.ptr;
+        T* dstp = (T*)sg.dst.ptr;
+        const int q = lane & 3;
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const int px = pass * 16 + (lane >> 2);
+            const int oy = oy0 + wave * 2 + (px >> 5);
+            const int oxx = ox0 + (px & 31);
+            if (oy >= H || oxx >= W) continue;
+            float v[8];
+            {
+                const f4_t v0 = *(const f4_t*)(stage + px * STAGE_LD + q * 8);
+                const f4_t v1 = *(const f4_t*)(stage + px * STAGE_LD + q * 8 + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { v[j] = v0[j]; v[4 + j] = v1[j]; }
+            }
+            const int cq = ch0 + q * 8;
+            if (resp != nullptr) {
+                float r[8];
+                load8<T>(resp + (int64_t)bimg * sg.res.sb + (int64_t)oy * sg.res.sy + (int64_t)oxx * sg.res.sx + cq, r);
+                if (mode == DEMFI_MODE_STORE) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = v[j] + r[j];
+                    apply_act_n<8>(v, act);
+                } else if (mode == DEMFI_MODE_MUL) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = sigmoidf_(v[j]) * r[j];
+                } else {
+                    float z[8];
+                    load8<T>(auxp + (int64_t)bimg * sg.aux.sb + (int64_t)oy * sg.aux.sy + (int64_t)oxx * sg.aux.sx + cq, z);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = (1.0f - z[j]) * r[j] + z[j] * tanhf(v[j]);
+                }
+            } else {
+                apply_act_n<8>(v, act);
+            }
+            const int dyy = oy * sg.scale + sg.dy, dxx = oxx * sg.scale + sg.dx;
+            store8<T>(dstp + (int64_t)bimg * sg.dst.sb + (int64_t)dyy * sg.dst.sy + (int64_t)dxx * sg.dst.sx + cq, v);
+        }
+        __builtin_amdgcn_wave_barrier();
+    });
+
+    // ---- direct path (thin / planar / ragged destinations): straight from the accumulator layout ----------
+    static_for<0, NCO * 4>([&](auto SG) {
+        {
+            constexpr int s = decltype(SG)::value >> 2;
+            constexpr int g = decltype(SG)::value & 3;
+            if (d->sub_seg[cblk * NCO + s] >= 0) return;
+            const int oct = (cblk * NCO + s) * 4 + g;
+            const int on = d->oct_n[oct];
+            if (on == 0) return;
+            const demfi_seg& sg = d->segs[d->oct_seg[oct]];
+            const int nq = min(max(on - 4 * hi, 0), 4);               // valid channels of this lane's quad
+            const int cq = d->oct_ch[oct] + 4 * hi;                   // first channel inside the seg's views
+            const f4_t bq = *gcp<f4_t>(bias + oct * 8 + 4 * hi);
+            const int mode = sg.mode, act = sg.act;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int oy = oy0 + wave * 2 + p;
+                if (oy >= H || ox >= W || nq == 0) continue;
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = acc[s][p][g * 4 + j] + bq[j];
+                const bool hasres = sg.res.ptr != nullptr;
+                if (hasres) {
+                    const int64_t ro = (int64_t)bimg * sg.res.sb + (int64_t)oy * sg.res.sy + (int64_t)ox * sg.res.sx
+                                       + (int64_t)cq * sg.res.sc;
+                    float r[4];
+                    if (sg.res.sc == 1 && nq == 4 && !sg.res.is_f32) {
+                        h4_t rv = *gcp<h4_t>((const half_t*)sg.res.ptr + ro);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) r[j] = (float)rv[j];
+                    } else if (sg.res.sc == 1 && nq == 4) {
+                        f4_t rv = *gcp<f4_t>((const float*)sg.res.ptr + ro);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) r[j] = rv[j];
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) r[j] = j < nq ? view_load(sg.res, ro + j * sg.res.sc) : 0.0f;
+                    }
+                    if (mode == DEMFI_MODE_STORE) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = v[j] + r[j];
+                        apply_act_n<4>(v, act);
+                    } else if (mode == DEMFI_MODE_MUL) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = sigmoidf_(v[j]) * r[j];
+                    } else {   // GRU: (1-z)*h + z*tanh(v)
+                        const int64_t ao = (int64_t)bimg * sg.aux.sb + (int64_t)oy * sg.aux.sy
+                                           + (int64_t)ox * sg.aux.sx + (int64_t)cq * sg.aux.sc;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float z = j < nq ? view_load(sg.aux, ao + j * sg.aux.sc) : 0.0f;
+                            v[j] = (1.0f - z) * r[j] + z * tanhf(v[j]);
+                        }
+                    }
+                } else {
+                    apply_act_n<4>(v, act);
+                }
+                const int dyy = oy * sg.scale + sg.dy, dxx = ox * sg.scale + sg.dx;
+                const int64_t dofs = (int64_t)bimg * sg.dst.sb + (int64_t)dyy * sg.dst.sy + (int64_t)dxx * sg.dst.sx
+                                     + (int64_t)cq * sg.dst.sc;
+                if (sg.dst.sc == 1 && nq == 4 && !sg.dst.is_f32) {
+                    h4_t o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = (half_t)v[j];
+                    *gp<h4_t>((half_t*)sg.dst.ptr + dofs) = o;
+                } else if (sg.dst.sc == 1 && nq == 4) {
+                    f4_t o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = v[j];
+                    *gp<f4_t>((float*)sg.dst.ptr + dofs) = o;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (j < nq) view_store(sg.dst, dofs + j * sg.dst.sc, v[j]);
+                }
+            }
+        }
+    });
 }
 
 // second launch_bounds argument = minimum waves per SIMD: 2-3 resident workgroups per CU let one workgroup's
@@ -194,7 +380,7 @@ __global__ __launch_bounds__(NT, (NCO <= 1 ? 4 : (NCO == 2 ? 3 : 2))) void conv_
                     const int iy = iy0 + ly, ix = ix0 + lxx;
                     uint4 val = make_uint4(0, 0, 0, 0);
                     if (src != nullptr && iy >= 0 && iy < inH && ix >= 0 && ix < inW)
-                        val = *(const uint4*)(srcb + (iy >> ush) * sy + (ix >> ush) * sx + v * 16);
+                        val = ld_global16(srcb + (iy >> ush) * sy + (ix >> ush) * sx + v * 16);
                     *(uint4*)(smem + px * rec + ldsoff + v * 16) = val;
                 }
             } else {
@@ -211,7 +397,7 @@ __global__ __launch_bounds__(NT, (NCO <= 1 ? 4 : (NCO == 2 ? 3 : 2))) void conv_
                         float val = 0.0f;
                         if (src != nullptr && iy >= 0 && iy < inH && ix >= 0 && ix < inW) {
                             const int64_t off = coff + (int64_t)(iy >> ush) * p.v.sy + (int64_t)(ix >> ush) * p.v.sx;
-                            val = f32src ? ((const float*)src)[off] : (float)((const half_t*)src)[off];
+                            val = f32src ? gcp<float>(src)[off] : (float)gcp<half_t>(src)[off];
                         }
                         *(T*)(smem + px * rec + ldsoff) = (T)val;
                     }
@@ -245,157 +431,316 @@ __global__ __launch_bounds__(NT, (NCO <= 1 ? 4 : (NCO == 2 ? 3 : 2))) void conv_
     }
 
     // ---------------- epilogue --------------------------------------------------------------------------
-    // acc[s][p][r]: pixel (oy0 + 2*wave + p, ox0 + lx), packed cout (cblk*NCO+s)*32 + 8*(r>>2) + 4*hi + (r&3)
-    const float* __restrict__ bias = d->bias;
-    const int ox = ox0 + lx;
+    conv_epilogue<T, NCO, true>(d, acc, smem, wave, lane, cblk, bimg, oy0, ox0, H, W);
+}
 
-    // ---- staged path: a 32-cout subtile whose 4 octets form one NHWC run of the path dtype goes through a
-    // wave-private LDS transpose so that every lane owns 8 consecutive channels of one pixel: residual / gate
-    // loads and the store are 16-byte (fp16) or 2x16-byte (fp32) accesses covering whole 64-byte runs per
-    // pixel, instead of 8-byte accesses at a 128-byte lane stride.
-    __syncthreads();                                   // every wave is done reading the input tile
-    float* stage = (float*)(smem + wave * (64 * STAGE_LD * 4));
-    static_for<0, NCO>([&](auto S) {
-        constexpr int s = decltype(S)::value;
-        const int sub = cblk * NCO + s;
-        const int segi = d->sub_seg[sub];
-        if (segi < 0) return;                          // uniform
-        const demfi_seg& sg = d->segs[segi];
-        const int ch0 = d->oct_ch[sub * 4];
+
+// ======================================================================================================
+// Persistent specialisation for the workhorse shape of the network: fp16, stride 1, KHxKW filter, ONE NHWC
+// input of 64 channels (128-byte pixel records), <= 64 output channels (all 3x3 64->64 layers of the FAC-FB
+// encoder, D1 and D2: ~52 % of the MACs of a forward).
+//   * one workgroup per CU walks many 8x32 output tiles (XCD-aware bands);
+//   * ALL filter taps stay resident in LDS for the whole launch (72 KiB for 3x3x64x64) -> no per-tap weight
+//     traffic and no per-tap barriers;
+//   * the haloed input tile is fetched by LDS-DMA (global_load_lds, no VGPR round trip, zero padding through a
+//     zero page) into a double buffer: tile k+1 streams in while tile k is on the matrix cores;
+//   * pixel records are unpadded (128 B); bank conflicts are removed by an XOR swizzle of the 16-byte slot,
+//     applied on the DMA's per-lane SOURCE address and on the ds_read address (the LDS image stays lane-linear).
+// ======================================================================================================
+constexpr int P_LW = TW + 2, P_LH = TH + 2;                    // 3x3 halo
+constexpr int P_NP = P_LW * P_LH;                               // 340 pixels
+constexpr int P_NI = (P_NP + 7) / 8;                            // 43 DMA instructions (8 pixels x 8 slots each)
+constexpr int P_TILE_BYTES = P_NI * 1024;                       // 44,032 B per buffer
+
+constexpr int P_NT = NT + 64;                                   // 4 MFMA waves + 1 DMA wave
+
+// One k-step pair of fragments: 2 k-steps x (NCO A fragments + 2 B fragments)
+template <int NCO> struct FragSet { uint4 a[2][NCO]; uint4 b[2][2]; };
+
+template <int NCO, int VAR>      // VAR: 0 = product; 1 no epilogue, 2 no MFMA phase, 3 no tile DMA, 4 epilogue only (ablation builds)
+__global__ __launch_bounds__(P_NT, 1) void conv3x3_c64_persist_kernel(const demfi_conv* __restrict__ d)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NTAPS = 9, NKS = 4;
+    constexpr int WBYTES = NTAPS * NKS * NCO * 1024;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int H = d->H, W = d->W;
+    const int tiles_x = (W + TW - 1) / TW;
+    const int tiles_y = (H + TH - 1) / TH;
+    const int tiles_img = tiles_x * tiles_y;
+    const int total = tiles_img * d->batch;
+    char* const wlds = smem;                                    // resident weights
+    char* const tbuf = smem + WBYTES;                           // 2 x tile buffer
+
+    // tile sequence of this workgroup: XCD x = b & 7 owns the contiguous band [lo, hi) of tile indices
+    const int G = gridDim.x;
+    int t_first, t_end, t_step;
+    if ((G & 7) == 0 && total >= G) {
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        const int q = total >> 3, r = total & 7;
+        const int lo = xcd * q + min(xcd, r);
+        t_first = lo + idx;
+        t_end = lo + q + (xcd < r ? 1 : 0);
+        t_step = G >> 3;
+    } else {
+        t_first = blockIdx.x;
+        t_end = total;
+        t_step = G;
+    }
+    if (t_first >= t_end) return;                               // uniform per workgroup
+
+    auto tile_coords = [&](int t, int& bimg, int& oy0, int& ox0) {
+        bimg = t / tiles_img;
+        const int rem = t - bimg * tiles_img;
+        const int ty = rem / tiles_x;
+        oy0 = ty * TH;
+        ox0 = (rem - ty * tiles_x) * TW;
+    };
+
+    if (wave == 4) {
+        // ================= DMA wave: owns every global->LDS transfer, so only ITS vmcnt tracks them ==============
+        const demfi_piece& pc = d->pieces[0];
+        const char* const src = (const char*)pc.v.ptr;
+        const int64_t sx = pc.v.sx * 2, sy = pc.v.sy * 2, sb = pc.v.sb * 2;
+        const char* const zeros = (const char*)d->zero_page;
+        // instruction i covers pixels 8i..8i+7; lane -> (pixel 8i + lane/8, physical 16-byte slot lane%8).
+        // The per-lane byte offsets relative to the tile origin and the (row, column) pairs never change: compute
+        // them once (86 VGPRs) so that issuing a tile is ~4 VALU per DMA instruction instead of ~50.
+        int off[P_NI], lyx[P_NI];
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f4_t bq = *(const f4_t*)(bias + sub * 32 + g * 8 + 4 * hi);
-                f4_t v;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = acc[s][p][g * 4 + j] + bq[j];
-                *(f4_t*)(stage + (p * 32 + lx) * STAGE_LD + g * 8 + 4 * hi) = v;
-            }
+        for (int i = 0; i < P_NI; ++i) {
+            const int px = i * 8 + (lane >> 3);
+            const int ly = px / P_LW;
+            const int lxx = px - ly * P_LW;
+            const int v = (lane & 7) ^ ((px >> 1) & 7);                 // logical slot stored at this physical slot
+            off[i] = (int)(ly * sy + lxx * sx) + v * 16;
+            lyx[i] = px < P_NP ? (ly | (lxx << 8)) : 0xffff;
         }
-        __syncthreads();
-        const int mode = sg.mode, act = sg.act;
-        const T* resp = (const T*)sg.res.ptr;
-        const T* auxp = (const T*)sg.aux.ptr;
-        T* dstp = (T*)sg.dst.ptr;
-        const int q = lane & 3;
+        auto issue_tile = [&](int t, int buf) {
+            int bimg, oy0, ox0;
+            tile_coords(t, bimg, oy0, ox0);
+            const char* base = src + (int64_t)bimg * sb + (int64_t)(oy0 - 1) * sy + (int64_t)(ox0 - 1) * sx;
+            char* dst = tbuf + buf * P_TILE_BYTES;
+            const bool interior = oy0 >= 1 && oy0 + TH + 1 <= H && ox0 >= 1 && ox0 + TW + 1 <= W;
+            if (interior) {
 #pragma unroll
-        for (int pass = 0; pass < 4; ++pass) {
-            const int px = pass * 16 + (lane >> 2);
-            const int oy = oy0 + wave * 2 + (px >> 5);
-            const int oxx = ox0 + (px & 31);
-            if (oy >= H || oxx >= W) continue;
-            float v[8];
-            {
-                const f4_t v0 = *(const f4_t*)(stage + px * STAGE_LD + q * 8);
-                const f4_t v1 = *(const f4_t*)(stage + px * STAGE_LD + q * 8 + 4);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { v[j] = v0[j]; v[4 + j] = v1[j]; }
-            }
-            const int cq = ch0 + q * 8;
-            if (resp != nullptr) {
-                float r[8];
-                load8<T>(resp + (int64_t)bimg * sg.res.sb + (int64_t)oy * sg.res.sy + (int64_t)oxx * sg.res.sx + cq, r);
-                if (mode == DEMFI_MODE_STORE) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] = apply_act(v[j] + r[j], act);
-                } else if (mode == DEMFI_MODE_MUL) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] = sigmoidf_(v[j]) * r[j];
-                } else {
-                    float z[8];
-                    load8<T>(auxp + (int64_t)bimg * sg.aux.sb + (int64_t)oy * sg.aux.sy + (int64_t)oxx * sg.aux.sx + cq, z);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] = (1.0f - z[j]) * r[j] + z[j] * tanhf(v[j]);
+                for (int i = 0; i < P_NI; ++i) {
+                    const char* g = (i == P_NI - 1 && lyx[i] == 0xffff) ? zeros : base + off[i];
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                                     (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
                 }
             } else {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = apply_act(v[j], act);
+                for (int i = 0; i < P_NI; ++i) {
+                    const int iy = oy0 - 1 + (lyx[i] & 255), ix = ox0 - 1 + (lyx[i] >> 8);
+                    const char* g = (lyx[i] != 0xffff && iy >= 0 && iy < H && ix >= 0 && ix < W) ? base + off[i] : zeros;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                                     (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+                }
             }
-            const int dyy = oy * sg.scale + sg.dy, dxx = oxx * sg.scale + sg.dx;
-            store8<T>(dstp + (int64_t)bimg * sg.dst.sb + (int64_t)dyy * sg.dst.sy + (int64_t)dxx * sg.dst.sx + cq, v);
+        };
+        const uint4* wsrc = (const uint4*)d->wpack;
+        for (int i = 0; i < NTAPS * NKS * NCO; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + i * 64 + lane),
+                                             (__attribute__((address_space(3))) void*)(wlds + i * 1024), 16, 0, 0);
+        issue_tile(t_first, 0);
+        int buf = 0;
+        for (int t = t_first; t < t_end; t += t_step, buf ^= 1) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tile t (and the weights) have landed in LDS
+            __syncthreads();                                    // A: hand tile t to the MFMA waves
+            if (VAR != 3 && VAR != 4 && t + t_step < t_end) issue_tile(t + t_step, buf ^ 1);   // streams in under the MFMAs
+            __syncthreads();                                    // B: (MFMA waves finished reading tile t)
         }
-        __syncthreads();
-    });
+        return;
+    }
 
-    // ---- direct path (thin / planar / ragged destinations): straight from the accumulator layout ----------
-    static_for<0, NCO * 4>([&](auto SG) {
-        {
-            constexpr int s = decltype(SG)::value >> 2;
-            constexpr int g = decltype(SG)::value & 3;
-            if (d->sub_seg[cblk * NCO + s] >= 0) return;
-            const int oct = (cblk * NCO + s) * 4 + g;
-            const int on = d->oct_n[oct];
-            if (on == 0) return;
-            const demfi_seg& sg = d->segs[d->oct_seg[oct]];
-            const int nq = min(max(on - 4 * hi, 0), 4);               // valid channels of this lane's quad
-            const int cq = d->oct_ch[oct] + 4 * hi;                   // first channel inside the seg's views
-            const f4_t bq = *(const f4_t*)(bias + oct * 8 + 4 * hi);
-            const int mode = sg.mode, act = sg.act;
+    // ================= MFMA waves ============================================================================
+    const int hi = lane >> 5;
+    const int lx = lane & 31;
+    // ---- everything the epilogue needs from the descriptor, hoisted out of the tile loop (barriers are memory
+    // fences: descriptor fields read inside the loop would be re-fetched through dependent scalar loads per tile)
+    const demfi_seg& sg0 = d->segs[d->sub_seg[0]];
+    half_t* const dstp = (half_t*)sg0.dst.ptr;
+    const half_t* const resp = (const half_t*)sg0.res.ptr;
+    const int64_t d_sx = sg0.dst.sx, d_sy = sg0.dst.sy, d_sb = sg0.dst.sb;
+    const int64_t r_sx = sg0.res.sx, r_sy = sg0.res.sy, r_sb = sg0.res.sb;
+    const float act_floor = sg0.act == DEMFI_ACT_RELU ? 0.0f : -__builtin_huge_valf();
+    const int ch0 = d->oct_ch[0];
+    constexpr int LPP = NCO * 4;                                // lanes per pixel in the store phase (16 B each)
+    constexpr int PXP = 64 / LPP;                               // pixels per store pass
+    constexpr int NPASS = 32 / PXP;                             // passes per 32-pixel row
+    constexpr int SLD = NCO * 32 + 4;                           // staged row: NCO*32 couts + 4 pad floats
+    const int e_px = lane / LPP, e_q = lane % LPP;              // store phase: pixel within pass, 8-channel group
+    float bias8[8];                                             // bias of the 8 channels this lane stores
+    {
+        const f4_t b0 = *gcp<f4_t>(d->bias + e_q * 8), b1 = *gcp<f4_t>(d->bias + e_q * 8 + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { bias8[j] = b0[j]; bias8[4 + j] = b1[j]; }
+    }
+
+    const int pxbase = (wave * 2) * P_LW + lx;                  // tile-linear pixel of (row 2*wave, column lx), tap (0,0)
+    const char* const wl = wlds + lane * 16;
+    int buf = 0;
+    for (int t = t_first; t < t_end; t += t_step, buf ^= 1) {
+        int bimg, oy0, ox0;
+        tile_coords(t, bimg, oy0, ox0);
+        // residual of this tile: issued before the MFMA phase, consumed in the epilogue (latency fully hidden)
+        uint4 rreg[2][NPASS];
+        if (resp != nullptr) {
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
-                const int oy = oy0 + wave * 2 + p;
-                if (oy >= H || ox >= W || nq == 0) continue;
-                float v[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = acc[s][p][g * 4 + j] + bq[j];
-                const bool hasres = sg.res.ptr != nullptr;
-                if (hasres) {
-                    const int64_t ro = (int64_t)bimg * sg.res.sb + (int64_t)oy * sg.res.sy + (int64_t)ox * sg.res.sx
-                                       + (int64_t)cq * sg.res.sc;
-                    float r[4];
-                    if (sg.res.sc == 1 && nq == 4 && !sg.res.is_f32) {
-                        h4_t rv = *(const h4_t*)((const half_t*)sg.res.ptr + ro);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) r[j] = (float)rv[j];
-                    } else if (sg.res.sc == 1 && nq == 4) {
-                        f4_t rv = *(const f4_t*)((const float*)sg.res.ptr + ro);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) r[j] = rv[j];
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) r[j] = j < nq ? view_load(sg.res, ro + j * sg.res.sc) : 0.0f;
-                    }
-                    if (mode == DEMFI_MODE_STORE) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] = apply_act(v[j] + r[j], act);
-                    } else if (mode == DEMFI_MODE_MUL) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] = sigmoidf_(v[j]) * r[j];
-                    } else {   // GRU: (1-z)*h + z*tanh(v)
-                        const int64_t ao = (int64_t)bimg * sg.aux.sb + (int64_t)oy * sg.aux.sy
-                                           + (int64_t)ox * sg.aux.sx + (int64_t)cq * sg.aux.sc;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const float z = j < nq ? view_load(sg.aux, ao + j * sg.aux.sc) : 0.0f;
-                            v[j] = (1.0f - z) * r[j] + z * tanhf(v[j]);
-                        }
-                    }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = apply_act(v[j], act);
-                }
-                const int dyy = oy * sg.scale + sg.dy, dxx = ox * sg.scale + sg.dx;
-                const int64_t dofs = (int64_t)bimg * sg.dst.sb + (int64_t)dyy * sg.dst.sy + (int64_t)dxx * sg.dst.sx
-                                     + (int64_t)cq * sg.dst.sc;
-                if (sg.dst.sc == 1 && nq == 4 && !sg.dst.is_f32) {
-                    h4_t o;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] = (half_t)v[j];
-                    *(h4_t*)((half_t*)sg.dst.ptr + dofs) = o;
-                } else if (sg.dst.sc == 1 && nq == 4) {
-                    f4_t o;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] = v[j];
-                    *(f4_t*)((float*)sg.dst.ptr + dofs) = o;
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (j < nq) view_store(sg.dst, dofs + j * sg.dst.sc, v[j]);
+                for (int ps = 0; ps < NPASS; ++ps) {
+                    const int oy = oy0 + wave * 2 + p, oxx = ox0 + ps * PXP + e_px;
+                    rreg[p][ps] = make_uint4(0, 0, 0, 0);
+                    if (oy < H && oxx < W)
+                        rreg[p][ps] = ld_global16(resp + bimg * r_sb + oy * r_sy + oxx * r_sx + ch0 + e_q * 8);
                 }
             }
         }
-    });
+        __syncthreads();                                        // A: tile t is in LDS
+        f16x_t acc[NCO][2];
+#pragma unroll
+        for (int s = 0; s < NCO; ++s) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { acc[s][0][i] = 0.0f; acc[s][1][i] = 0.0f; }
+        }
+        const char* tb = tbuf + buf * P_TILE_BYTES;
+        // keep the 72 swizzled fragment offsets from being hoisted out of the tile loop as 72 live registers: derive
+        // them from a value the optimiser must treat as tile-variant (recomputing them costs ~150 VALU per tile)
+        int pxb = pxbase;
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+v"(pxb));
+#endif
+        if (VAR != 2 && VAR != 4) {
+            // software pipeline over 18 k-step pairs: the fragments of pair i+1 are in flight while the 4*NCO MFMAs
+            // of pair i run (one wave per SIMD: nothing else hides the LDS latency)
+            auto load_pair = [&](FragSet<NCO>& f, int pair) {
+                const int tap = pair >> 1, ks0 = (pair & 1) * 2;
+                const int px0 = pxb + (tap / 3) * P_LW + (tap % 3);
+                const int px1 = px0 + P_LW;
+                const int sw0 = (px0 >> 1) & 7, sw1 = (px1 >> 1) & 7;
+                const char* r0 = tb + px0 * 128;
+                const char* r1 = tb + px1 * 128;
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int ks = ks0 + k;
+#pragma unroll
+                    for (int s = 0; s < NCO; ++s) f.a[k][s] = *(const uint4*)(wl + ((tap * NKS + ks) * NCO + s) * 1024);
+                    f.b[k][0] = *(const uint4*)(r0 + (((ks * 2 + hi) ^ sw0) << 4));
+                    f.b[k][1] = *(const uint4*)(r1 + (((ks * 2 + hi) ^ sw1) << 4));
+                }
+            };
+            auto mma_pair = [&](const FragSet<NCO>& f) {
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+#pragma unroll
+                    for (int s = 0; s < NCO; ++s) {
+                        Mma<half_t>::run(acc[s][0], f.a[k][s], f.b[k][0]);
+                        Mma<half_t>::run(acc[s][1], f.a[k][s], f.b[k][1]);
+                    }
+                }
+            };
+            FragSet<NCO> f0, f1;
+            load_pair(f0, 0);
+            static_for<0, 9>([&](auto I) {
+                constexpr int i = decltype(I)::value;
+                load_pair(f1, 2 * i + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_pair(f0);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (i < 8) load_pair(f0, 2 * i + 2);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_pair(f1);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        }
+        __syncthreads();                                        // B: every MFMA wave is done reading tile t
+        if (VAR == 1) {
+#pragma unroll
+            for (int s = 0; s < NCO; ++s) {
+#if defined(__HIP_DEVICE_COMPILE__)
+                asm volatile("" ::"v"(acc[s][0]));
+                asm volatile("" ::"v"(acc[s][1]));
+#endif
+            }
+            continue;
+        }
+        // ---- epilogue: per output row, transpose through a wave-private LDS area (inside the consumed tile buffer)
+        // so that LPP consecutive lanes own one pixel's NCO*32 channels: full-line 16-byte stores / residual loads.
+        float* stg = (float*)(tbuf + buf * P_TILE_BYTES + wave * (32 * SLD * 4));
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+#pragma unroll
+            for (int s = 0; s < NCO; ++s) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f4_t v;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = acc[s][p][g * 4 + j];
+                    *(f4_t*)(stg + lx * SLD + s * 32 + g * 8 + 4 * hi) = v;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            const int oy = oy0 + wave * 2 + p;
+#pragma unroll
+            for (int ps = 0; ps < NPASS; ++ps) {
+                const int pxl = ps * PXP + e_px;
+                const int oxx = ox0 + pxl;
+                const f4_t v0 = *(const f4_t*)(stg + pxl * SLD + e_q * 8);
+                const f4_t v1 = *(const f4_t*)(stg + pxl * SLD + e_q * 8 + 4);
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { v[j] = v0[j] + bias8[j]; v[4 + j] = v1[j] + bias8[4 + j]; }
+                if (resp != nullptr) {
+                    const h8_t r = __builtin_bit_cast(h8_t, rreg[p][ps]);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] += (float)r[j];
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], act_floor);       // ReLU or identity, branch-free
+                if (oy < H && oxx < W) store8<half_t>(dstp + bimg * d_sb + oy * d_sy + oxx * d_sx + ch0 + e_q * 8, v);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+template <int NCO, int VAR = 0>
+int launch_persist(const demfi_conv* h, const demfi_conv* dev, hipStream_t st)
+{
+    const size_t lds = 9 * 4 * NCO * 1024 + 2 * P_TILE_BYTES;
+    static bool attr_done = false;
+    if (!attr_done) {
+        DEMFI_HIP_CHECK(hipFuncSetAttribute((const void*)conv3x3_c64_persist_kernel<NCO, VAR>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_done = true;
+    }
+    const int total = ((h->W + TW - 1) / TW) * ((h->H + TH - 1) / TH) * h->batch;
+    const int grid = total >= 256 ? 256 : total;
+    hipLaunchKernelGGL((conv3x3_c64_persist_kernel<NCO, VAR>), dim3(grid), dim3(P_NT), lds, st, dev);
+    DEMFI_HIP_CHECK(hipGetLastError());
+    return DEMFI_OK;
+}
+
+bool persist_eligible(const demfi_conv* h)
+{
+    if (h->dtype != DEMFI_F16 || h->stride != 1 || h->kh != 3 || h->kw != 3 || h->pad_y != 1 || h->pad_x != 1) return false;
+    if (h->n_chunks != 1 || h->n_pieces != 1 || h->chunks[0].nks != 4 || h->rec_bytes != 128) return false;
+    const demfi_piece& p = h->pieces[0];
+    if (!p.fat || p.nch != 64 || p.up_shift != 0 || !p.v.ptr || p.v.is_f32) return false;
+    if (h->nco > 2 || h->cout_pad != 32 * h->nco || !h->zero_page || h->inH != h->H || h->inW != h->W) return false;
+    // epilogue of the persistent kernel: ONE NHWC fp16 destination holding all NCO*32 channels (optional residual)
+    const int sg = h->sub_seg[0];
+    if (sg < 0) return false;
+    for (int sb = 0; sb < h->nco; ++sb)
+        if (h->sub_seg[sb] != sg || h->oct_ch[sb * 4] != h->oct_ch[0] + 32 * sb) return false;
+    const demfi_seg& seg = h->segs[sg];
+    if (seg.mode != DEMFI_MODE_STORE || seg.scale != 1 || seg.dy != 0 || seg.dx != 0) return false;
+    if (seg.act != DEMFI_ACT_NONE && seg.act != DEMFI_ACT_RELU) return false;
+    return true;
 }
 
 template <typename T, int NCO>
@@ -490,5 +835,19 @@ extern "C" int demfi_conv2d(const demfi_conv* h, const demfi_conv* dev, void* st
         if (!ok) return demfi_set_error(DEMFI_ERR_ARG, "demfi_conv2d: subtile %d is not eligible for the staged epilogue", sb);
     }
     hipStream_t st = (hipStream_t)stream;
+    if (persist_eligible(h)) {
+#ifdef DEMFI_ABLATION
+        static const int var = getenv("DEMFI_PERSIST_VARIANT") ? atoi(getenv("DEMFI_PERSIST_VARIANT")) : 0;
+        if (var == -1) goto general;
+        if (h->nco == 2 && var == 1) return launch_persist<2, 1>(h, dev, st);
+        if (h->nco == 2 && var == 2) return launch_persist<2, 2>(h, dev, st);
+        if (h->nco == 2 && var == 3) return launch_persist<2, 3>(h, dev, st);
+        if (h->nco == 2 && var == 4) return launch_persist<2, 4>(h, dev, st);
+#endif
+        return h->nco == 1 ? launch_persist<1>(h, dev, st) : launch_persist<2>(h, dev, st);
+    }
+#ifdef DEMFI_ABLATION
+general:
+#endif
     return h->dtype == DEMFI_F16 ? dispatch<half_t>(h, dev, st, (size_t)lds) : dispatch<float>(h, dev, st, (size_t)lds);
 }

@@ -164,7 +164,7 @@ __device__ __forceinline__ void gather4(const char* base, int64_t sx, int64_t sy
     for (int k = 0; k < 4; ++k) {
         if (m.inb & (1 << k)) {
             const char* p = base + (int64_t)(m.y0 + (k >> 1)) * sy + (int64_t)(m.x0 + (k & 1)) * sx;
-            const uint4 raw = *(const uint4*)p;
+            const uint4 raw = ld_global16(p);
             if constexpr (sizeof(T) == 2) {
                 const h8_t v = __builtin_bit_cast(h8_t, raw);
 #pragma unroll
@@ -185,12 +185,12 @@ __device__ __forceinline__ void store16(char* p, const float* v)
         h8_t o;
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] = (half_t)v[j];
-        *(uint4*)p = __builtin_bit_cast(uint4, o);
+        st_global16(p, __builtin_bit_cast(uint4, o));
     } else {
         f4_t o;
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[j] = v[j];
-        *(uint4*)p = __builtin_bit_cast(uint4, o);
+        st_global16(p, __builtin_bit_cast(uint4, o));
     }
 }
 
@@ -300,8 +300,8 @@ __global__ void gate_blend_kernel(const float* __restrict__ w, demfi_view S, dem
     const int part = (int)(i & ((1 << lpp_shift) - 1));
     const int y = (int)(pix / W), x = (int)(pix - (int64_t)y * W);
     const float g = w[pix];
-    const uint4 sr = *(const uint4*)((const char*)S.ptr + ((int64_t)y * S.sy + (int64_t)x * S.sx) * sizeof(T) + part * 16);
-    const uint4 er = *(const uint4*)((const char*)E.ptr + ((int64_t)y * E.sy + (int64_t)x * E.sx) * sizeof(T) + part * 16);
+    const uint4 sr = ld_global16((const char*)S.ptr + ((int64_t)y * S.sy + (int64_t)x * S.sx) * sizeof(T) + part * 16);
+    const uint4 er = ld_global16((const char*)E.ptr + ((int64_t)y * E.sy + (int64_t)x * E.sx) * sizeof(T) + part * 16);
     float r[N];
     if constexpr (sizeof(T) == 2) {
         const h8_t s = __builtin_bit_cast(h8_t, sr), e = __builtin_bit_cast(h8_t, er);

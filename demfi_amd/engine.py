@@ -280,9 +280,11 @@ class Plan:
         base = self.weight_blob.data_ptr()
         if getattr(self, '_rebased', False):
             raise RuntimeError('weights already rebased')
+        self.zero_page = torch.zeros(256, dtype=torch.uint8, device=self.device)
         for d in self._descs:
             d.wpack = base + (d.wpack or 0)
             d.bias = base + (d.bias or 0)
+            d.zero_page = self.zero_page.data_ptr()
         self._rebased = True
         n = len(self._descs)
         sz = C.sizeof(L.Conv)

@@ -116,6 +116,8 @@ typedef struct demfi_conv {
     int64_t w_blk_stride;       /* packed-weight stride between cout blocks, 16-byte units         */
     const void*  wpack;         /* packed weights, see demfi_pack_conv_weights                     */
     const float* bias;          /* [cout_pad] fp32 in packed cout order                            */
+    const void*  zero_page;     /* >= 16 bytes of zeros in device memory (source of padding pixels for the
+                                   LDS-DMA tile loads of the persistent 3x3 path); NULL disables that path */
     demfi_chunk chunks[DEMFI_MAX_CHUNKS];
     demfi_piece pieces[DEMFI_MAX_PIECES];
     demfi_seg   segs[DEMFI_MAX_SEGS];
