@@ -154,26 +154,31 @@ template <typename T> struct Vec16;
 template <> struct Vec16<half_t> { static constexpr int N = 8; };
 template <> struct Vec16<float> { static constexpr int N = 4; };
 
+// Bilinear gather of 16 bytes of channels.  All four corner loads are issued unconditionally (out-of-bounds corners
+// read a clamped in-bounds address and carry weight 0, which contributes exactly 0 for finite data), so the 4 (or 8
+// with two images) loads of a thread are in flight together instead of being serialised behind divergent branches.
 template <typename T>
-__device__ __forceinline__ void gather4(const char* base, int64_t sx, int64_t sy, const SampleMap& m, float* o)
+__device__ __forceinline__ void gather4(const char* base, int64_t sx, int64_t sy, const SampleMap& m, int H, int W, float* o)
 {
     constexpr int N = Vec16<T>::N;
+    uint4 raw[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int yy = min(max(m.y0 + (k >> 1), 0), H - 1), xx = min(max(m.x0 + (k & 1), 0), W - 1);
+        raw[k] = ld_global16(base + (int64_t)yy * sy + (int64_t)xx * sx);
+    }
 #pragma unroll
     for (int j = 0; j < N; ++j) o[j] = 0.0f;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        if (m.inb & (1 << k)) {
-            const char* p = base + (int64_t)(m.y0 + (k >> 1)) * sy + (int64_t)(m.x0 + (k & 1)) * sx;
-            const uint4 raw = ld_global16(p);
-            if constexpr (sizeof(T) == 2) {
-                const h8_t v = __builtin_bit_cast(h8_t, raw);
+        if constexpr (sizeof(T) == 2) {
+            const h8_t v = __builtin_bit_cast(h8_t, raw[k]);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] = o[j] + (float)v[j] * m.w[k];
-            } else {
-                const f4_t v = __builtin_bit_cast(f4_t, raw);
+            for (int j = 0; j < 8; ++j) o[j] = o[j] + (float)v[j] * m.w[k];
+        } else {
+            const f4_t v = __builtin_bit_cast(f4_t, raw[k]);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = o[j] + v[j] * m.w[k];
-            }
+            for (int j = 0; j < 4; ++j) o[j] = o[j] + v[j] * m.w[k];
         }
     }
 }
@@ -194,41 +199,116 @@ __device__ __forceinline__ void store16(char* p, const float* v)
     }
 }
 
-// Fat (NHWC) warp+blend: LPP = C*sizeof(T)/16 consecutive lanes share one pixel, each owns 16 bytes of channels.
+// Fat (NHWC) warp+blend.  The kernel was VALU-bound when every one of the LPP lanes of a pixel redid the coordinate
+// round trips (8 IEEE divisions + exp per warp pair): now each wave first computes the maps of 64 consecutive pixels
+// with ONE lane per pixel, parks them in a wave-private LDS record, and then walks the pixels LPP lanes at a time
+// (16 bytes of channels per lane): broadcast LDS reads, 8 unconditional 16-byte gathers, FMA accumulation.
+struct WarpRec {                    // 16 dwords per pixel
+    int xy0a, xy0b;                 // x0 | y0 << 16 (biased by 8) of the two warps
+    float wa[4], wb[4];             // corner weights, out-of-bounds and invalid-mask already folded to 0
+    float ka, kb, inv_den, den;     // (1-t)*o0, t*(1-o0), 1/den, den
+    int pad[2];
+};
+
 template <typename T>
-__global__ void warp_blend_fat_kernel(demfi_view A, const float* __restrict__ fa, demfi_view B,
+__global__ __launch_bounds__(NT) void warp_blend_fat_kernel(demfi_view A, const float* __restrict__ fa, demfi_view B,
                                       const float* __restrict__ fb, const float* __restrict__ logit,
                                       const float* __restrict__ tptr, demfi_view O, int lpp_shift, int H, int W,
                                       float* __restrict__ occ_out, int* __restrict__ dbg)
 {
     constexpr int N = Vec16<T>::N;
-    const int64_t hw = (int64_t)H * W;
-    const int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x;
-    const int64_t pix = i >> lpp_shift;
-    if (pix >= hw) return;
-    const int part = (int)(i & ((1 << lpp_shift) - 1));
-    const int y = (int)(pix / W), x = (int)(pix - (int64_t)y * W);
-    bool va, vb;
-    const SampleMap ma = bwarp_map(x, y, fa[pix], fa[hw + pix], H, W, va);
-    const SampleMap mb = bwarp_map(x, y, fb[pix], fb[hw + pix], H, W, vb);
-    const float t = *tptr;
-    const float o0 = sigmoidf_(logit[pix]);
-    const float o1 = 1.0f - o0;
-    if (part == 0) {
-        if (occ_out) occ_out[pix] = o0;
-        if (dbg) { dbg_store(dbg, 0, hw, pix, ma, va); dbg_store(dbg, 1, hw, pix, mb, vb); }
-    }
-    float wa[N], wb[N], r[N];
-    gather4<T>((const char*)A.ptr + part * 16, A.sx * sizeof(T), A.sy * sizeof(T), ma, wa);
-    gather4<T>((const char*)B.ptr + part * 16, B.sx * sizeof(T), B.sy * sizeof(T), mb, wb);
-    const float ka = (1.0f - t) * o0, kb = t * o1;
-    const float den = ka + kb;
+    __shared__ WarpRec recs[NT];                                  // 64 records per wave
+    const int hw = H * W;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int pix0 = (blockIdx.x * (NT / 64) + wave) * 64;        // first pixel of this wave
+    WarpRec* wr = recs + wave * 64;
+    // ---- phase 1: one lane per pixel -------------------------------------------------------------------
+    {
+        const int pix = pix0 + lane;
+        WarpRec r;
+        if (pix < hw) {
+            const int y = pix / W, x = pix - y * W;
+            bool va, vb;
+            const SampleMap ma = bwarp_map(x, y, fa[pix], fa[hw + pix], H, W, va);
+            const SampleMap mb = bwarp_map(x, y, fb[pix], fb[hw + pix], H, W, vb);
+            const float t = *tptr;
+            const float o0 = sigmoidf_(logit[pix]);
+            const float o1 = 1.0f - o0;
+            if (occ_out) occ_out[pix] = o0;
+            if (dbg) { dbg_store(dbg, 0, hw, pix, ma, va); dbg_store(dbg, 1, hw, pix, mb, vb); }
+            r.xy0a = (ma.x0 + 8) | ((ma.y0 + 8) << 16);
+            r.xy0b = (mb.x0 + 8) | ((mb.y0 + 8) << 16);
 #pragma unroll
-    for (int j = 0; j < N; ++j) {
-        const float a = va ? wa[j] : 0.0f, b = vb ? wb[j] : 0.0f;       // output * mask (766)
-        r[j] = (ka * a + kb * b) / den;                                  // Eq.(2)
+            for (int k = 0; k < 4; ++k) { r.wa[k] = va ? ma.w[k] : 0.0f; r.wb[k] = vb ? mb.w[k] : 0.0f; }   // output * mask (766)
+            r.ka = (1.0f - t) * o0;
+            r.kb = t * o1;
+            r.den = r.ka + r.kb;
+            r.inv_den = 1.0f / r.den;
+            r.pad[0] = r.pad[1] = 0;
+            wr[lane] = r;
+        }
     }
-    store16<T>((char*)O.ptr + ((int64_t)y * O.sy + (int64_t)x * O.sx) * sizeof(T) + part * 16, r);
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    // ---- phase 2: LPP lanes per pixel, software-pipelined: the 8 gathers of iteration it+1 are in flight while
+    // iteration it is blended and stored ----------------------------------------------------------------
+    const int lpp = 1 << lpp_shift;
+    const int ppi = 64 >> lpp_shift;                              // pixels per iteration
+    const int part = lane & (lpp - 1);
+    const int64_t asx = A.sx * sizeof(T), asy = A.sy * sizeof(T), bsx = B.sx * sizeof(T), bsy = B.sy * sizeof(T);
+    const char* ap = (const char*)A.ptr + part * 16;
+    const char* bp = (const char*)B.ptr + part * 16;
+    const int psub = lane >> lpp_shift;
+    auto issue = [&](int it, uint4 (&ra)[4], uint4 (&rb)[4], WarpRec& r) {
+        int pl = it * ppi + psub;
+        if (pix0 + pl >= hw) pl = 0;                              // clamp: results of out-of-range pixels are never stored
+        r = wr[pl];
+        const int ax0 = (r.xy0a & 0xffff) - 8, ay0 = (r.xy0a >> 16) - 8;
+        const int bx0 = (r.xy0b & 0xffff) - 8, by0 = (r.xy0b >> 16) - 8;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int ya = min(max(ay0 + (k >> 1), 0), H - 1), xa = min(max(ax0 + (k & 1), 0), W - 1);
+            const int yb = min(max(by0 + (k >> 1), 0), H - 1), xb = min(max(bx0 + (k & 1), 0), W - 1);
+            ra[k] = ld_global16(ap + ya * asy + xa * asx);
+            rb[k] = ld_global16(bp + yb * bsy + xb * bsx);
+        }
+    };
+    auto finish = [&](int it, const uint4 (&ra)[4], const uint4 (&rb)[4], const WarpRec& r) {
+        const int pix = pix0 + it * ppi + psub;
+        if (pix >= hw) return;
+        const int y = pix / W, x = pix - y * W;
+        float wa[N], wb[N], o[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) { wa[j] = 0.0f; wb[j] = 0.0f; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {                             // ATen order nw, ne, sw, se; zero weights add exactly 0
+            if constexpr (sizeof(T) == 2) {
+                const h8_t va = __builtin_bit_cast(h8_t, ra[k]), vb = __builtin_bit_cast(h8_t, rb[k]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { wa[j] = __builtin_fmaf((float)va[j], r.wa[k], wa[j]); wb[j] = __builtin_fmaf((float)vb[j], r.wb[k], wb[j]); }
+            } else {
+                const f4_t va = __builtin_bit_cast(f4_t, ra[k]), vb = __builtin_bit_cast(f4_t, rb[k]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { wa[j] = wa[j] + va[j] * r.wa[k]; wb[j] = wb[j] + vb[j] * r.wb[k]; }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            if constexpr (sizeof(T) == 2) o[j] = __builtin_fmaf(r.ka, wa[j], r.kb * wb[j]) * r.inv_den;      // Eq.(2), fp16 result
+            else o[j] = (r.ka * wa[j] + r.kb * wb[j]) / r.den;                                              // Eq.(2), exact fp32 steps
+        }
+        store16<T>((char*)O.ptr + ((int64_t)y * O.sy + (int64_t)x * O.sx) * sizeof(T) + part * 16, o);
+    };
+    uint4 ra0[4], rb0[4], ra1[4], rb1[4];
+    WarpRec r0, r1;
+    issue(0, ra0, rb0, r0);
+    for (int it = 0; it < lpp; it += 2) {                         // lpp is 8 (fp16) or 16 (fp32): always even
+        issue(it + 1, ra1, rb1, r1);
+        finish(it, ra0, rb0, r0);
+        if (it + 2 < lpp) issue(it + 2, ra0, rb0, r0);
+        finish(it + 1, ra1, rb1, r1);
+    }
 }
 
 // Thin (any strides) warp+blend, one thread per pixel, loops over C channels (C = 3 frames).
@@ -283,7 +363,7 @@ __global__ void fgac_gather_kernel(demfi_view S, const float* __restrict__ flow,
     const SampleMap m = make_sample_map(ix, iy, H, W);
     if (dbg && part == 0) dbg_store(dbg, 0, hw, pix, m, true);
     float r[N];
-    gather4<T>((const char*)S.ptr + part * 16, S.sx * sizeof(T), S.sy * sizeof(T), m, r);
+    gather4<T>((const char*)S.ptr + part * 16, S.sx * sizeof(T), S.sy * sizeof(T), m, H, W, r);
     store16<T>((char*)O.ptr + ((int64_t)y * O.sy + (int64_t)x * O.sx) * sizeof(T) + part * 16, r);
 }
 
@@ -392,12 +472,12 @@ extern "C" int demfi_warp_blend(const demfi_view* A, const float* fa, const demf
         int f32 = 0;
         const int sh = fat_lpp_shift(A, C, "demfi_warp_blend", &f32);
         if (sh < 0) return sh;
-        const int64_t n = hw << sh;
+        const unsigned nblk = (unsigned)((hw + NT - 1) / NT);           // one wave per 64 pixels, 4 waves per workgroup
         if (f32)
-            hipLaunchKernelGGL(warp_blend_fat_kernel<float>, dim3(blocks_for(n)), dim3(NT), 0, st, *A, fa, *B, fb, logit, t,
+            hipLaunchKernelGGL(warp_blend_fat_kernel<float>, dim3(nblk), dim3(NT), 0, st, *A, fa, *B, fb, logit, t,
                                *out, sh, H, W, occ_out, dbg_maps);
         else
-            hipLaunchKernelGGL(warp_blend_fat_kernel<half_t>, dim3(blocks_for(n)), dim3(NT), 0, st, *A, fa, *B, fb, logit,
+            hipLaunchKernelGGL(warp_blend_fat_kernel<half_t>, dim3(nblk), dim3(NT), 0, st, *A, fa, *B, fb, logit,
                                t, *out, sh, H, W, occ_out, dbg_maps);
     } else {
         hipLaunchKernelGGL(warp_blend_thin_kernel, dim3(blocks_for(hw)), dim3(NT), 0, st, *A, fa, *B, fb, logit, t, *out, C,

@@ -70,7 +70,11 @@ def main():
         A = torch.randn(H, W, 64, device=DEV).to(dtype)
         B = torch.randn(H, W, 64, device=DEV).to(dtype)
         O = torch.zeros(H, W, 64, device=DEV, dtype=dtype)
-        fl = (torch.randn(4, H, W, device=DEV) * 8).contiguous()
+        if os.environ.get('PROBE_SMOOTH'):          # coherent motion (what a trained network produces)
+            yy, xx = torch.meshgrid(torch.arange(H, device=DEV).float(), torch.arange(W, device=DEV).float(), indexing='ij')
+            fl = torch.stack([3.3 + 2 * torch.sin(yy / 37), -2.7 + 2 * torch.cos(xx / 53), -4.1 + torch.sin(xx / 41), 1.9 + torch.cos(yy / 29)]).contiguous()
+        else:                                        # white-noise flows: every pixel gathers from unrelated lines
+            fl = (torch.randn(4, H, W, device=DEV) * 8).contiguous()
         lg = torch.randn(H, W, device=DEV)
         t = torch.tensor([0.375], device=DEV)
         mk = lambda z: L.View(z.data_ptr(), 64, W * 64, 1, 0, 1 if dtype == torch.float32 else 0, 0)
