@@ -44,6 +44,19 @@ __device__ __forceinline__ void view_store(const demfi_view& v, int64_t off, flo
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// Epilogue activations on the hardware transcendentals (v_exp_f32 / v_rcp_f32, ~1 ulp each): 5-6 instructions instead
+// of the ~30 of expf + IEEE division.  |error| <= ~2e-7 absolute, far inside the fp32 parity tolerance; the GRU gate
+// convolutions spent 60 % of their VALU time in libm sigmoid/tanh.
+__device__ __forceinline__ float fast_sigmoid(float x)
+{
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+__device__ __forceinline__ float fast_tanh(float x)
+{
+    // tanh(x) = 1 - 2 / (1 + e^(2x)); e^(2x) -> inf gives 1, -> 0 gives -1
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
+}
+
 // fp32 round trip of the reference's coordinate handling:
 //   g = 2*p/den - 1        (bwarp: den = max(size-1,1), DeMFInet.py:753-754; FGAC: den = size-1, 503-504)
 //   i = ((g + 1) / 2) * (size - 1)        (ATen grid_sampler_unnormalize, align_corners=True)

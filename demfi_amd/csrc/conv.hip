@@ -107,22 +107,14 @@ __device__ __forceinline__ void apply_act_n(float (&v)[N], int act)
         break;
     case DEMFI_ACT_TANH:
 #pragma unroll
-        for (int j = 0; j < N; ++j) v[j] = tanhf(v[j]);
+        for (int j = 0; j < N; ++j) v[j] = fast_tanh(v[j]);
         break;
     case DEMFI_ACT_SIGMOID:
 #pragma unroll
-        for (int j = 0; j < N; ++j) v[j] = 1.0f / (1.0f + expf(-v[j]));
+        for (int j = 0; j < N; ++j) v[j] = fast_sigmoid(v[j]);
         break;
     default: break;
     }
-}
-
-__device__ __forceinline__ float apply_act(float v, int act)
-{
-    if (act == DEMFI_ACT_RELU) return fmaxf(v, 0.0f);
-    if (act == DEMFI_ACT_TANH) return tanhf(v);
-    if (act == DEMFI_ACT_SIGMOID) return sigmoidf_(v);
-    return v;
 }
 
 // ---- epilogue shared by the general and the persistent kernel -------------------------------------------
@@ -192,12 +184,12 @@ __device__ __forceinline__ void conv_epilogue(const demfi_conv* __restrict__ d, 
                     apply_act_n<8>(v, act);
                 } else if (mode == DEMFI_MODE_MUL) {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] = sigmoidf_(v[j]) * r[j];
+                    for (int j = 0; j < 8; ++j) v[j] = fast_sigmoid(v[j]) * r[j];
                 } else {
                     float z[8];
                     load8<T>(auxp + (int64_t)bimg * sg.aux.sb + (int64_t)oy * sg.aux.sy + (int64_t)oxx * sg.aux.sx + cq, z);
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] = (1.0f - z[j]) * r[j] + z[j] * tanhf(v[j]);
+                    for (int j = 0; j < 8; ++j) v[j] = (1.0f - z[j]) * r[j] + z[j] * fast_tanh(v[j]);
                 }
             } else {
                 apply_act_n<8>(v, act);
@@ -252,14 +244,14 @@ __device__ __forceinline__ void conv_epilogue(const demfi_conv* __restrict__ d, 
                         apply_act_n<4>(v, act);
                     } else if (mode == DEMFI_MODE_MUL) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] = sigmoidf_(v[j]) * r[j];
+                        for (int j = 0; j < 4; ++j) v[j] = fast_sigmoid(v[j]) * r[j];
                     } else {   // GRU: (1-z)*h + z*tanh(v)
                         const int64_t ao = (int64_t)bimg * sg.aux.sb + (int64_t)oy * sg.aux.sy
                                            + (int64_t)ox * sg.aux.sx + (int64_t)cq * sg.aux.sc;
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             const float z = j < nq ? view_load(sg.aux, ao + j * sg.aux.sc) : 0.0f;
-                            v[j] = (1.0f - z) * r[j] + z * tanhf(v[j]);
+                            v[j] = (1.0f - z) * r[j] + z * fast_tanh(v[j]);
                         }
                     }
                 } else {
