@@ -395,6 +395,27 @@ __global__ void gate_blend_kernel(const float* __restrict__ w, demfi_view S, dem
     store16<T>((char*)O.ptr + ((int64_t)y * O.sy + (int64_t)x * O.sx) * sizeof(T) + part * 16, r);
 }
 
+// Gather up to 32 planar fp32 channels (flows, logits, frames) into an NHWC slice of the path dtype, so that the
+// consuming convolution stages them with 16-byte vector loads instead of element-wise "thin" loads.
+struct PackArgs { const float* plane[32]; };
+
+template <typename T>
+__global__ void pack_planes_kernel(PackArgs a, int nch8, T* __restrict__ dst, int64_t dst_sx, int hw)
+{
+    constexpr int G = 16 / sizeof(T);                  // channels per 16-byte store
+    const int i = blockIdx.x * NT + threadIdx.x;
+    const int ngrp = nch8 * 8 / G;
+    if (i >= hw * ngrp) return;
+    const int g = i / hw, pix = i - g * hw;            // pixel fastest: plane reads coalesce
+    float v[G];
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+        const float* p = a.plane[g * G + j];
+        v[j] = p ? p[pix] : 0.0f;
+    }
+    store16<T>((char*)(dst + (int64_t)pix * dst_sx + g * G), v);
+}
+
 // A fat view usable by the 16-byte-per-lane kernels: NHWC (sc == 1), C*elt a power-of-two multiple of 16 B.
 int fat_lpp_shift(const demfi_view* v, int C, const char* who, int* is_f32)
 {
@@ -521,6 +542,27 @@ extern "C" int demfi_gate_blend(const float* w, const demfi_view* source, const 
         hipLaunchKernelGGL(gate_blend_kernel<float>, dim3(blocks_for(n)), dim3(NT), 0, st, w, *source, *e, *out, sh, H, W);
     else
         hipLaunchKernelGGL(gate_blend_kernel<half_t>, dim3(blocks_for(n)), dim3(NT), 0, st, w, *source, *e, *out, sh, H, W);
+    DEMFI_HIP_CHECK(hipGetLastError());
+    return DEMFI_OK;
+}
+
+extern "C" int demfi_pack_planes(const float* const* planes, int nch, void* dst, int dtype, int64_t dst_pix_stride,
+                                 int H, int W, void* stream)
+{
+    if (!planes || !dst || nch <= 0 || nch > 32 || nch % 8 || H <= 0 || W <= 0)
+        return demfi_set_error(DEMFI_ERR_ARG, "demfi_pack_planes: nch=%d must be a multiple of 8, <= 32", nch);
+    PackArgs a;
+    for (int i = 0; i < 32; ++i) a.plane[i] = i < nch ? planes[i] : nullptr;
+    const int hw = H * W;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == DEMFI_F16)
+        hipLaunchKernelGGL(pack_planes_kernel<half_t>, dim3(blocks_for((int64_t)hw * nch / 8)), dim3(NT), 0, st, a, nch / 8,
+                           (half_t*)dst, dst_pix_stride, hw);
+    else if (dtype == DEMFI_F32)
+        hipLaunchKernelGGL(pack_planes_kernel<float>, dim3(blocks_for((int64_t)hw * nch / 4)), dim3(NT), 0, st, a, nch / 8,
+                           (float*)dst, dst_pix_stride, hw);
+    else
+        return demfi_set_error(DEMFI_ERR_ARG, "demfi_pack_planes: dtype");
     DEMFI_HIP_CHECK(hipGetLastError());
     return DEMFI_OK;
 }

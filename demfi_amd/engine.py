@@ -67,6 +67,7 @@ class Plan:
         self._wblobs = []         # (offset, numpy bytes)
         self._wbytes = 0
         self._keep = []           # tensors referenced only by raw pointers
+        self._keep_c = []         # ctypes arrays referenced by launch ops
         self.macs = {}            # name -> MACs per launch (algorithmic, unpadded)
 
     def _fat(self, h, w, c, batch=1):
@@ -86,6 +87,22 @@ class Plan:
         nch = Ct - c0 if nch is None else nch
         ptr = buf.data_ptr() + (c0 + (0 if b is None else b * h * w * Ct)) * self.esz
         return _Src(True, ptr, Ct, w * Ct, 1, h * w * Ct if b is None else 0, self.f32, range(cin0, cin0 + nch), up)
+
+    def fsrc_map(self, buf, cin, b=0):
+        """Input piece = ALL channels of a fat buffer with an explicit channel -> original-cin list (-1 = unused
+        padding channel, gets zero weights)."""
+        B, h, w, Ct = buf.shape
+        assert len(cin) == Ct
+        ptr = buf.data_ptr() + b * h * w * Ct * self.esz
+        return _Src(True, ptr, Ct, w * Ct, 1, 0, self.f32, cin, 0)
+
+    def pack_op(self, planes, dst):
+        """('pack', ...) launch op: planes = list of [H,W] fp32 plane tensors (None = zero) -> fat buffer dst."""
+        Ct = dst.shape[-1]
+        planes = list(planes) + [None] * (Ct - len(planes))
+        arr = (C.c_void_p * Ct)(*[None if p is None else p.data_ptr() for p in planes])
+        self._keep_c.append(arr)
+        return ('pack', arr, dst, Ct)
 
     def tsrc(self, buf, cin, c0=0, nch=None):
         """Input piece from a planar fp32 buffer [C,h,w]; cin = list of original input channels."""
@@ -131,7 +148,7 @@ class Plan:
             rec //= 2
         # ---- pack the input pieces into chunks of <= rec bytes (fat pieces first: 16-byte aligned) -------
         order = [s for s in srcs if s.fat] + [s for s in srcs if not s.fat]
-        covered = sorted(c for s in srcs for c in s.cin)
+        covered = sorted(c for s in srcs for c in s.cin if c >= 0)
         assert covered == list(range(cin)), '%s: inputs cover %d channels, weight has %d' % (name, len(covered), cin)
         d = L.Conv()
         chunks, pieces, cin_map = [], [], []
@@ -375,6 +392,12 @@ class Engine(Plan):
         self.h1 = self._fat(H, W, 64)
         self.fo1 = self._fat(H, W, 32)
         self.stnew = self._thin(3)
+        # planar flows / logits / frames packed to NHWC once, so the consuming convs stage them with vector loads
+        self.misc16 = self._fat(H, W, 16)
+        self.ref32 = self._fat(H, W, 32)
+        self.agg3s = self._fat(H, W, 32)
+        self.agg3d = self._fat(H, W, 8)
+        self.delta8 = self._fat(H, W, 8)
         self.g_a = self._fat(H, W, 64)
         self.g_t = self._fat(H, W, 64)
         self.g_b = self._fat(H, W, 64)
@@ -459,8 +482,9 @@ class Engine(Plan):
         th.append(('warp_fat', self.F01, 0, 1, self.ft, self.ffo, 4, self.Ft, None, None))
         p = 'Refine_Module.'
         # Agg1 = cat[aF0, aF1, Ft, flow_t0, flow_t1, flow_01, flow_10, occ_0_logit] (DeMFInet.py:77)
+        th.append(self.pack_op([self.ft[i] for i in range(4)] + [self.ffo[i] for i in range(5)], self.misc16))
         self.conv(th, p + 'enc1', [self.fsrc(self.aF, 0, b=0), self.fsrc(self.aF, 64, b=1), self.fsrc(self.Ft, 128),
-                                   self.tsrc(self.ft, range(192, 196)), self.tsrc(self.ffo, range(196, 201))],
+                                   self.fsrc_map(self.misc16, list(range(192, 201)) + [-1] * 7)],
                   [D(self.fview(self.u1), range(64), R)], H2, W2, stride=2)
         self.conv(th, p + 'enc2', [self.fsrc(self.u1, 0)], [D(self.fview(self.u2), range(128), R)], H4, W4, stride=2)
         self.conv(th, p + 'enc3', [self.fsrc(self.u2, 0)], [D(self.fview(self.u3), range(256), R)], H8, W8, stride=2)
@@ -487,10 +511,15 @@ class Engine(Plan):
                   [D(self.fview(self.frec[0]), range(64), T)], H, W)
         # Mixer reference branch (iteration-invariant, hoisted): cat[S0p,S1p,Stp,B0,B1,B-1,B2 | flow_10,flow_01 | t_ref]
         p = 'Booster_Module.'
-        self.conv(th, p + 'Mixer.conv_ref1',
-                  [self.tsrc(self.sharp1, range(0, 9))] + self._x_frames(9) +
-                  [self.tsrc(self.ffo, [21, 22], 2, 2), self.tsrc(self.ffo, [23, 24], 0, 2), self.tsrc(d0, range(25, 30))],
+        xpl = [self.x[c, f] for f in range(4) for c in range(3)]          # B0, B1, B-1, B2 colour planes (cat order)
+        th.append(self.pack_op([self.sharp1[i] for i in range(9)] + xpl +
+                               [self.ffo[2], self.ffo[3], self.ffo[0], self.ffo[1]] + [d0[i] for i in range(5)], self.ref32))
+        self.conv(th, p + 'Mixer.conv_ref1', [self.fsrc_map(self.ref32, list(range(30)) + [-1, -1])],
                   [D(self.fview(self.re1), range(32), R)], H, W)
+        # iteration-invariant part of Agg3 (DeMFInet.py:151-155): S0p,S1p | occ_0 | rflow_t0,t1 | flow_10,flow_01 | frames
+        th.append(self.pack_op([self.sharp1[i] for i in range(6)] + [self.occ[0]] + [d0[i] for i in range(4)] +
+                               [self.ffo[2], self.ffo[3], self.ffo[0], self.ffo[1]] + xpl, self.agg3s))
+        agg3s_cin = list(range(0, 6)) + [73] + list(range(74, 78)) + [78, 79, 80, 81] + list(range(87, 99)) + [-1] * 5
         self.conv(th, p + 'Mixer.conv_ref2', [self.fsrc(self.re1, 0)], [D(self.fview(self.ref_enc), range(32), R)], H, W)
         # ============================ recursive boosting, one list per iteration ============================
         zr = {}
@@ -502,7 +531,9 @@ class Engine(Plan):
             self.seg_iter.append(sg)
             dc, dn = self.delta[it], self.delta[it + 1]
             hin, hout = self.frec[it % 2], self.frec[(it + 1) % 2]
-            self.conv(sg, p + 'Mixer.conv_delta1', [self.tsrc(dc, range(5))], [D(self.fview(self.de1), range(32), R)], H, W)
+            sg.append(self.pack_op([dc[i] for i in range(5)], self.delta8))
+            self.conv(sg, p + 'Mixer.conv_delta1', [self.fsrc_map(self.delta8, list(range(5)) + [-1] * 3)],
+                      [D(self.fview(self.de1), range(32), R)], H, W)
             self.conv(sg, p + 'Mixer.conv_delta2', [self.fsrc(self.de1, 0)], [D(self.fview(self.de2), range(32), R)], H, W)
             self.conv(sg, p + 'Mixer.conv_blend1', [self.fsrc(self.ref_enc, 0), self.fsrc(self.de2, 32)],
                       [D(self.fview(self.bl1), range(32), R)], H, W)
@@ -523,11 +554,11 @@ class Engine(Plan):
                       H, W)
             sg.append(('warp_thin', it))
             # Agg3 (DeMFInet.py:151-155)
+            sg.append(self.pack_op([self.stnew[i] for i in range(3)] + [dn[i] for i in range(4)] + [self.occ[it + 1]],
+                                   self.agg3d))
             self.conv(sg, 'Dec_first_2',
-                      [self.fsrc(hout, 9), self.tsrc(self.sharp1, range(0, 6), 0, 6), self.tsrc(self.stnew, range(6, 9)),
-                       self.tsrc(self.occ, [73], 0, 1), self.tsrc(d0, range(74, 78), 0, 4),
-                       self.tsrc(self.ffo, [78, 79], 2, 2), self.tsrc(self.ffo, [80, 81], 0, 2),
-                       self.tsrc(dn, range(82, 86), 0, 4), self.tsrc(self.occ, [86], it + 1, 1)] + self._x_frames(87),
+                      [self.fsrc(hout, 9), self.fsrc_map(self.agg3s, agg3s_cin),
+                       self.fsrc_map(self.agg3d, [6, 7, 8, 82, 83, 84, 85, 86])],
                       [D(self.fview(self.g_a), range(64), R)], H, W)
             cur = self._resblocks(sg, 'Decoder_res_2', self.hp.num_ResB_Dec, self.g_a, self.g_t, self.g_b, H, W, 1)
             self.conv(sg, 'Dec_last1_2', [self.fsrc(cur, 0)], [D(self.fview(self.g_t), range(64), R)], H, W)
@@ -548,6 +579,9 @@ class Engine(Plan):
             if k == 'conv':
                 i = op[1]
                 self.launch_conv(i, stream, op[2])
+            elif k == 'pack':
+                _, arr, dst, nch = op
+                L.check(lib.demfi_pack_planes(arr, nch, dst.data_ptr(), self.dt, nch, H, W, stream), k)
             elif k == 's2d':
                 L.check(lib.demfi_space_to_depth(self.x.data_ptr(), self.s2d.data_ptr(), self.dt, H, W, stream), k)
             elif k == 'overlay':

@@ -205,6 +205,13 @@ int demfi_fgac_gather(const demfi_view* src, const float* flow, const demfi_view
 int demfi_gate_blend(const float* w, const demfi_view* source, const demfi_view* e, const demfi_view* out,
                      int C, int H, int W, void* stream);
 
+/* Pack planar fp32 channels into an NHWC slice of the path dtype (replaces the thin members of torch.cat at
+ * DeMFInet.py:77, 117-120, 123, 151-155 for the consuming convolutions).  planes: HOST array of nch device
+ * pointers to [H,W] fp32 planes (NULL = zero channel); nch multiple of 8, <= 32; dst: first channel of the slice,
+ * dst_pix_stride in elements. */
+int demfi_pack_planes(const float* const* planes, int nch, void* dst, int dtype, int64_t dst_pix_stride,
+                      int H, int W, void* stream);
+
 /* ---- hipGraph capture of a launch sequence ------------------------------------------------------ */
 int demfi_graph_begin(void* stream);
 int demfi_graph_end(void* stream, void** graph_exec_out);

@@ -140,6 +140,14 @@ class PlanSim:
             k = op[0]
             if k == 'conv':
                 self.conv(e._descs[op[1]])
+            elif k == 'pack':
+                _, arr, dst, nch = op
+                for c in range(nch):
+                    if arr[c] is None:
+                        dst[0, :, :, c] = 0
+                    else:
+                        v = L.View(arr[c], 1, W, H * W, 0, 1, 0)
+                        dst[0, :, :, c] = self.strided(v, 1, H, W)[0].to(dst.dtype)
             elif k == 's2d':
                 x = e.x                                                   # [3,4,H,W] -> frames-major 12 planes
                 cat = x.permute(1, 0, 2, 3).reshape(1, 12, H, W)
