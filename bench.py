@@ -44,12 +44,12 @@ def parse():
 
 def cpu_baseline(n_tst, full_px):
     """Oracle (CPU restatement, reference semantics: one FULL forward per t, no trunk caching) on a bounded sample:
-    a 184x320 frame = 1/16 of the padded 736x1280 pixels, one t; scaled to 720p-equivalent frames/s."""
+    the full padded 736x1280 frame (about 25 s on 32 threads), one t; scaled to 720p-equivalent frames/s."""
     from demfi_amd import synthetic_state_dict, synthetic_window
     from oracle import demfi_oracle as O
     torch.set_num_threads(min(os.cpu_count() or 1, 32))       # beyond ~32 threads MKLDNN convs of this size slow down
     sd = synthetic_state_dict(0)
-    h, w = 184, 320
+    h, w = 736, 1280                                          # the whole padded frame of the workload, ONE of the 7 t
     x = synthetic_window(h, w, 1)
     t = torch.tensor([[0.5]])
     with torch.no_grad():
@@ -125,7 +125,10 @@ def main():
         ach = g_fl / (g_ms * 1e-3) / 1e12
         out['roofline'] = {'kernel': '%s 3x3 64->64 batch 3 (D1 residual blocks, %d launches/frame)' %
                                      ('conv3x3_c64_persist_kernel<2>' if a.dtype == 'fp16' else 'conv_kernel<float,2>', len(grp)), 'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak,
-                           'unit': 'TFLOP/s', 'frac': round(ach / peak, 4), 'traffic': None,
+                           'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
+                           # HBM bytes per launch from rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE, gfx950 correction),
+                           # profiles/r01b_pmc_dominant_conv_and_warp.txt; algorithmic = 723.5 MB (in + out once)
+                           'traffic': 737.6e6 if a.dtype == 'fp16' and (eng.H, eng.W) == (736, 1280) else None,
                            'avg_launch_ms': round(g_ms, 4), 'flop_per_launch': g_fl,
                            'all_convs_TFLOPs': round(tot_conv_fl / (tot_conv_ms * 1e-3) / 1e12, 2),
                            'slowest_conv': '%s %.3f ms' % (dom[2], dom[3])}
