@@ -100,7 +100,7 @@ __global__ void cfr_splat_kernel(const float* __restrict__ flow01, const float* 
 }
 
 // Linear combination + normalisation of CFR (DeMFInet.py:614-620), every op one fp32 rounding.
-__global__ void cfr_finish_kernel(const long long* __restrict__ acc, const float* __restrict__ tptr, int64_t hw,
+__global__ void cfr_finish_kernel(long long* __restrict__ acc, const float* __restrict__ tptr, int64_t hw,
                                   float* __restrict__ out)
 {
     const int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x;
@@ -115,6 +115,10 @@ __global__ void cfr_finish_kernel(const long long* __restrict__ acc, const float
     f10[0] = (float)((double)acc[3 * hw + i] * inv);
     f10[1] = (float)((double)acc[4 * hw + i] * inv);
     const float n1 = (float)((double)acc[5 * hw + i] * inv);
+    // leave the accumulators zeroed for the next call (no memset node: under hipGraph replay a hipMemsetAsync
+    // captured between kernels was observed not to be ordered before the splat)
+#pragma unroll
+    for (int k = 0; k < 6; ++k) acc[k * hw + i] = 0;
     const float norm = omt * n0 + t * n1;                                   // 617
     const float m = norm > 0.0f ? 1.0f : 0.0f;                              // 618
     const float ca = (-omt) * t, cb = t * t, cc = omt * omt, cd = t * omt;
@@ -471,10 +475,9 @@ extern "C" int demfi_cfr_flow_align(const float* flow01, const float* flow10, co
         return demfi_set_error(DEMFI_ERR_ARG, "demfi_cfr_flow_align: bad args");
     hipStream_t st = (hipStream_t)stream;
     const int64_t hw = (int64_t)H * W;
-    DEMFI_HIP_CHECK(hipMemsetAsync(acc, 0, sizeof(int64_t) * 6 * hw, st));
     hipLaunchKernelGGL(cfr_splat_kernel, dim3(blocks_for(2 * hw)), dim3(NT), 0, st, flow01, flow10, t, H, W,
                        (long long*)acc, dbg_idx);
-    hipLaunchKernelGGL(cfr_finish_kernel, dim3(blocks_for(hw)), dim3(NT), 0, st, (const long long*)acc, t, hw, out);
+    hipLaunchKernelGGL(cfr_finish_kernel, dim3(blocks_for(hw)), dim3(NT), 0, st, (long long*)acc, t, hw, out);
     DEMFI_HIP_CHECK(hipGetLastError());
     return DEMFI_OK;
 }

@@ -177,7 +177,8 @@ int demfi_overlay_mean(const float* x, float* out, int H, int W, void* stream);
 
 /* CFR_flow_t_align (DeMFInet.py:606-622) = two forward splats (fwarp 625-671, sample_one 683-729) +
  * the linear combination / normalisation.  flow01, flow10: planar fp32 [2,H,W]; t: device pointer to
- * one fp32; acc: caller workspace of 6*H*W int64 (zeroed by this call); out: planar fp32 [4,H,W] =
+ * one fp32; acc: caller workspace of 6*H*W int64 that MUST be all-zero on entry (allocate it zeroed once) and is
+ * left all-zero on exit; out: planar fp32 [4,H,W] =
  * (flow_t0, flow_t1).  The splat accumulates in 64-bit fixed point (2^-32 resolution) so the result
  * does not depend on the order of the atomic adds.  dbg_idx (optional, may be NULL): int32
  * [2 flows][4 corners][H*W] flat target index of every source pixel, -1 where masked off

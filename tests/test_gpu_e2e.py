@@ -132,3 +132,39 @@ def test_fp16_psnr_against_fp32_reference(golden_dir, model16):
         print('fp16 vs fp32-reference PSNR (S0,S1,St) %s: %.2f %.2f %.2f dB' % (name, *ps))
         assert all(torch.isfinite(z).all() for z in fin[N - 1])
         assert min(ps) > 30.0
+
+
+def test_window_runner_graph_replay_matches_module(model16):
+    """The x M window scheduler (reflect pad into the engine, trunk once, hipGraph replay per t) returns exactly what
+    M-1 separate pad -> forward -> crop calls of the module return."""
+    from demfi_amd.harness import t_schedule
+    from demfi_amd.runner import WindowRunner
+    h, w, N, M = 50, 70, 2, 4
+    x = synthetic_window(h, w, 11).to(DEV)
+    runner = WindowRunner(model16, h, w, n_tst=N, mfi=M, use_graph=True)
+    for _ in range(2):                                     # second call replays the captured graphs
+        st, s01 = runner.run_window(x)
+        torch.cuda.synchronize()
+        for k, tv in enumerate(t_schedule(M)):
+            ref = pad_forward_crop(model16, x, torch.tensor([[float(tv)]], device=DEV), N)
+            assert torch.equal(st[k], ref[1][N - 1][2][0]), k
+            if k == 0:
+                assert torch.equal(s01[0], ref[1][N - 1][0][0]) and torch.equal(s01[1], ref[1][N - 1][1][0])
+
+
+def test_full_size_720p_fp16_properties(model16):
+    """BASELINE config 2 shape (720p -> 736x1280, N_tst=3): size-independent properties -- finite outputs, run-to-run
+    bit-identical results (deterministic splat + fixed MFMA accumulation order, also across the persistent kernel's
+    dynamic tile walk), occlusion maps in [0,1], and D2 frames = D1 frames + residual (same S0p/S1p across t)."""
+    x = synthetic_window(720, 1280, 21).to(DEV)
+    a = pad_forward_crop(model16, x, torch.tensor([[0.375]], device=DEV), 3)
+    b = pad_forward_crop(model16, x, torch.tensor([[0.375]], device=DEV), 3)
+    c = pad_forward_crop(model16, x, torch.tensor([[0.625]], device=DEV), 3)
+    for i in range(3):
+        assert tuple(a[1][2][i].shape) == (1, 3, 720, 1280)
+        assert torch.isfinite(a[1][2][i]).all()
+        assert torch.equal(a[1][2][i], b[1][2][i])
+    for o in a[3]:
+        assert float(o.min()) >= 0.0 and float(o.max()) <= 1.0
+    assert torch.equal(a[4], c[4])                                  # overlay does not depend on t
+    assert not torch.equal(a[1][2][2], c[1][2][2])                  # St does
