@@ -436,6 +436,8 @@ __global__ __launch_bounds__(NT, (NCO <= 1 ? 4 : (NCO == 2 ? 3 : 2))) void conv_
 //     traffic and no per-tap barriers;
 //   * the haloed input tile is fetched by LDS-DMA (global_load_lds, no VGPR round trip, zero padding through a
 //     zero page) into a double buffer: tile k+1 streams in while tile k is on the matrix cores;
+//   * the epilogue needs no LDS: a v_permlane32_swap per accumulator-quad pair gives every lane 8 consecutive
+//     output channels of its pixel (16-byte stores / residual loads), so there is ONE barrier per tile;
 //   * pixel records are unpadded (128 B); bank conflicts are removed by an XOR swizzle of the 16-byte slot,
 //     applied on the DMA's per-lane SOURCE address and on the ds_read address (the LDS image stays lane-linear).
 // ======================================================================================================
@@ -543,7 +545,6 @@ __global__ __launch_bounds__(P_NT, 1) void conv3x3_c64_persist_kernel(const demf
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tile t (and the weights) have landed in LDS
             __syncthreads();                                    // A: hand tile t to the MFMA waves
             if (VAR != 3 && VAR != 4 && t + t_step < t_end) issue_tile(t + t_step, buf ^ 1);   // streams in under the MFMAs
-            __syncthreads();                                    // B: (MFMA waves finished reading tile t)
         }
         return;
     }
@@ -560,18 +561,11 @@ __global__ __launch_bounds__(P_NT, 1) void conv3x3_c64_persist_kernel(const demf
     const int64_t r_sx = sg0.res.sx, r_sy = sg0.res.sy, r_sb = sg0.res.sb;
     const float act_floor = sg0.act == DEMFI_ACT_RELU ? 0.0f : -__builtin_huge_valf();
     const int ch0 = d->oct_ch[0];
-    constexpr int LPP = NCO * 4;                                // lanes per pixel in the store phase (16 B each)
-    constexpr int PXP = 64 / LPP;                               // pixels per store pass
-    constexpr int NPASS = 32 / PXP;                             // passes per 32-pixel row
-    constexpr int SLD = NCO * 32 + 4;                           // staged row: NCO*32 couts + 4 pad floats
-    const int e_px = lane / LPP, e_q = lane % LPP;              // store phase: pixel within pass, 8-channel group
-    float bias8[8];                                             // bias of the 8 channels this lane stores
-    {
-        const f4_t b0 = *gcp<f4_t>(d->bias + e_q * 8), b1 = *gcp<f4_t>(d->bias + e_q * 8 + 4);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { bias8[j] = b0[j]; bias8[4 + j] = b1[j]; }
-    }
-
+    // Epilogue layout: after a v_permlane32_swap of each accumulator-quad pair, lane (lx, hi) holds 8 consecutive output
+    // channels of pixel lx (couts s*32 + 16m + 8hi ..): 16-byte stores / residual loads straight from registers, no LDS
+    // transpose.  The bias (NCO*32 floats) sits in the 2 KiB of LDS behind the tile buffers.
+    float* const bias_lds = (float*)(tbuf + 2 * P_TILE_BYTES);
+    if (tid < NCO * 32) bias_lds[tid] = d->bias[tid];
     int boff[12];                                               // [kx*4 + ks]: (column lx+kx) record + swizzled 16-byte slot
 #pragma unroll
     for (int g = 0; g < 12; ++g) {
@@ -584,16 +578,19 @@ __global__ __launch_bounds__(P_NT, 1) void conv3x3_c64_persist_kernel(const demf
         int bimg, oy0, ox0;
         tile_coords(t, bimg, oy0, ox0);
         // residual of this tile: issued before the MFMA phase, consumed in the epilogue (latency fully hidden)
-        uint4 rreg[2][NPASS];
+        uint4 rreg[NCO][2][2];
         if (resp != nullptr) {
 #pragma unroll
-            for (int p = 0; p < 2; ++p) {
+            for (int s = 0; s < NCO; ++s) {
 #pragma unroll
-                for (int ps = 0; ps < NPASS; ++ps) {
-                    const int oy = oy0 + wave * 2 + p, oxx = ox0 + ps * PXP + e_px;
-                    rreg[p][ps] = make_uint4(0, 0, 0, 0);
-                    if (oy < H && oxx < W)
-                        rreg[p][ps] = ld_global16(resp + bimg * r_sb + oy * r_sy + oxx * r_sx + ch0 + e_q * 8);
+                for (int p = 0; p < 2; ++p) {
+#pragma unroll
+                    for (int m2 = 0; m2 < 2; ++m2) {
+                        const int oy = oy0 + wave * 2 + p, oxx = ox0 + lx;
+                        rreg[s][p][m2] = make_uint4(0, 0, 0, 0);
+                        if (oy < H && oxx < W)
+                            rreg[s][p][m2] = ld_global16(resp + bimg * r_sb + oy * r_sy + oxx * r_sx + ch0 + s * 32 + m2 * 16 + hi * 8);
+                    }
                 }
             }
         }
@@ -645,7 +642,8 @@ __global__ __launch_bounds__(P_NT, 1) void conv3x3_c64_persist_kernel(const demf
                 __builtin_amdgcn_sched_barrier(0);
             });
         }
-        __syncthreads();                                        // B: every MFMA wave is done reading tile t
+        // no second barrier: the epilogue works from registers, and tile t's buffer is only overwritten by the DMA of
+        // tile t+2, issued after barrier A of tile t+1, which every MFMA wave reaches after this MFMA phase
         if (VAR == 1) {
 #pragma unroll
             for (int s = 0; s < NCO; ++s) {
@@ -656,42 +654,44 @@ __global__ __launch_bounds__(P_NT, 1) void conv3x3_c64_persist_kernel(const demf
             }
             continue;
         }
-        // ---- epilogue: per output row, transpose through a wave-private LDS area (inside the consumed tile buffer)
-        // so that LPP consecutive lanes own one pixel's NCO*32 channels: full-line 16-byte stores / residual loads.
-        float* stg = (float*)(tbuf + buf * P_TILE_BYTES + wave * (32 * SLD * 4));
+        // ---- epilogue straight from the accumulators (the tile buffer is not reused: barrier B only orders the DMA) ----
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
+        for (int s = 0; s < NCO; ++s) {
 #pragma unroll
-            for (int s = 0; s < NCO; ++s) {
+            for (int m2 = 0; m2 < 2; ++m2) {
+                const f4_t b0 = *(const f4_t*)(bias_lds + s * 32 + m2 * 16 + hi * 8);
+                const f4_t b1 = *(const f4_t*)(bias_lds + s * 32 + m2 * 16 + hi * 8 + 4);
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    f4_t v;
+                for (int p = 0; p < 2; ++p) {
+                    float v[8];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = acc[s][p][g * 4 + j];
-                    *(f4_t*)(stg + lx * SLD + s * 32 + g * 8 + 4 * hi) = v;
+                    for (int j = 0; j < 4; ++j) {
+                        // quad g = 2*m2 (couts 16m2 + 4hi + j) and g = 2*m2+1 (couts 16m2 + 8 + 4hi + j) of this lane
+                        float qa = acc[s][p][(2 * m2) * 4 + j];
+                        float qb = acc[s][p][(2 * m2 + 1) * 4 + j];
+                        // lanes 32-63 of qa <-> lanes 0-31 of qb: lower half gets (own A | upper's A) = couts 16m2 .. +7,
+                        // upper half gets (lower's B | own B) = couts 16m2+8 .. +15.  Inline asm: on ROCm 7.2 the
+                        // __builtin_amdgcn_permlane32_swap builtin returned the same value in both result slots.
+#if defined(__HIP_DEVICE_COMPILE__)
+                        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(qa), "+v"(qb));
+#endif
+                        v[j] = qa;
+                        v[4 + j] = qb;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { v[j] += b0[j]; v[4 + j] += b1[j]; }
+                    if (resp != nullptr) {
+                        const h8_t r = __builtin_bit_cast(h8_t, rreg[s][p][m2]);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] += (float)r[j];
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], act_floor);   // ReLU or identity, branch-free
+                    const int oy = oy0 + wave * 2 + p, oxx = ox0 + lx;
+                    if (oy < H && oxx < W)
+                        store8<half_t>(dstp + bimg * d_sb + oy * d_sy + oxx * d_sx + ch0 + s * 32 + m2 * 16 + hi * 8, v);
                 }
             }
-            __builtin_amdgcn_wave_barrier();
-            const int oy = oy0 + wave * 2 + p;
-#pragma unroll
-            for (int ps = 0; ps < NPASS; ++ps) {
-                const int pxl = ps * PXP + e_px;
-                const int oxx = ox0 + pxl;
-                const f4_t v0 = *(const f4_t*)(stg + pxl * SLD + e_q * 8);
-                const f4_t v1 = *(const f4_t*)(stg + pxl * SLD + e_q * 8 + 4);
-                float v[8];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { v[j] = v0[j] + bias8[j]; v[4 + j] = v1[j] + bias8[4 + j]; }
-                if (resp != nullptr) {
-                    const h8_t r = __builtin_bit_cast(h8_t, rreg[p][ps]);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] += (float)r[j];
-                }
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], act_floor);       // ReLU or identity, branch-free
-                if (oy < H && oxx < W) store8<half_t>(dstp + bimg * d_sb + oy * d_sy + oxx * d_sx + ch0 + e_q * 8, v);
-            }
-            __builtin_amdgcn_wave_barrier();
         }
     }
 }
@@ -699,7 +699,7 @@ __global__ __launch_bounds__(P_NT, 1) void conv3x3_c64_persist_kernel(const demf
 template <int NCO, int VAR = 0>
 int launch_persist(const demfi_conv* h, const demfi_conv* dev, hipStream_t st)
 {
-    const size_t lds = 9 * 4 * NCO * 1024 + 2 * P_TILE_BYTES;
+    const size_t lds = 9 * 4 * NCO * 1024 + 2 * P_TILE_BYTES + 1024;      // weights + 2 tiles + bias
     static bool attr_done = false;
     if (!attr_done) {
         DEMFI_HIP_CHECK(hipFuncSetAttribute((const void*)conv3x3_c64_persist_kernel<NCO, VAR>,
