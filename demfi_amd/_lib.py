@@ -67,6 +67,8 @@ _SIGS = {
     'demfi_gate_blend': (C.c_int, [C.c_void_p, C.POINTER(View), C.POINTER(View), C.POINTER(View), C.c_int, C.c_int,
                                    C.c_int, C.c_void_p]),
     'demfi_pack_planes': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
+    'demfi_u8_to_window': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    'demfi_frame_to_u8': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'demfi_graph_begin': (C.c_int, [C.c_void_p]),
     'demfi_graph_end': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     'demfi_graph_launch': (C.c_int, [C.c_void_p, C.c_void_p]),

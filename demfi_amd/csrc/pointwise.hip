@@ -420,6 +420,42 @@ __global__ void pack_planes_kernel(PackArgs a, int nch8, T* __restrict__ dst, in
     store16<T>((char*)(dst + (int64_t)pix * dst_sx + g * G), v);
 }
 
+// ---- uint8 frame I/O of the boundary caller --------------------------------------------
+// Input side: cv2.imread BGR uint8 [h,w,3] x 4 frames -> RGBframes_np2Tensor (utils.py:224-238): (u/255 - 0.5)*2 in
+// fp32, layout [C,T,H,W] -- fused with the harness' bottom/right reflect padding (utils.py:1363).
+struct U8Frames { const unsigned char* f[4]; };
+
+__global__ void u8_to_window_kernel(U8Frames fr, float* __restrict__ x, int h, int w, int H, int W)
+{
+    const int i = blockIdx.x * NT + threadIdx.x;
+    if (i >= 4 * H * W) return;
+    const int X = i % W, Y = (i / W) % H, f = i / (W * H);
+    const int sx = X < w ? X : 2 * (w - 1) - X;
+    const int sy = Y < h ? Y : 2 * (h - 1) - Y;
+    const unsigned char* p = fr.f[f] + ((int64_t)sy * w + sx) * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float v = (float)p[c] / 255.0f;
+        v = v - 0.5f;
+        x[((int64_t)(c * 4 + f) * H + Y) * W + X] = v * 2.0f;
+    }
+}
+
+// Output side: denorm255_np (utils.py:718-721) on the float64 copy of the fp32 frame, then .astype(np.uint8)
+// truncation (main.py:1165-1178), cropped to h x w, HWC.
+__global__ void frame_to_u8_kernel(const float* __restrict__ fr, unsigned char* __restrict__ out, int h, int w, int H, int W)
+{
+    const int i = blockIdx.x * NT + threadIdx.x;
+    if (i >= h * w) return;
+    const int X = i % w, Y = i / w;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        double v = ((double)fr[((int64_t)c * H + Y) * W + X] + 1.0) / 2.0;
+        v = v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v);
+        out[(int64_t)i * 3 + c] = (unsigned char)(v * 255.0);
+    }
+}
+
 // A fat view usable by the 16-byte-per-lane kernels: NHWC (sc == 1), C*elt a power-of-two multiple of 16 B.
 int fat_lpp_shift(const demfi_view* v, int C, const char* who, int* is_f32)
 {
@@ -566,6 +602,28 @@ extern "C" int demfi_pack_planes(const float* const* planes, int nch, void* dst,
                            (float*)dst, dst_pix_stride, hw);
     else
         return demfi_set_error(DEMFI_ERR_ARG, "demfi_pack_planes: dtype");
+    DEMFI_HIP_CHECK(hipGetLastError());
+    return DEMFI_OK;
+}
+
+extern "C" int demfi_u8_to_window(const uint8_t* const* frames, int h, int w, float* x, int H, int W, void* stream)
+{
+    if (!frames || !x || h < 2 || w < 2 || H < h || W < w || H - h >= h || W - w >= w)
+        return demfi_set_error(DEMFI_ERR_ARG, "demfi_u8_to_window: bad sizes %dx%d -> %dx%d", h, w, H, W);
+    U8Frames fr;
+    for (int i = 0; i < 4; ++i) {
+        if (!frames[i]) return demfi_set_error(DEMFI_ERR_ARG, "demfi_u8_to_window: frame %d is NULL", i);
+        fr.f[i] = frames[i];
+    }
+    hipLaunchKernelGGL(u8_to_window_kernel, dim3(blocks_for((int64_t)4 * H * W)), dim3(NT), 0, (hipStream_t)stream, fr, x, h, w, H, W);
+    DEMFI_HIP_CHECK(hipGetLastError());
+    return DEMFI_OK;
+}
+
+extern "C" int demfi_frame_to_u8(const float* frame, uint8_t* out, int h, int w, int H, int W, void* stream)
+{
+    if (!frame || !out || h <= 0 || w <= 0 || H < h || W < w) return demfi_set_error(DEMFI_ERR_ARG, "demfi_frame_to_u8: bad args");
+    hipLaunchKernelGGL(frame_to_u8_kernel, dim3(blocks_for((int64_t)h * w)), dim3(NT), 0, (hipStream_t)stream, frame, out, h, w, H, W);
     DEMFI_HIP_CHECK(hipGetLastError());
     return DEMFI_OK;
 }

@@ -44,6 +44,9 @@ class WindowRunner:
     def run_window(self, x):
         """x: [1,3,4,h,w] fp32 on the GPU.  Returns (St [M-1,3,h,w], S0S1 [2,3,h,w]) -- views of reused buffers."""
         e = self.engine
+        if tuple(x.shape) != (1, 3, 4, self.h, self.w):
+            raise ValueError('run_window expects [1,3,4,%d,%d], got %s' % (self.h, self.w, tuple(x.shape)))
+        x = x.contiguous().float()                  # the pad kernel reads raw [3,4,h,w] memory
         cur = torch.cuda.current_stream(e.device)
         self.stream.wait_stream(cur)
         with torch.cuda.stream(self.stream):
@@ -74,6 +77,47 @@ class WindowRunner:
                     self.s01[1].copy_(e.finals[self.n_tst - 1, 1, :, :self.h, :self.w], non_blocking=True)
         cur.wait_stream(self.stream)
         return self.out, self.s01
+
+    def run_window_u8(self, frames_u8):
+        """uint8 in / uint8 out: frames_u8 = 4 BGR uint8 [h,w,3] GPU tensors in the order (B0,B1,B-1,B2).  Returns
+        (St uint8 [M-1,h,w,3], S0S1 uint8 [2,h,w,3]).  Normalisation + reflect padding are fused into ONE kernel writing
+        the engine input; crop + denorm + uint8 truncation into one kernel per output frame."""
+        e = self.engine
+        if getattr(self, '_out_u8', None) is None:
+            self._out_u8 = torch.zeros((self.mfi - 1, self.h, self.w, 3), dtype=torch.uint8, device=e.device)
+            self._s01_u8 = torch.zeros((2, self.h, self.w, 3), dtype=torch.uint8, device=e.device)
+        assert len(frames_u8) == 4 and all(f.dtype == torch.uint8 and tuple(f.shape) == (self.h, self.w, 3) and f.is_contiguous()
+                                           for f in frames_u8)
+        ptrs = (C.c_void_p * 4)(*[f.data_ptr() for f in frames_u8])
+        cur = torch.cuda.current_stream(e.device)
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            h = self.stream.cuda_stream
+            L.check(self.lib.demfi_u8_to_window(ptrs, self.h, self.w, e.x.data_ptr(), e.H, e.W, h), 'u8_to_window')
+            if self.use_graph and self._g_trunk is None:
+                e.run_trunk(h)
+                e.run_t(h, self.n_tst)
+                self.stream.synchronize()
+                self._g_trunk = self._capture(e.run_trunk)
+                self._g_t = self._capture(lambda s: e.run_t(s, self.n_tst))
+            if self.use_graph:
+                L.check(self.lib.demfi_graph_launch(self._g_trunk, h), 'graph_launch')
+            else:
+                e.run_trunk(h)
+            fin = e.finals[self.n_tst - 1]
+            for k in range(self.mfi - 1):
+                e.t_dev.copy_(self.t_all[k:k + 1], non_blocking=True)
+                if self.use_graph:
+                    L.check(self.lib.demfi_graph_launch(self._g_t, h), 'graph_launch')
+                else:
+                    e.run_t(h, self.n_tst)
+                L.check(self.lib.demfi_frame_to_u8(fin[2].data_ptr(), self._out_u8[k].data_ptr(), self.h, self.w, e.H, e.W, h), 'to_u8')
+                if k == 0:
+                    for i in range(2):
+                        L.check(self.lib.demfi_frame_to_u8(fin[i].data_ptr(), self._s01_u8[i].data_ptr(), self.h, self.w, e.H,
+                                                           e.W, h), 'to_u8')
+        cur.wait_stream(self.stream)
+        return self._out_u8, self._s01_u8
 
     def __del__(self):
         try:

@@ -213,6 +213,15 @@ int demfi_gate_blend(const float* w, const demfi_view* source, const demfi_view*
 int demfi_pack_planes(const float* const* planes, int nch, void* dst, int dtype, int64_t dst_pix_stride,
                       int H, int W, void* stream);
 
+/* uint8 frame I/O of the boundary caller.
+ * demfi_u8_to_window: frames = HOST array of 4 device pointers to BGR uint8 [h,w,3] images in the module's frame order
+ * (B0,B1,B-1,B2); writes x [3,4,H,W] fp32 = RGBframes_np2Tensor normalisation (utils.py:224-238) + reflect padding to
+ * H x W (utils.py:1363).
+ * demfi_frame_to_u8: frame planar fp32 [3,H,W] -> out uint8 [h,w,3]: crop + denorm255_np (utils.py:718-721) + uint8
+ * truncation (main.py:1165-1178), bit-identical to the reference's float64 arithmetic. */
+int demfi_u8_to_window(const uint8_t* const* frames, int h, int w, float* x, int H, int W, void* stream);
+int demfi_frame_to_u8(const float* frame, uint8_t* out, int h, int w, int H, int W, void* stream);
+
 /* ---- hipGraph capture of a launch sequence ------------------------------------------------------ */
 int demfi_graph_begin(void* stream);
 int demfi_graph_end(void* stream, void** graph_exec_out);

@@ -420,3 +420,18 @@ def psnr(a, b):
 def t_schedule(M):
     """t values of a x M window (utils.py:558): linspace(1/M, 1-1/M, M-1) as float32."""
     return np.linspace(1 / M, 1 - 1 / M, M - 1).astype(np.float32)
+
+
+def frames_u8_to_tensor(frames):
+    """RGBframes_np2Tensor (utils.py:224-238, channel == 3): list of T uint8 [h,w,3] BGR images (cv2.imread order) ->
+    fp32 [3,T,h,w] in [-1,1]."""
+    arr = np.stack(frames, 0)                                  # [T,h,w,C]
+    t = torch.Tensor(arr.transpose((3, 0, 1, 2)).astype(float)).mul_(1.0)
+    return (t / 255.0 - 0.5) * 2
+
+
+def frame_to_u8(pred):
+    """What the reference writes to disk (main.py:1165-1178): pred [3,h,w] float32 -> float64 numpy -> denorm255_np
+    (utils.py:718-721) -> [h,w,3] -> astype(uint8) (truncation)."""
+    p = np.asarray(pred, dtype=np.float64)
+    return np.transpose(denorm255(p), [1, 2, 0]).astype(np.uint8)

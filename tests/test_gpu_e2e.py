@@ -168,3 +168,40 @@ def test_full_size_720p_fp16_properties(model16):
         assert float(o.min()) >= 0.0 and float(o.max()) <= 1.0
     assert torch.equal(a[4], c[4])                                  # overlay does not depend on t
     assert not torch.equal(a[1][2][2], c[1][2][2])                  # St does
+
+
+def test_uint8_io_bit_exact_and_runner_u8(model16):
+    """uint8 BGR frames in (normalise + reflect pad fused), uint8 frames out (crop +
+    denorm255 + truncation fused) -- both bit-identical to the reference's host arithmetic."""
+    import ctypes as C
+    from demfi_amd import _lib as L
+    from demfi_amd.harness import t_schedule
+    from demfi_amd.runner import WindowRunner
+    lib = L.load()
+    h, w, H, W = 50, 70, 64, 96
+    g = torch.Generator().manual_seed(5)
+    frames = [torch.randint(0, 256, (h, w, 3), generator=g, dtype=torch.uint8) for _ in range(4)]
+    dev = [f.to(DEV) for f in frames]
+    x = torch.zeros(3, 4, H, W, device=DEV)
+    ptrs = (C.c_void_p * 4)(*[f.data_ptr() for f in dev])
+    st = torch.cuda.current_stream().cuda_stream
+    L.check(lib.demfi_u8_to_window(ptrs, h, w, x.data_ptr(), H, W, st))
+    ref = O.frames_u8_to_tensor([f.numpy() for f in frames])                       # [3,4,h,w]
+    refp = torch.nn.functional.pad(ref.reshape(1, 12, h, w), [0, W - w, 0, H - h], mode='reflect').reshape(3, 4, H, W)
+    torch.cuda.synchronize()
+    assert torch.equal(x.cpu(), refp)
+    fr = (torch.randn(3, H, W, generator=g) * 0.8).to(DEV)
+    out = torch.zeros(h, w, 3, dtype=torch.uint8, device=DEV)
+    L.check(lib.demfi_frame_to_u8(fr.data_ptr(), out.data_ptr(), h, w, H, W, st))
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), O.frame_to_u8(fr.cpu().numpy()[:, :h, :w]))
+    # the uint8 runner == float runner on the same window, then quantised
+    N, M = 2, 4
+    runner = WindowRunner(model16, h, w, n_tst=N, mfi=M)
+    stf, s01f = runner.run_window(ref[None].to(DEV))
+    stf, s01f = stf.clone(), s01f.clone()
+    stu, s01u = runner.run_window_u8(dev)
+    torch.cuda.synchronize()
+    for k in range(M - 1):
+        assert np.array_equal(stu[k].cpu().numpy(), O.frame_to_u8(stf[k].cpu().numpy()))
+    assert np.array_equal(s01u[1].cpu().numpy(), O.frame_to_u8(s01f[1].cpu().numpy()))
