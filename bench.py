@@ -42,26 +42,37 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(n_tst, full_px):
+def cpu_baseline(n_tst, full_px, model=None, dev=None):
     """Oracle (CPU restatement, reference semantics: one FULL forward per t, no trunk caching) on a bounded sample:
-    the full padded 736x1280 frame (about 25 s on 32 threads), one t; scaled to 720p-equivalent frames/s."""
+    the full padded 736x1280 frame of the workload, ONE of the 7 t (about 30 s on 32 threads).  The same window / t is
+    then pushed through the HIP path to report the metric's second half: PSNR against the fp32 reference semantics."""
     from demfi_amd import synthetic_state_dict, synthetic_window
     from oracle import demfi_oracle as O
     torch.set_num_threads(min(os.cpu_count() or 1, 32))       # beyond ~32 threads MKLDNN convs of this size slow down
     sd = synthetic_state_dict(0)
-    h, w = 736, 1280                                          # the whole padded frame of the workload, ONE of the 7 t
+    h, w = 736, 1280
     x = synthetic_window(h, w, 1)
     t = torch.tensor([[0.5]])
     with torch.no_grad():
         O.forward(sd, synthetic_window(64, 64, 2), t, 1)          # warm-up
         t0 = time.time()
-        O.forward(sd, x, t, n_tst)
+        ref = O.forward(sd, x, t, n_tst)
         dt = time.time() - t0
     frac = (h * w) / float(full_px)
-    return {'value': round(frac / dt, 5), 'unit': 'frames/s (720p-equivalent)', 'cores': torch.get_num_threads(),
-            'kind': 'port', 'seconds_for_sample': round(dt, 2),
-            'sample': 'oracle/demfi_oracle.forward fp32, one t, N_tst=%d, on a %dx%d window (%.3f of the padded 736x1280 '
-                      'pixels); reference semantics = full forward per frame' % (n_tst, h, w, frac)}
+    out = {'value': round(frac / dt, 5), 'unit': 'frames/s (720p-equivalent)', 'cores': torch.get_num_threads(),
+           'kind': 'port', 'seconds_for_sample': round(dt, 2),
+           'sample': 'oracle/demfi_oracle.forward fp32, one t, N_tst=%d, on a %dx%d window (%.3f of the padded 736x1280 '
+                     'pixels); reference semantics = full forward per frame' % (n_tst, h, w, frac)}
+    psnr = None
+    if model is not None:
+        got = model(x.to(dev), t.to(dev), n_tst)
+        st = got[1][n_tst - 1][2][0].float().cpu().numpy()
+        st_ref = ref[1][n_tst - 1][2][0].numpy()
+        gt = x[0, :, 0].numpy()                                 # fixed pseudo ground truth (SURVEY.md section 8d)
+        psnr = {'St_vs_oracle_fp32_dB': round(float(O.psnr(st, st_ref)), 2),
+                'dPSNR_vs_pseudoGT_dB': round(float(O.psnr(st, gt) - O.psnr(st_ref, gt)), 4),
+                'note': 'same window, t=0.5, N_tst=%d; oracle = CPU fp32 restatement pinned to the reference' % n_tst}
+    return out, psnr
 
 
 def main():
@@ -149,7 +160,7 @@ def main():
                     tf = 2.0 * p[4] / (p[3] * 1e-3) / 1e12 if p[4] else 0.0
                     f.write('%-7s %-10s %-48s %9.4f ms %8.1f TFLOP/s\n' % (p[0], p[1], p[2], p[3], tf))
         if world == 1 and not a.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(a.n_tst, eng.H * eng.W)
+            out['cpu_baseline'], out['psnr'] = cpu_baseline(a.n_tst, eng.H * eng.W, model, dev)
         print(json.dumps(out))
     D.finalize()
 
