@@ -205,3 +205,23 @@ def test_uint8_io_bit_exact_and_runner_u8(model16):
     for k in range(M - 1):
         assert np.array_equal(stu[k].cpu().numpy(), O.frame_to_u8(stf[k].cpu().numpy()))
     assert np.array_equal(s01u[1].cpu().numpy(), O.frame_to_u8(s01f[1].cpu().numpy()))
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16])
+def test_ragged_frame_size_multiple_of_8_only(dtype):
+    """The model itself only needs H, W % 8 == 0 (UNet, DeMFInet.py:575-603); tiles of 8x32 are then partial in x
+    (W = 72 -> 2.25 tiles) and the persistent kernel walks fewer tiles than CUs."""
+    sd = synthetic_state_dict(0)
+    m = _model(dtype, sd)
+    x = synthetic_window(40, 72, 31)
+    t = torch.tensor([[0.375]])
+    out = m(x.to(DEV), t.to(DEV), 2)
+    with torch.no_grad():
+        ref = O.forward(sd, x, t, 2)
+    for i in range(3):
+        got = out[1][1][i][0].cpu().numpy()
+        assert np.isfinite(got).all()
+        if dtype == torch.float32:
+            _close(got, ref[1][1][i][0].numpy(), 'ragged')
+        else:
+            assert O.psnr(got, ref[1][1][i][0].numpy()) > 30.0
