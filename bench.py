@@ -85,9 +85,13 @@ def main():
     from demfi_amd import DeMFInet, HyperParams, synthetic_state_dict, synthetic_window
     from demfi_amd.runner import WindowRunner
     from demfi_amd import dist as D
+    # test hook: DEMFI_BENCH_BACKEND=gloo runs all ranks of a multi-process launch on the GPUs that exist (rank % count),
+    # so the N>1 control flow can be exercised on a 1-GPU box; the driver's 8-GPU run uses the default nccl (= RCCL)
+    backend = os.environ.get('DEMFI_BENCH_BACKEND') or None
+    local = local % torch.cuda.device_count() if backend == 'gloo' else local
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
-    D.init(world, rank, local)
+    D.init(world, rank, local, backend=backend)
     dtype = torch.float16 if a.dtype == 'fp16' else torch.float32
     model = DeMFInet(HyperParams(gpu=local), dtype=dtype)
     if rank == 0:

@@ -1,6 +1,6 @@
 """GPU-box diagnostic: per-stage differences between the HIP engine buffers and the oracle's intermediates."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # repo root
 import torch, numpy as np
 from demfi_amd import DeMFInet, HyperParams, synthetic_state_dict, synthetic_window
 from oracle import demfi_oracle as O
