@@ -154,6 +154,25 @@ __device__ __forceinline__ void dbg_store(int* dbg, int which, int64_t hw, int64
     d[2 * hw + pix] = m.inb | (valid ? 16 : 0);
 }
 
+// v_fma_mix_f32: d = (f16 half of a) * b + c in fp32 -- folds the fp16->fp32 conversion of a gathered value into the FMA
+// (the compiler does not select it here; the blend kernels are VALU-bound, so the saved v_cvt is wall time).
+__device__ __forceinline__ float fma_mix_lo(unsigned a, float b, float c)
+{
+    float d = 0.0f;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+#endif
+    return d;
+}
+__device__ __forceinline__ float fma_mix_hi(unsigned a, float b, float c)
+{
+    float d = 0.0f;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+#endif
+    return d;
+}
+
 template <typename T> struct Vec16;
 template <> struct Vec16<half_t> { static constexpr int N = 8; };
 template <> struct Vec16<float> { static constexpr int N = 4; };
@@ -207,11 +226,10 @@ __device__ __forceinline__ void store16(char* p, const float* v)
 // round trips (8 IEEE divisions + exp per warp pair): now each wave first computes the maps of 64 consecutive pixels
 // with ONE lane per pixel, parks them in a wave-private LDS record, and then walks the pixels LPP lanes at a time
 // (16 bytes of channels per lane): broadcast LDS reads, 8 unconditional 16-byte gathers, FMA accumulation.
-struct WarpRec {                    // 16 dwords per pixel
-    int xy0a, xy0b;                 // x0 | y0 << 16 (biased by 8) of the two warps
+struct WarpRec {                    // 20 dwords per pixel
+    int offa[4], offb[4];           // byte offsets of the 4 (clamped) corner records of the two warps
     float wa[4], wb[4];             // corner weights, out-of-bounds and invalid-mask already folded to 0
     float ka, kb, inv_den, den;     // (1-t)*o0, t*(1-o0), 1/den, den
-    int pad[2];
 };
 
 template <typename T>
@@ -227,6 +245,7 @@ __global__ __launch_bounds__(NT) void warp_blend_fat_kernel(demfi_view A, const 
     const int wave = threadIdx.x >> 6;
     const int pix0 = (blockIdx.x * (NT / 64) + wave) * 64;        // first pixel of this wave
     WarpRec* wr = recs + wave * 64;
+    if (pix0 >= hw) return;                                        // whole wave past the image (no workgroup barrier below)
     // ---- phase 1: one lane per pixel -------------------------------------------------------------------
     {
         const int pix = pix0 + lane;
@@ -241,15 +260,20 @@ __global__ __launch_bounds__(NT) void warp_blend_fat_kernel(demfi_view A, const 
             const float o1 = 1.0f - o0;
             if (occ_out) occ_out[pix] = o0;
             if (dbg) { dbg_store(dbg, 0, hw, pix, ma, va); dbg_store(dbg, 1, hw, pix, mb, vb); }
-            r.xy0a = (ma.x0 + 8) | ((ma.y0 + 8) << 16);
-            r.xy0b = (mb.x0 + 8) | ((mb.y0 + 8) << 16);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { r.wa[k] = va ? ma.w[k] : 0.0f; r.wb[k] = vb ? mb.w[k] : 0.0f; }   // output * mask (766)
+            for (int k = 0; k < 4; ++k) {
+                r.wa[k] = va ? ma.w[k] : 0.0f;                           // output * mask (766)
+                r.wb[k] = vb ? mb.w[k] : 0.0f;
+                // out-of-bounds corners carry weight 0: point them at a clamped in-bounds record so the load is legal
+                const int ya = min(max(ma.y0 + (k >> 1), 0), H - 1), xa = min(max(ma.x0 + (k & 1), 0), W - 1);
+                const int yb = min(max(mb.y0 + (k >> 1), 0), H - 1), xb = min(max(mb.x0 + (k & 1), 0), W - 1);
+                r.offa[k] = (int)((ya * A.sy + xa * A.sx) * (int64_t)sizeof(T));
+                r.offb[k] = (int)((yb * B.sy + xb * B.sx) * (int64_t)sizeof(T));
+            }
             r.ka = (1.0f - t) * o0;
             r.kb = t * o1;
             r.den = r.ka + r.kb;
             r.inv_den = 1.0f / r.den;
-            r.pad[0] = r.pad[1] = 0;
             wr[lane] = r;
         }
     }
@@ -260,7 +284,6 @@ __global__ __launch_bounds__(NT) void warp_blend_fat_kernel(demfi_view A, const 
     const int lpp = 1 << lpp_shift;
     const int ppi = 64 >> lpp_shift;                              // pixels per iteration
     const int part = lane & (lpp - 1);
-    const int64_t asx = A.sx * sizeof(T), asy = A.sy * sizeof(T), bsx = B.sx * sizeof(T), bsy = B.sy * sizeof(T);
     const char* ap = (const char*)A.ptr + part * 16;
     const char* bp = (const char*)B.ptr + part * 16;
     const int psub = lane >> lpp_shift;
@@ -268,14 +291,10 @@ __global__ __launch_bounds__(NT) void warp_blend_fat_kernel(demfi_view A, const 
         int pl = it * ppi + psub;
         if (pix0 + pl >= hw) pl = 0;                              // clamp: results of out-of-range pixels are never stored
         r = wr[pl];
-        const int ax0 = (r.xy0a & 0xffff) - 8, ay0 = (r.xy0a >> 16) - 8;
-        const int bx0 = (r.xy0b & 0xffff) - 8, by0 = (r.xy0b >> 16) - 8;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int ya = min(max(ay0 + (k >> 1), 0), H - 1), xa = min(max(ax0 + (k & 1), 0), W - 1);
-            const int yb = min(max(by0 + (k >> 1), 0), H - 1), xb = min(max(bx0 + (k & 1), 0), W - 1);
-            ra[k] = ld_global16(ap + ya * asy + xa * asx);
-            rb[k] = ld_global16(bp + yb * bsy + xb * bsx);
+            ra[k] = ld_global16(ap + r.offa[k]);
+            rb[k] = ld_global16(bp + r.offb[k]);
         }
     };
     auto finish = [&](int it, const uint4 (&ra)[4], const uint4 (&rb)[4], const WarpRec& r) {
@@ -288,9 +307,14 @@ __global__ __launch_bounds__(NT) void warp_blend_fat_kernel(demfi_view A, const 
 #pragma unroll
         for (int k = 0; k < 4; ++k) {                             // ATen order nw, ne, sw, se; zero weights add exactly 0
             if constexpr (sizeof(T) == 2) {
-                const h8_t va = __builtin_bit_cast(h8_t, ra[k]), vb = __builtin_bit_cast(h8_t, rb[k]);
+                const unsigned pa[4] = {ra[k].x, ra[k].y, ra[k].z, ra[k].w}, pb[4] = {rb[k].x, rb[k].y, rb[k].z, rb[k].w};
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { wa[j] = __builtin_fmaf((float)va[j], r.wa[k], wa[j]); wb[j] = __builtin_fmaf((float)vb[j], r.wb[k], wb[j]); }
+                for (int q = 0; q < 4; ++q) {
+                    wa[2 * q] = fma_mix_lo(pa[q], r.wa[k], wa[2 * q]);
+                    wa[2 * q + 1] = fma_mix_hi(pa[q], r.wa[k], wa[2 * q + 1]);
+                    wb[2 * q] = fma_mix_lo(pb[q], r.wb[k], wb[2 * q]);
+                    wb[2 * q + 1] = fma_mix_hi(pb[q], r.wb[k], wb[2 * q + 1]);
+                }
             } else {
                 const f4_t va = __builtin_bit_cast(f4_t, ra[k]), vb = __builtin_bit_cast(f4_t, rb[k]);
 #pragma unroll
