@@ -451,7 +451,12 @@ constexpr int P_NT = NT + 64;                                   // 4 MFMA waves 
 // One k-step pair of fragments: 2 k-steps x (NCO A fragments + 2 B fragments)
 template <int NCO> struct FragSet { uint4 a[2][NCO]; uint4 b[2][2]; };
 
-template <int NCO, int VAR>      // VAR: 0 = product; 1 no epilogue, 2 no MFMA phase, 3 no tile DMA, 4 epilogue only (ablation builds)
+// PIPE (NCO == 2 only; EXPERIMENT, instantiated only in -DDEMFI_ABLATION builds with DEMFI_PERSIST_VARIANT=6): the two
+// 32-cout subtiles are computed in two half-phases per tile and the register epilogue of one subtile is interleaved,
+// a few instructions at a time, between the MFMAs of the other.  Measured 0.32 ms vs 0.29 ms for the plain version
+// (3x3 64->64, 736x1280, batch 3): halving the A-fragment reuse (3 ds_reads per 2 MFMAs) costs more than the hidden
+// epilogue gains.
+template <int NCO, int VAR, bool PIPE = false>      // VAR: 0 = product; 1 no epilogue, 2 no MFMA phase, 3 no tile DMA, 4 epilogue only (ablation builds)
 __global__ __launch_bounds__(P_NT, 1) void conv3x3_c64_persist_kernel(const demfi_conv* __restrict__ d)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -573,6 +578,109 @@ __global__ __launch_bounds__(P_NT, 1) void conv3x3_c64_persist_kernel(const demf
         boff[g] = col * 128 + ((((g & 3) * 2 + hi) ^ ((col >> 1) & 7)) << 4);
     }
     const char* const wl = wlds + lane * 16;
+    if constexpr (PIPE && NCO == 2) {
+        f16x_t acc[2][2];
+        uint4 rr[2][2][2];                                      // residual of subtile s: [s][p][m2], loaded one half-phase early
+        int cb[2], cy[2], cx[2];                                // tile coordinates the accumulators of subtile s belong to
+        float v[8];                                             // values of the epilogue unit in flight
+        // one epilogue unit = (m2, p) of subtile S: 8 consecutive couts of pixel (row p, column lx); 5 chunks of ~6-10
+        // instructions each, issued one chunk per k-step between the MFMAs of the OTHER subtile
+        auto epi_chunk = [&](auto S_, auto STEP_) {
+            constexpr int S = decltype(S_)::value, STEP = decltype(STEP_)::value;
+            constexpr int unit = STEP / 5, chunk = STEP % 5, m2 = unit >> 1, p = unit & 1;
+            if constexpr (chunk == 0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float qa = acc[S][p][(2 * m2) * 4 + j];
+                    float qb = acc[S][p][(2 * m2 + 1) * 4 + j];
+#if defined(__HIP_DEVICE_COMPILE__)
+                    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(qa), "+v"(qb));
+#endif
+                    v[j] = qa;
+                    v[4 + j] = qb;
+                }
+            } else if constexpr (chunk == 1) {
+                const f4_t b0 = *(const f4_t*)(bias_lds + S * 32 + m2 * 16 + hi * 8);
+                const f4_t b1 = *(const f4_t*)(bias_lds + S * 32 + m2 * 16 + hi * 8 + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { v[j] += b0[j]; v[4 + j] += b1[j]; }
+            } else if constexpr (chunk == 2) {
+                if (resp != nullptr) {
+                    const h8_t r = __builtin_bit_cast(h8_t, rr[S][p][m2]);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] += (float)r[j];
+                }
+            } else if constexpr (chunk == 3) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], act_floor);
+            } else {
+                const int oy = cy[S] + wave * 2 + p, oxx = cx[S] + lx;
+                if (oy < H && oxx < W)
+                    store8<half_t>(dstp + cb[S] * d_sb + oy * d_sy + oxx * d_sx + ch0 + S * 32 + m2 * 16 + hi * 8, v);
+            }
+        };
+        auto load_res = [&](auto S_, int bimg, int oy0, int ox0) {
+            constexpr int S = decltype(S_)::value;
+            if (resp == nullptr) return;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+#pragma unroll
+                for (int m2 = 0; m2 < 2; ++m2) {
+                    const int oy = oy0 + wave * 2 + p, oxx = ox0 + lx;
+                    rr[S][p][m2] = make_uint4(0, 0, 0, 0);
+                    if (oy < H && oxx < W)
+                        rr[S][p][m2] = ld_global16(resp + bimg * r_sb + oy * r_sy + oxx * r_sx + ch0 + S * 32 + m2 * 16 + hi * 8);
+                }
+            }
+        };
+        struct Frag1 { uint4 a, b0, b1; };
+        // half-phase of subtile S on the tile in 'tb'; EPI: interleave the epilogue of the other subtile
+        auto half_phase = [&](auto S_, const char* tb, bool epi) {
+            constexpr int S = decltype(S_)::value;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { acc[S][0][i] = 0.0f; acc[S][1][i] = 0.0f; }
+            auto load_step = [&](Frag1& f, int st) {                  // st = tap*4 + ks
+                const int tap = st >> 2, ks = st & 3;
+                const int ky = tap / 3, kx = tap % 3;
+                f.a = *(const uint4*)(wl + ((tap * NKS + ks) * 2 + S) * 1024);
+                const char* p0 = tb + boff[kx * 4 + ks];
+                f.b0 = *(const uint4*)(p0 + ky * (P_LW * 128));
+                f.b1 = *(const uint4*)(p0 + (ky + 1) * (P_LW * 128));
+            };
+            Frag1 f[3];                                                // fragments two k-steps ahead of the MFMAs
+            load_step(f[0], 0);
+            load_step(f[1], 1);
+            static_for<0, 36>([&](auto ST) {
+                constexpr int st = decltype(ST)::value;
+                if constexpr (st + 2 < 36) load_step(f[(st + 2) % 3], st + 2);
+                __builtin_amdgcn_sched_barrier(0);
+                Mma<half_t>::run(acc[S][0], f[st % 3].a, f[st % 3].b0);
+                Mma<half_t>::run(acc[S][1], f[st % 3].a, f[st % 3].b1);
+                if constexpr (st < 20) {
+                    if (epi) epi_chunk(std::integral_constant<int, 1 - S>{}, ST);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        };
+        int buf = 0;
+        bool have_prev = false;
+        for (int t = t_first; t < t_end; t += t_step, buf ^= 1) {
+            int bimg, oy0, ox0;
+            tile_coords(t, bimg, oy0, ox0);
+            __syncthreads();                                    // A: tile t is in LDS
+            const char* tb = tbuf + buf * P_TILE_BYTES + (wave * 2) * (P_LW * 128);
+            load_res(std::integral_constant<int, 0>{}, bimg, oy0, ox0);
+            half_phase(std::integral_constant<int, 0>{}, tb, have_prev);          // + epilogue of subtile 1 of the previous tile
+            cb[0] = bimg; cy[0] = oy0; cx[0] = ox0;
+            load_res(std::integral_constant<int, 1>{}, bimg, oy0, ox0);
+            half_phase(std::integral_constant<int, 1>{}, tb, true);               // + epilogue of subtile 0 of this tile
+            cb[1] = bimg; cy[1] = oy0; cx[1] = ox0;
+            have_prev = true;
+        }
+        // drain: subtile 1 of the last tile
+        static_for<0, 20>([&](auto ST) { epi_chunk(std::integral_constant<int, 1>{}, ST); });
+        return;
+    }
     int buf = 0;
     for (int t = t_first; t < t_end; t += t_step, buf ^= 1) {
         int bimg, oy0, ox0;
@@ -696,19 +804,19 @@ __global__ __launch_bounds__(P_NT, 1) void conv3x3_c64_persist_kernel(const demf
     }
 }
 
-template <int NCO, int VAR = 0>
+template <int NCO, int VAR = 0, bool PIPE = false>
 int launch_persist(const demfi_conv* h, const demfi_conv* dev, hipStream_t st)
 {
     const size_t lds = 9 * 4 * NCO * 1024 + 2 * P_TILE_BYTES + 1024;      // weights + 2 tiles + bias
     static bool attr_done = false;
     if (!attr_done) {
-        DEMFI_HIP_CHECK(hipFuncSetAttribute((const void*)conv3x3_c64_persist_kernel<NCO, VAR>,
+        DEMFI_HIP_CHECK(hipFuncSetAttribute((const void*)conv3x3_c64_persist_kernel<NCO, VAR, PIPE>,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done = true;
     }
     const int total = ((h->W + TW - 1) / TW) * ((h->H + TH - 1) / TH) * h->batch;
     const int grid = total >= 256 ? 256 : total;
-    hipLaunchKernelGGL((conv3x3_c64_persist_kernel<NCO, VAR>), dim3(grid), dim3(P_NT), lds, st, dev);
+    hipLaunchKernelGGL((conv3x3_c64_persist_kernel<NCO, VAR, PIPE>), dim3(grid), dim3(P_NT), lds, st, dev);
     DEMFI_HIP_CHECK(hipGetLastError());
     return DEMFI_OK;
 }
@@ -1122,6 +1230,7 @@ extern "C" int demfi_conv2d(const demfi_conv* h, const demfi_conv* dev, void* st
             if (var == 13) return launch_regw<3>(h, dev, st);
             if (var == 14) return launch_regw<4>(h, dev, st);
             if (var == 10) return launch_regw(h, dev, st);
+            if (var == 6) return launch_persist<2, 0, true>(h, dev, st);
 #endif
             return launch_persist<2>(h, dev, st);
         }
