@@ -456,7 +456,7 @@ template <int NCO> struct FragSet { uint4 a[2][NCO]; uint4 b[2][2]; };
 // a few instructions at a time, between the MFMAs of the other.  Measured 0.32 ms vs 0.29 ms for the plain version
 // (3x3 64->64, 736x1280, batch 3): halving the A-fragment reuse (3 ds_reads per 2 MFMAs) costs more than the hidden
 // epilogue gains.
-template <int NCO, int VAR, bool PIPE = false>      // VAR: 0 = product; 1 no epilogue, 2 no MFMA phase, 3 no tile DMA, 4 epilogue only (ablation builds)
+template <int NCO, int VAR, bool PIPE = false, bool RES = true>   // RES: the segment has a residual input (compile time: keeps the loads free of phis).  VAR: 0 = product; 1 no epilogue, 2 no MFMA phase, 3 no tile DMA, 4 epilogue only (ablation builds)
 __global__ __launch_bounds__(P_NT, 1) void conv3x3_c64_persist_kernel(const demfi_conv* __restrict__ d)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -571,6 +571,7 @@ __global__ __launch_bounds__(P_NT, 1) void conv3x3_c64_persist_kernel(const demf
     // transpose.  The bias (NCO*32 floats) sits in the 2 KiB of LDS behind the tile buffers.
     float* const bias_lds = (float*)(tbuf + 2 * P_TILE_BYTES);
     if (tid < NCO * 32) bias_lds[tid] = d->bias[tid];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the write is in LDS before this wave's first (raw) barrier A
     int boff[12];                                               // [kx*4 + ks]: (column lx+kx) record + swizzled 16-byte slot
 #pragma unroll
     for (int g = 0; g < 12; ++g) {
@@ -685,24 +686,26 @@ __global__ __launch_bounds__(P_NT, 1) void conv3x3_c64_persist_kernel(const demf
     for (int t = t_first; t < t_end; t += t_step, buf ^= 1) {
         int bimg, oy0, ox0;
         tile_coords(t, bimg, oy0, ox0);
-        // residual of this tile: issued before the MFMA phase, consumed in the epilogue (latency fully hidden)
-        uint4 rreg[NCO][2][2];
-        if (resp != nullptr) {
+        // Residual of this tile: issued before the MFMA phase, consumed in the epilogue.  The loads are unconditional
+        // (clamped address, no per-lane branch) and barrier A is a RAW s_barrier: a lane-divergent load leaves register
+        // copies behind and __syncthreads() carries a fence -- either one makes the compiler put s_waitcnt vmcnt(0)
+        // in front of the MFMA phase, i.e. a full HBM round trip per tile (measured: +0.064 ms on the 0.28 ms launch).
+        u4_t rreg[NCO][2][2];
+        if constexpr (RES) {
 #pragma unroll
-            for (int s = 0; s < NCO; ++s) {
+            for (int p = 0; p < 2; ++p) {
+                const int oy = min(oy0 + wave * 2 + p, H - 1), oxx = min(ox0 + lx, W - 1);
+                const half_t* rp = resp + bimg * r_sb + oy * r_sy + oxx * r_sx + ch0 + hi * 8;
 #pragma unroll
-                for (int p = 0; p < 2; ++p) {
+                for (int s = 0; s < NCO; ++s) {
 #pragma unroll
-                    for (int m2 = 0; m2 < 2; ++m2) {
-                        const int oy = oy0 + wave * 2 + p, oxx = ox0 + lx;
-                        rreg[s][p][m2] = make_uint4(0, 0, 0, 0);
-                        if (oy < H && oxx < W)
-                            rreg[s][p][m2] = ld_global16(resp + bimg * r_sb + oy * r_sy + oxx * r_sx + ch0 + s * 32 + m2 * 16 + hi * 8);
-                    }
+                    for (int m2 = 0; m2 < 2; ++m2) rreg[s][p][m2] = *gcp<u4_t>(rp + s * 32 + m2 * 16);
                 }
             }
         }
-        __syncthreads();                                        // A: tile t is in LDS
+        // A: tile t is in LDS (the DMA wave waited for it).  These waves wrote no LDS and consumed every ds_read of the
+        // previous tile, so no counter has to drain here; "memory" keeps the compiler from moving LDS reads above it.
+        asm volatile("s_barrier" ::: "memory");
         f16x_t acc[NCO][2];
 #pragma unroll
         for (int s = 0; s < NCO; ++s) {
@@ -763,6 +766,15 @@ __global__ __launch_bounds__(P_NT, 1) void conv3x3_c64_persist_kernel(const demf
             continue;
         }
         // ---- epilogue straight from the accumulators (the tile buffer is not reused: barrier B only orders the DMA) ----
+        if constexpr (RES) {
+            // Retire the residual loads HERE (they landed during the MFMA phase): otherwise the compiler's in-order
+            // vmcnt bookkeeping makes the later units wait for this epilogue's own stores to be acknowledged.
+#pragma unroll
+            for (int s = 0; s < NCO; ++s) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(rreg[s][q >> 1][q & 1]));
+            }
+        }
 #pragma unroll
         for (int s = 0; s < NCO; ++s) {
 #pragma unroll
@@ -788,7 +800,7 @@ __global__ __launch_bounds__(P_NT, 1) void conv3x3_c64_persist_kernel(const demf
                     }
 #pragma unroll
                     for (int j = 0; j < 4; ++j) { v[j] += b0[j]; v[4 + j] += b1[j]; }
-                    if (resp != nullptr) {
+                    if constexpr (RES) {
                         const h8_t r = __builtin_bit_cast(h8_t, rreg[s][p][m2]);
 #pragma unroll
                         for (int j = 0; j < 8; ++j) v[j] += (float)r[j];
@@ -810,13 +822,18 @@ int launch_persist(const demfi_conv* h, const demfi_conv* dev, hipStream_t st)
     const size_t lds = 9 * 4 * NCO * 1024 + 2 * P_TILE_BYTES + 1024;      // weights + 2 tiles + bias
     static bool attr_done = false;
     if (!attr_done) {
-        DEMFI_HIP_CHECK(hipFuncSetAttribute((const void*)conv3x3_c64_persist_kernel<NCO, VAR, PIPE>,
+        DEMFI_HIP_CHECK(hipFuncSetAttribute((const void*)conv3x3_c64_persist_kernel<NCO, VAR, PIPE, true>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        DEMFI_HIP_CHECK(hipFuncSetAttribute((const void*)conv3x3_c64_persist_kernel<NCO, VAR, PIPE, false>,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done = true;
     }
     const int total = ((h->W + TW - 1) / TW) * ((h->H + TH - 1) / TH) * h->batch;
     const int grid = total >= 256 ? 256 : total;
-    hipLaunchKernelGGL((conv3x3_c64_persist_kernel<NCO, VAR, PIPE>), dim3(grid), dim3(P_NT), lds, st, dev);
+    if (h->segs[h->sub_seg[0]].res.ptr != nullptr)
+        hipLaunchKernelGGL((conv3x3_c64_persist_kernel<NCO, VAR, PIPE, true>), dim3(grid), dim3(P_NT), lds, st, dev);
+    else
+        hipLaunchKernelGGL((conv3x3_c64_persist_kernel<NCO, VAR, PIPE, false>), dim3(grid), dim3(P_NT), lds, st, dev);
     DEMFI_HIP_CHECK(hipGetLastError());
     return DEMFI_OK;
 }
