@@ -144,7 +144,11 @@ class Plan:
         nco = sub if sub <= 5 else 4
         # LDS per workgroup = haloed input tile + 2-tap weight ring; keep it under the budget (2 workgroups per CU)
         rec = 128
-        while rec > 32 and LH * LW * (rec + 16) + 2 * (rec // 32) * nco * 1024 > self.LDS_BUDGET:
+        # the SepConvGRU layers (1x5 / 5x1 over two 64-channel NHWC pieces) run on their own persistent kernel, which wants
+        # the two pieces as two 64-channel chunks whatever the general kernel's LDS budget says
+        sep = (esz == 2 and stride == 1 and (kh, kw) in ((1, 5), (5, 1)) and len(srcs) == 2 and cout in (64, 128)
+               and all(s.fat and len(s.cin) == 64 and not s.up for s in srcs))
+        while not sep and rec > 32 and LH * LW * (rec + 16) + 2 * (rec // 32) * nco * 1024 > self.LDS_BUDGET:
             rec //= 2
         # ---- pack the input pieces into chunks of <= rec bytes (fat pieces first: 16-byte aligned) -------
         order = [s for s in srcs if s.fat] + [s for s in srcs if not s.fat]

@@ -160,6 +160,46 @@ def test_conv_multi_piece_routing_upsample_shuffle(dtype):
     assert (nchw(hn) - ((1 - nchw(zb)) * nchw(h) + nchw(zb) * qv)).abs().max() < tol
 
 
+@pytest.mark.parametrize('kh,kw', [(1, 5), (5, 1)])
+@pytest.mark.parametrize('H,W,batch', [(8, 32, 1), (37, 75, 2), (64, 96, 1), (100, 45, 1), (33, 8, 3)])
+def test_sep_gru_persistent_kernel(kh, kw, H, W, batch):
+    """SepConvGRU half-step (DeMFInet.py:844-849 / 851-856) through the persistent 1x5 / 5x1 kernel: fused z|r launch
+    (sigmoid, sigmoid*h) and the q launch ((1-z)h + z tanh), ragged tile edges, batch > 1, both orientations."""
+    torch.manual_seed(11 + kh)
+    pl = Plan(H, W, torch.float16, DEV)
+    h, xx = pl._fat(H, W, 64, batch), pl._fat(H, W, 64, batch)
+    h.copy_(torch.tanh(torch.randn(h.shape, device=DEV)))
+    xx.copy_(torch.randn(xx.shape, device=DEV))
+    zb, rh, hn = pl._fat(H, W, 64, batch), pl._fat(H, W, 64, batch), pl._fat(H, W, 64, batch)
+    wzr = torch.randn(128, 128, kh, kw) * 0.05
+    bzr = torch.randn(128) * 0.1
+    wq = torch.randn(64, 128, kh, kw) * 0.05
+    bq = torch.randn(64) * 0.1
+    seg = []
+    pl.conv(seg, 'zr', [pl.fsrc(h, 0), pl.fsrc(xx, 64)],
+            [_Dst(pl.fview(zb), range(0, 64), L.ACT_SIGMOID), _Dst(pl.fview(rh), range(64, 128), mode=L.MODE_MUL, res=pl.fview(h))],
+            H, W, batch=batch, weight=wzr, bias=bzr)
+    pl.conv(seg, 'q', [pl.fsrc(rh, 0), pl.fsrc(xx, 64)],
+            [_Dst(pl.fview(hn), range(64), mode=L.MODE_GRU, res=pl.fview(h), aux=pl.fview(zb))], H, W, batch=batch,
+            weight=wq, bias=bq)
+    pl._upload()
+    for rep in range(2):                                   # twice: the launch leaves no state behind
+        zb.zero_(); rh.zero_(); hn.zero_()
+        pl.launch_conv(0, _stream())
+        pl.launch_conv(1, _stream())
+    torch.cuda.synchronize()
+    F = torch.nn.functional
+    nchw = lambda t: t.permute(0, 3, 1, 2).float().cpu()
+    q16 = lambda z: z.half().float()
+    pad = (kh // 2, kw // 2)
+    zr = F.conv2d(torch.cat([nchw(h), nchw(xx)], 1), q16(wzr), bzr, padding=pad)
+    z, r = torch.sigmoid(zr[:, :64]), torch.sigmoid(zr[:, 64:])
+    assert (nchw(zb) - z).abs().max() < 1e-2
+    assert (nchw(rh) - r * nchw(h)).abs().max() < 1e-2
+    qv = torch.tanh(F.conv2d(torch.cat([nchw(rh), nchw(xx)], 1), q16(wq), bq, padding=pad))
+    assert (nchw(hn) - ((1 - nchw(zb)) * nchw(h) + nchw(zb) * qv)).abs().max() < 1e-2
+
+
 # ------------------------------------------------------------------------------------------------------
 # warps: fixtures from the reference + bit-identical integer maps
 # ------------------------------------------------------------------------------------------------------

@@ -14,7 +14,8 @@ import torch                                             # noqa: E402
 from demfi_amd import _lib as L                          # noqa: E402
 from demfi_amd.engine import Plan, _Dst                  # noqa: E402
 
-H, W = 736, 1280
+H, W = int(os.environ.get('PROBE_H', 736)), int(os.environ.get('PROBE_W', 1280))   # PROBE_H=184: tensors small enough to stay in the 256 MB Infinity Cache
+B3 = int(os.environ.get('PROBE_B', 3))
 DEV = 'cuda:0'
 
 
@@ -39,13 +40,28 @@ def main():
     pl = Plan(H, W, dtype, DEV)
     cases = []
     if case in ('c3x3', 'all'):
-        cases.append(('c3x3 64->64 b3', conv_case(pl, 'c3x3', 64, 64, 3, 3, 3)))
+        cases.append(('c3x3 64->64 b3', conv_case(pl, 'c3x3', 64, 64, 3, 3, B3)))
     if case in ('c3x3res', 'all'):
-        cases.append(('c3x3 64->64 b3 +res', conv_case(pl, 'c3x3res', 64, 64, 3, 3, 3, True, act=L.ACT_NONE)))
+        cases.append(('c3x3 64->64 b3 +res', conv_case(pl, 'c3x3res', 64, 64, 3, 3, B3, True, act=L.ACT_NONE)))
     if case in ('c7x7', 'all'):
         cases.append(('c7x7 192->64', conv_case(pl, 'c7x7', 192, 64, 7, 7, act=L.ACT_TANH)))
     if case in ('c1x5', 'all'):
         cases.append(('c1x5 128->128', conv_case(pl, 'c1x5', 128, 128, 1, 5, act=L.ACT_SIGMOID)))
+    if case in ('gru', 'all'):                           # the four SepConvGRU launches: zr 1x5, q 1x5, zr 5x1, q 5x1
+        hb, xb, zb, rh, hn = (pl._fat(H, W, 64) for _ in range(5))
+        hb.copy_(torch.tanh(torch.randn(hb.shape, device=DEV)))
+        xb.copy_(torch.randn(xb.shape, device=DEV))
+        for kh, kw in ((1, 5), (5, 1)):
+            seg = []
+            pl.conv(seg, 'zr%d%d' % (kh, kw), [pl.fsrc(hb, 0), pl.fsrc(xb, 64)],
+                    [_Dst(pl.fview(zb), range(0, 64), L.ACT_SIGMOID),
+                     _Dst(pl.fview(rh), range(64, 128), mode=L.MODE_MUL, res=pl.fview(hb))], H, W,
+                    weight=torch.randn(128, 128, kh, kw) * 0.04, bias=torch.zeros(128))
+            cases.append(('gru zr %dx%d 128->128' % (kh, kw), 2.0 * 128 * 128 * 5 * H * W))
+            pl.conv(seg, 'q%d%d' % (kh, kw), [pl.fsrc(rh, 0), pl.fsrc(xb, 64)],
+                    [_Dst(pl.fview(hn), range(64), mode=L.MODE_GRU, res=pl.fview(hb), aux=pl.fview(zb))], H, W,
+                    weight=torch.randn(64, 128, kh, kw) * 0.04, bias=torch.zeros(64))
+            cases.append(('gru q %dx%d 128->64' % (kh, kw), 2.0 * 64 * 128 * 5 * H * W))
     if case in ('c1x1', 'all'):
         cases.append(('c1x1 1152->96 half', conv_case(pl, 'c1x1', 1152, 96, 1, 1, h=H // 2, w=W // 2, act=L.ACT_NONE)))
     if case in ('c3x3_32', 'all'):
