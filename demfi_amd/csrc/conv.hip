@@ -581,7 +581,7 @@ __global__ __launch_bounds__(P_NT, 1) void conv3x3_c64_persist_kernel(const demf
     const char* const wl = wlds + lane * 16;
     if constexpr (PIPE && NCO == 2) {
         f16x_t acc[2][2];
-        uint4 rr[2][2][2];                                      // residual of subtile s: [s][p][m2], loaded one half-phase early
+        u4_t rr[2][2][2];                                       // residual of subtile s: [s][p][m2], loaded one half-phase early
         int cb[2], cy[2], cx[2];                                // tile coordinates the accumulators of subtile s belong to
         float v[8];                                             // values of the epilogue unit in flight
         // one epilogue unit = (m2, p) of subtile S: 8 consecutive couts of pixel (row p, column lx); 5 chunks of ~6-10
@@ -606,7 +606,12 @@ __global__ __launch_bounds__(P_NT, 1) void conv3x3_c64_persist_kernel(const demf
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { v[j] += b0[j]; v[4 + j] += b1[j]; }
             } else if constexpr (chunk == 2) {
-                if (resp != nullptr) {
+                if constexpr (RES) {
+                    // in flight at most: the 4 loads of the other subtile issued at the start of this half-phase; the "+v"
+                    // operands tie every consumer of rr[S] to this wait
+                    auto& rs = rr[S];
+                    if constexpr (unit == 0)
+                        asm volatile("s_waitcnt vmcnt(4)" : "+v"(rs[0][0]), "+v"(rs[0][1]), "+v"(rs[1][0]), "+v"(rs[1][1])::"memory");
                     const h8_t r = __builtin_bit_cast(h8_t, rr[S][p][m2]);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) v[j] += (float)r[j];
@@ -620,17 +625,22 @@ __global__ __launch_bounds__(P_NT, 1) void conv3x3_c64_persist_kernel(const demf
                     store8<half_t>(dstp + cb[S] * d_sb + oy * d_sy + oxx * d_sx + ch0 + S * 32 + m2 * 16 + hi * 8, v);
             }
         };
+        // Residual loads are issued through inline asm: the compiler then inserts NO vmcnt waits of its own (its in-order
+        // bookkeeping would make an epilogue unit wait for the stores of the units before it); one manual
+        // s_waitcnt vmcnt(4) per half-phase retires them (the 4 loads of the next subtile may stay in flight).
         auto load_res = [&](auto S_, int bimg, int oy0, int ox0) {
             constexpr int S = decltype(S_)::value;
-            if (resp == nullptr) return;
+            if constexpr (!RES) return;
+            auto& rs = rr[S];                                   // (an asm operand alone does not capture 'rr' in a generic lambda)
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
 #pragma unroll
                 for (int m2 = 0; m2 < 2; ++m2) {
-                    const int oy = oy0 + wave * 2 + p, oxx = ox0 + lx;
-                    rr[S][p][m2] = make_uint4(0, 0, 0, 0);
-                    if (oy < H && oxx < W)
-                        rr[S][p][m2] = ld_global16(resp + bimg * r_sb + oy * r_sy + oxx * r_sx + ch0 + S * 32 + m2 * 16 + hi * 8);
+                    const int oy = min(oy0 + wave * 2 + p, H - 1), oxx = min(ox0 + lx, W - 1);
+                    const half_t* g = resp + bimg * r_sb + oy * r_sy + oxx * r_sx + ch0 + S * 32 + m2 * 16 + hi * 8;
+#if defined(__HIP_DEVICE_COMPILE__)
+                    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rs[p][m2]) : "v"(g) : "memory");
+#endif
                 }
             }
         };
@@ -668,7 +678,7 @@ __global__ __launch_bounds__(P_NT, 1) void conv3x3_c64_persist_kernel(const demf
         for (int t = t_first; t < t_end; t += t_step, buf ^= 1) {
             int bimg, oy0, ox0;
             tile_coords(t, bimg, oy0, ox0);
-            __syncthreads();                                    // A: tile t is in LDS
+            asm volatile("s_barrier" ::: "memory");             // A: tile t is in LDS (raw: stores / residual loads stay in flight)
             const char* tb = tbuf + buf * P_TILE_BYTES + (wave * 2) * (P_LW * 128);
             load_res(std::integral_constant<int, 0>{}, bimg, oy0, ox0);
             half_phase(std::integral_constant<int, 0>{}, tb, have_prev);          // + epilogue of subtile 1 of the previous tile

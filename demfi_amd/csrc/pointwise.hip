@@ -243,15 +243,28 @@ __global__ __launch_bounds__(NT) void warp_blend_fat_kernel(demfi_view A, const 
     const int hw = H * W;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int pix0 = (blockIdx.x * (NT / 64) + wave) * 64;        // first pixel of this wave
+    // A workgroup covers a 4-row x 64-pixel tile (wave w = row w), and XCD x = blockIdx & 7 owns a contiguous band of
+    // tiles: the two source rows a pixel gathers from are shared with the rows above / below, so that reuse now hits the
+    // CU's L1 or the XCD's own L2 instead of being fetched once per XCD (linear 64-pixel spans: rows y and y+1 of one
+    // image column sat on different XCDs).
+    const int tiles_x = (W + 63) >> 6;
+    const int ntile = tiles_x * ((H + 3) >> 2);
+    const int per = (ntile + 7) >> 3;
+    const int tile = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if (tile >= ntile) return;
+    const int ty = tile / tiles_x;
+    const int y = ty * 4 + wave;
+    const int x0 = (tile - ty * tiles_x) << 6;
+    if (y >= H) return;                                            // whole wave past the image (no workgroup barrier below)
+    const int pix0 = y * W + x0;                                   // first pixel of this wave
+    const int nvalid = min(64, W - x0);
     WarpRec* wr = recs + wave * 64;
-    if (pix0 >= hw) return;                                        // whole wave past the image (no workgroup barrier below)
     // ---- phase 1: one lane per pixel -------------------------------------------------------------------
     {
         const int pix = pix0 + lane;
         WarpRec r;
-        if (pix < hw) {
-            const int y = pix / W, x = pix - y * W;
+        if (lane < nvalid) {
+            const int x = x0 + lane;
             bool va, vb;
             const SampleMap ma = bwarp_map(x, y, fa[pix], fa[hw + pix], H, W, va);
             const SampleMap mb = bwarp_map(x, y, fb[pix], fb[hw + pix], H, W, vb);
@@ -289,7 +302,7 @@ __global__ __launch_bounds__(NT) void warp_blend_fat_kernel(demfi_view A, const 
     const int psub = lane >> lpp_shift;
     auto issue = [&](int it, uint4 (&ra)[4], uint4 (&rb)[4], WarpRec& r) {
         int pl = it * ppi + psub;
-        if (pix0 + pl >= hw) pl = 0;                              // clamp: results of out-of-range pixels are never stored
+        if (pl >= nvalid) pl = 0;                                 // clamp: results of out-of-range pixels are never stored
         r = wr[pl];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -298,9 +311,9 @@ __global__ __launch_bounds__(NT) void warp_blend_fat_kernel(demfi_view A, const 
         }
     };
     auto finish = [&](int it, const uint4 (&ra)[4], const uint4 (&rb)[4], const WarpRec& r) {
-        const int pix = pix0 + it * ppi + psub;
-        if (pix >= hw) return;
-        const int y = pix / W, x = pix - y * W;
+        const int pl = it * ppi + psub;
+        if (pl >= nvalid) return;
+        const int x = x0 + pl;
         float wa[N], wb[N], o[N];
 #pragma unroll
         for (int j = 0; j < N; ++j) { wa[j] = 0.0f; wb[j] = 0.0f; }
@@ -556,7 +569,8 @@ extern "C" int demfi_warp_blend(const demfi_view* A, const float* fa, const demf
         int f32 = 0;
         const int sh = fat_lpp_shift(A, C, "demfi_warp_blend", &f32);
         if (sh < 0) return sh;
-        const unsigned nblk = (unsigned)((hw + NT - 1) / NT);           // one wave per 64 pixels, 4 waves per workgroup
+        // 4-row x 64-pixel tiles, 8 XCD bands of ceil(ntile / 8) tiles each
+        const unsigned nblk = 8u * (unsigned)((((W + 63) / 64) * ((H + 3) / 4) + 7) / 8);
         if (f32)
             hipLaunchKernelGGL(warp_blend_fat_kernel<float>, dim3(nblk), dim3(NT), 0, st, *A, fa, *B, fb, logit, t,
                                *out, sh, H, W, occ_out, dbg_maps);
