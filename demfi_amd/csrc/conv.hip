@@ -850,6 +850,282 @@ int launch_persist(const demfi_conv* h, const demfi_conv* dev, hipStream_t st)
 
 
 // ======================================================================================================
+// Persistent 3x3 kernel for the NARROW layers (fp16, stride 1): K = 16, 32 or 64 input channels in ONE chunk made of
+// up to two NHWC pieces (+ zero padding), <= 64 output channels -- Mixer conv_delta1/2, conv_blend1/2
+// (DeMFInet.py:800-836) and every other layer of that shape.  These layers are HBM-bound (2-35 GFLOP on 75-180 MB), and
+// the general kernel spent its time on per-tile overhead (one workgroup per tile: weight ring, VGPR-staged input,
+// 9 barriers).  Same machinery as the 64-channel kernel above with the record size as a template parameter:
+//   * REC = 32 / 64 / 128 bytes per pixel record (NKS = 1 / 2 / 4 k-steps); XOR swizzle of the 16-byte slot by record
+//     column, chosen per REC so that the ds_read_b128 lane groups stay conflict-free;
+//   * the DMA wave composes a record from the pieces: per instruction and lane a precomputed (piece, byte offset);
+//   * the smaller the record the deeper the tile ring (2 / 3 / 4 buffers, 1-3 tiles in flight, counted vmcnt): a tile of
+//     these layers is only ~1 us of work, much less than the HBM latency;
+//   * MFMA loop pipelined per k-step (fragments two steps ahead); register epilogue as above.
+// ======================================================================================================
+template <int REC> struct NarrowCfg {
+    static constexpr int NKS = REC / 32;                        // k-steps per tap
+    static constexpr int SL = REC / 16;                         // 16-byte slots per record
+    static constexpr int PPI = 1024 / REC;                      // records per DMA instruction
+    static constexpr int NI = (P_NP + PPI - 1) / PPI;           // DMA instructions per tile: 43 / 22 / 11
+    static constexpr int TILE_BYTES = NI * 1024;
+    static constexpr int NBUF = REC == 128 ? 2 : (REC == 64 ? 3 : 4);
+    static_assert((NBUF - 1) * NI <= 63, "tiles in flight must be countable in vmcnt");
+    static __device__ __forceinline__ int swz(int col) { return REC == 128 ? (col >> 1) & 7 : (REC == 64 ? (col >> 2) & 3 : (col >> 4) & 1); }
+    static constexpr size_t lds_bytes(int nco) { return (size_t)9 * NKS * nco * 1024 + (size_t)NBUF * TILE_BYTES + 1024; }
+};
+
+struct NarrowFrag { uint4 a[2], b0, b1; };
+
+template <int NCO, int REC, bool RES>
+__global__ __launch_bounds__(P_NT, 1) void conv3x3_narrow_persist_kernel(const demfi_conv* __restrict__ d)
+{
+    using Cfg = NarrowCfg<REC>;
+    constexpr int NKS = Cfg::NKS, SL = Cfg::SL, NI = Cfg::NI, NBUF = Cfg::NBUF, TILE_BYTES = Cfg::TILE_BYTES;
+    constexpr int NSTEP = 9 * NKS;
+    constexpr int WBYTES = NSTEP * NCO * 1024;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int H = d->H, W = d->W;
+    const int tiles_x = (W + TW - 1) / TW;
+    const int tiles_y = (H + TH - 1) / TH;
+    const int tiles_img = tiles_x * tiles_y;
+    const int total = tiles_img * d->batch;
+    char* const wlds = smem;
+    char* const tbuf = smem + WBYTES;
+    const int G = gridDim.x;
+    int t_first, t_end, t_step;
+    if ((G & 7) == 0 && total >= G) {
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        const int q = total >> 3, r = total & 7;
+        const int lo = xcd * q + min(xcd, r);
+        t_first = lo + idx;
+        t_end = lo + q + (xcd < r ? 1 : 0);
+        t_step = G >> 3;
+    } else {
+        t_first = blockIdx.x;
+        t_end = total;
+        t_step = G;
+    }
+    if (t_first >= t_end) return;                               // uniform per workgroup
+    const int n_tiles = (t_end - t_first + t_step - 1) / t_step;
+    auto tile_coords = [&](int t, int& bimg, int& oy0, int& ox0) {
+        bimg = t / tiles_img;
+        const int rem = t - bimg * tiles_img;
+        const int ty = rem / tiles_x;
+        oy0 = ty * TH;
+        ox0 = (rem - ty * tiles_x) * TW;
+    };
+
+    if (wave == 4) {
+        // ================= DMA wave ==========================================================================
+        // the (at most two) real pieces of the chunk; everything else of the record is zero padding
+        const demfi_chunk& ch = d->chunks[0];
+        const char* src[2] = {nullptr, nullptr};
+        int64_t psx[2] = {0, 0}, psy[2] = {0, 0}, psb[2] = {0, 0};
+        int pb0[2] = {0, 0}, pb1[2] = {0, 0};                    // byte range of the piece inside the record
+        int nreal = 0;
+        for (int k = 0; k < ch.n_pieces; ++k) {
+            const demfi_piece& pc = d->pieces[ch.first_piece + k];
+            if (pc.v.ptr == nullptr || nreal == 2) continue;
+            src[nreal] = (const char*)pc.v.ptr;
+            psx[nreal] = pc.v.sx * 2; psy[nreal] = pc.v.sy * 2; psb[nreal] = pc.v.sb * 2;
+            pb0[nreal] = pc.lds_ch * 2; pb1[nreal] = (pc.lds_ch + pc.nch) * 2;
+            ++nreal;
+        }
+        const char* const zeros = (const char*)d->zero_page;
+        // instruction i covers records PPI*i ..; lane -> (record PPI*i + lane/SL, physical slot lane%SL)
+        int off[NI], meta[NI];                                    // meta = row | column << 8 | piece << 16 (piece 2 = zeros)
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int px = i * Cfg::PPI + lane / SL;
+            const int ly = px / P_LW;
+            const int lxx = px - ly * P_LW;
+            const int byte = (((lane & (SL - 1)) ^ Cfg::swz(lxx)) << 4);      // logical slot held by this physical slot
+            int sel = 2;
+            if (px < P_NP) {
+                if (byte >= pb0[0] && byte < pb1[0]) sel = 0;
+                else if (byte >= pb0[1] && byte < pb1[1]) sel = 1;
+            }
+            const int pi = sel == 1 ? 1 : 0;
+            off[i] = (int)(ly * psy[pi] + lxx * psx[pi]) + byte - pb0[pi];
+            meta[i] = ly | (lxx << 8) | (sel << 16);
+        }
+        auto issue_tile = [&](int k) {
+            int bimg, oy0, ox0;
+            tile_coords(t_first + k * t_step, bimg, oy0, ox0);
+            const char* base0 = src[0] + (int64_t)bimg * psb[0] + (int64_t)(oy0 - 1) * psy[0] + (int64_t)(ox0 - 1) * psx[0];
+            const char* base1 = src[1] + (int64_t)bimg * psb[1] + (int64_t)(oy0 - 1) * psy[1] + (int64_t)(ox0 - 1) * psx[1];
+            char* dst = tbuf + (k % NBUF) * TILE_BYTES;
+            const bool interior = oy0 >= 1 && oy0 + TH + 1 <= H && ox0 >= 1 && ox0 + TW + 1 <= W;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int sel = meta[i] >> 16;
+                const int iy = oy0 - 1 + (meta[i] & 255), ix = ox0 - 1 + ((meta[i] >> 8) & 255);
+                const bool ok = sel != 2 && (interior || (iy >= 0 && iy < H && ix >= 0 && ix < W));
+                const char* g = ok ? (sel == 1 ? base1 : base0) + off[i] : zeros;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                                 (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+            }
+        };
+        const uint4* wsrc = (const uint4*)d->wpack;
+        for (int i = 0; i < NSTEP * NCO; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + i * 64 + lane),
+                                             (__attribute__((address_space(3))) void*)(wlds + i * 1024), 16, 0, 0);
+        for (int k = 0; k < NBUF - 1 && k < n_tiles; ++k) issue_tile(k);
+        for (int k = 0; k < n_tiles; ++k) {
+            // tiles k+1 .. k+NBUF-2 (those that exist) may stay in flight; loads retire in order
+            const int ahead = min(NBUF - 2, n_tiles - 1 - k);
+            if (ahead >= 2)      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NI <= 63 ? 2 * NI : 0) : "memory");
+            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI <= 63 ? NI : 0) : "memory");
+            else                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                                    // hand tile k to the MFMA waves
+            // ring slot of tile k+NBUF-1 = slot of tile k-1: every MFMA wave finished reading it before this barrier
+            if (k + NBUF - 1 < n_tiles) issue_tile(k + NBUF - 1);
+        }
+        return;
+    }
+
+    // ================= MFMA waves ============================================================================
+    const int hi = lane >> 5;
+    const int lx = lane & 31;
+    const demfi_seg& sg0 = d->segs[d->sub_seg[0]];
+    half_t* const dstp = (half_t*)sg0.dst.ptr;
+    const half_t* const resp = (const half_t*)sg0.res.ptr;
+    const int64_t d_sx = sg0.dst.sx, d_sy = sg0.dst.sy, d_sb = sg0.dst.sb;
+    const int64_t r_sx = sg0.res.sx, r_sy = sg0.res.sy, r_sb = sg0.res.sb;
+    const float act_floor = sg0.act == DEMFI_ACT_RELU ? 0.0f : -__builtin_huge_valf();
+    const int ch0 = d->oct_ch[0];
+    float* const bias_lds = (float*)(tbuf + NBUF * TILE_BYTES);
+    if (tid < NCO * 32) bias_lds[tid] = d->bias[tid];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    int boff[3 * NKS];                                          // [kx*NKS + ks]: record (lx + kx) + swizzled 16-byte slot
+#pragma unroll
+    for (int g = 0; g < 3 * NKS; ++g) {
+        const int col = lx + g / NKS;
+        boff[g] = col * REC + ((((g % NKS) * 2 + hi) ^ Cfg::swz(col)) << 4);
+    }
+    const char* const wl = wlds + lane * 16;
+    int slot = 0;
+    for (int k = 0; k < n_tiles; ++k) {
+        int bimg, oy0, ox0;
+        tile_coords(t_first + k * t_step, bimg, oy0, ox0);
+        u4_t rreg[NCO][2][2];
+        if constexpr (RES) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int oy = min(oy0 + wave * 2 + p, H - 1), oxx = min(ox0 + lx, W - 1);
+                const half_t* rp = resp + bimg * r_sb + oy * r_sy + oxx * r_sx + ch0 + hi * 8;
+#pragma unroll
+                for (int s = 0; s < NCO; ++s) {
+#pragma unroll
+                    for (int m2 = 0; m2 < 2; ++m2) rreg[s][p][m2] = *gcp<u4_t>(rp + s * 32 + m2 * 16);
+                }
+            }
+        }
+        asm volatile("s_barrier" ::: "memory");                 // tile k is in ring slot `slot`
+        f16x_t acc[NCO][2];
+#pragma unroll
+        for (int s = 0; s < NCO; ++s) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { acc[s][0][i] = 0.0f; acc[s][1][i] = 0.0f; }
+        }
+        const char* tb = tbuf + slot * TILE_BYTES + (wave * 2) * (P_LW * REC);
+        slot = slot == NBUF - 1 ? 0 : slot + 1;
+        {
+            auto load_step = [&](NarrowFrag& f, int g) {        // g = tap*NKS + ks
+                const int tap = g / NKS, ks = g % NKS;
+                const int ky = tap / 3, kx = tap % 3;
+#pragma unroll
+                for (int s = 0; s < NCO; ++s) f.a[s] = *(const uint4*)(wl + (g * NCO + s) * 1024);
+                const char* p0 = tb + boff[kx * NKS + ks];
+                f.b0 = *(const uint4*)(p0 + ky * (P_LW * REC));
+                f.b1 = *(const uint4*)(p0 + (ky + 1) * (P_LW * REC));
+            };
+            NarrowFrag f[3];                                    // fragments two k-steps ahead of the MFMAs
+            load_step(f[0], 0);
+            if constexpr (NSTEP > 1) load_step(f[1], 1);
+            static_for<0, NSTEP>([&](auto ST) {
+                constexpr int st = decltype(ST)::value;
+                if constexpr (st + 2 < NSTEP) load_step(f[(st + 2) % 3], st + 2);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s = 0; s < NCO; ++s) {
+                    Mma<half_t>::run(acc[s][0], f[st % 3].a[s], f[st % 3].b0);
+                    Mma<half_t>::run(acc[s][1], f[st % 3].a[s], f[st % 3].b1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        }
+        if constexpr (RES) {
+#pragma unroll
+            for (int s = 0; s < NCO; ++s) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(rreg[s][q >> 1][q & 1]));
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < NCO; ++s) {
+#pragma unroll
+            for (int m2 = 0; m2 < 2; ++m2) {
+                const f4_t b0 = *(const f4_t*)(bias_lds + s * 32 + m2 * 16 + hi * 8);
+                const f4_t b1 = *(const f4_t*)(bias_lds + s * 32 + m2 * 16 + hi * 8 + 4);
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float qa = acc[s][p][(2 * m2) * 4 + j];
+                        float qb = acc[s][p][(2 * m2 + 1) * 4 + j];
+#if defined(__HIP_DEVICE_COMPILE__)
+                        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(qa), "+v"(qb));
+#endif
+                        v[j] = qa;
+                        v[4 + j] = qb;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { v[j] += b0[j]; v[4 + j] += b1[j]; }
+                    if constexpr (RES) {
+                        const h8_t r = __builtin_bit_cast(h8_t, rreg[s][p][m2]);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] += (float)r[j];
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], act_floor);
+                    const int oy = oy0 + wave * 2 + p, oxx = ox0 + lx;
+                    if (oy < H && oxx < W)
+                        store8<half_t>(dstp + bimg * d_sb + oy * d_sy + oxx * d_sx + ch0 + s * 32 + m2 * 16 + hi * 8, v);
+                }
+            }
+        }
+    }
+}
+
+template <int NCO, int REC>
+int launch_narrow(const demfi_conv* h, const demfi_conv* dev, hipStream_t st)
+{
+    const size_t lds = NarrowCfg<REC>::lds_bytes(NCO);
+    static bool attr_done = false;
+    if (!attr_done) {
+        DEMFI_HIP_CHECK(hipFuncSetAttribute((const void*)conv3x3_narrow_persist_kernel<NCO, REC, true>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        DEMFI_HIP_CHECK(hipFuncSetAttribute((const void*)conv3x3_narrow_persist_kernel<NCO, REC, false>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_done = true;
+    }
+    const int total = ((h->W + TW - 1) / TW) * ((h->H + TH - 1) / TH) * h->batch;
+    const int grid = total >= 256 ? 256 : total;
+    if (h->segs[h->sub_seg[0]].res.ptr != nullptr)
+        hipLaunchKernelGGL((conv3x3_narrow_persist_kernel<NCO, REC, true>), dim3(grid), dim3(P_NT), lds, st, dev);
+    else
+        hipLaunchKernelGGL((conv3x3_narrow_persist_kernel<NCO, REC, false>), dim3(grid), dim3(P_NT), lds, st, dev);
+    DEMFI_HIP_CHECK(hipGetLastError());
+    return DEMFI_OK;
+}
+
+
+// ======================================================================================================
 // Persistent kernel for the SepConvGRU convolutions (DeMFInet.py:838-857): fp16, 1x5 or 5x1 filter, input = two
 // NHWC pieces of 64 channels (h | x resp. r*h | x), 64 output channels per workgroup (convq: 64 couts; the fused
 // convz|convr launch: 128 couts = two workgroup "halves", the parity of the work item selects z or r).
@@ -1520,14 +1796,41 @@ int launch_regw(const demfi_conv* h, const demfi_conv* dev, hipStream_t st)
     return DEMFI_OK;
 }
 
+// epilogue of the persistent 3x3 kernels: ONE NHWC fp16 destination holding all NCO*32 channels (optional residual)
+static bool persist_out_eligible(const demfi_conv* h);
+
 bool persist_eligible(const demfi_conv* h)
 {
     if (h->dtype != DEMFI_F16 || h->stride != 1 || h->kh != 3 || h->kw != 3 || h->pad_y != 1 || h->pad_x != 1) return false;
     if (h->n_chunks != 1 || h->n_pieces != 1 || h->chunks[0].nks != 4 || h->rec_bytes != 128) return false;
     const demfi_piece& p = h->pieces[0];
     if (!p.fat || p.nch != 64 || p.up_shift != 0 || !p.v.ptr || p.v.is_f32) return false;
+    return persist_out_eligible(h);
+}
+
+// narrow layers: one chunk of 32 / 64 / 128 bytes built from <= 2 NHWC fp16 pieces + zero padding
+static bool narrow_eligible(const demfi_conv* h)
+{
+    if (h->dtype != DEMFI_F16 || h->stride != 1 || h->kh != 3 || h->kw != 3 || h->pad_y != 1 || h->pad_x != 1) return false;
+    if (h->n_chunks != 1) return false;
+    const demfi_chunk& ch = h->chunks[0];
+    if (ch.nks != 1 && ch.nks != 2 && ch.nks != 4) return false;
+    int nreal = 0;
+    for (int k = 0; k < ch.n_pieces; ++k) {
+        const demfi_piece& p = h->pieces[ch.first_piece + k];
+        if ((p.lds_ch * 2) % 16 || (p.nch * 2) % 16) return false;
+        if (p.v.ptr == nullptr) continue;
+        if (!p.fat || p.up_shift != 0 || p.v.is_f32 || p.v.sc != 1) return false;
+        if (p.v.sy * 2 * 16 >= (int64_t)1 << 31 || p.v.sx * 2 * 64 >= (int64_t)1 << 31) return false;   // 32-bit offsets inside a tile
+        ++nreal;
+    }
+    if (nreal < 1 || nreal > 2) return false;
+    return persist_out_eligible(h);
+}
+
+static bool persist_out_eligible(const demfi_conv* h)
+{
     if (h->nco > 2 || h->cout_pad != 32 * h->nco || !h->zero_page || h->inH != h->H || h->inW != h->W) return false;
-    // epilogue of the persistent kernel: ONE NHWC fp16 destination holding all NCO*32 channels (optional residual)
     const int sg = h->sub_seg[0];
     if (sg < 0) return false;
     for (int sb = 0; sb < h->nco; ++sb)
@@ -1663,6 +1966,19 @@ extern "C" int demfi_conv2d(const demfi_conv* h, const demfi_conv* dev, void* st
             return launch_persist<2>(h, dev, st);
         }
         return launch_persist<1>(h, dev, st);
+    }
+    if (narrow_eligible(h)) {
+#ifdef DEMFI_ABLATION
+        if (!(getenv("DEMFI_NARROW_OFF") && atoi(getenv("DEMFI_NARROW_OFF"))))
+#endif
+        switch (h->chunks[0].nks * 2 + h->nco) {
+        case 1 * 2 + 1: return launch_narrow<1, 32>(h, dev, st);
+        case 1 * 2 + 2: return launch_narrow<2, 32>(h, dev, st);
+        case 2 * 2 + 1: return launch_narrow<1, 64>(h, dev, st);
+        case 2 * 2 + 2: return launch_narrow<2, 64>(h, dev, st);
+        case 4 * 2 + 1: return launch_narrow<1, 128>(h, dev, st);
+        case 4 * 2 + 2: return launch_narrow<2, 128>(h, dev, st);
+        }
     }
 #ifdef DEMFI_ABLATION
 general:

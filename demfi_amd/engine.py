@@ -323,7 +323,14 @@ class Plan:
 class Engine(Plan):
     """Buffers + descriptors + launch list for one frame size.  ``dtype`` is torch.float16 or torch.float32."""
 
-    def __init__(self, state_dict, H, W, dtype=torch.float16, device='cuda:0', max_updates=3, hp=None):
+    # per-t state: buffers written by the per-t segment + its launch lists.  ``n_ctx`` > 1 builds several independent
+    # copies ("contexts") so that different time instants t of one window can run concurrently on different streams
+    # (they only share the read-only trunk outputs); use_ctx(c) binds context c to the attributes below.
+    _T_ATTRS = ('t_dev', 'cfr_acc', 'ft', 'Ft', 'u1', 'u2', 'u3', 'd0', 'd1', 'd2', 'rF', 'delta', 'occ', 'dec_a', 'dec_t',
+                'dec_b', 'sharp1', 'frec', 're1', 'ref_enc', 'de1', 'de2', 'bl1', 'xb', 'zb', 'rh', 'h1', 'fo1', 'stnew',
+                'misc16', 'ref32', 'agg3s', 'agg3d', 'delta8', 'g_a', 'g_t', 'g_b', 'finals', 'seg_t_head', 'seg_iter')
+
+    def __init__(self, state_dict, H, W, dtype=torch.float16, device='cuda:0', max_updates=3, hp=None, n_ctx=1):
         if H % 8 or W % 8:
             raise ValueError('DeMFI-Net needs H, W multiples of 8 (the harness pads to 32): got %dx%d' % (H, W))
         super().__init__(H, W, dtype, device, state_dict)
@@ -332,19 +339,34 @@ class Engine(Plan):
             raise NotImplementedError('the HIP path is built for nf=64, scale_factor=2 (the released configuration)')
         self.N = max_updates
         self.table = layer_table(self.hp)
-        self.seg_trunk, self.seg_t_head, self.seg_iter = [], [], []
-        self._alloc()
-        self._build()
+        self.seg_trunk = []
+        self._alloc_trunk()
+        self._build_trunk()
+        self._ctx = []
+        for _ in range(max(1, n_ctx)):
+            self.seg_t_head, self.seg_iter = [], []
+            self._alloc_t()
+            self._build_t()
+            self._ctx.append({k: getattr(self, k) for k in self._T_ATTRS})
+        self.use_ctx(0)
         self._upload()
+
+    @property
+    def n_ctx(self):
+        return len(self._ctx)
+
+    def use_ctx(self, c):
+        """Bind per-t context c (buffers + launch lists) to this engine's attributes."""
+        self.__dict__.update(self._ctx[c])
+        self.ctx = c
 
     # ------------------------------------------------------------------------------------------------
     # buffers
     # ------------------------------------------------------------------------------------------------
-    def _alloc(self):
+    def _alloc_trunk(self):
         H, W, N = self.H, self.W, self.N
         H2, W2, H4, W4, H8, W8 = H // 2, W // 2, H // 4, W // 4, H // 8, W // 8
         self.x = torch.zeros((3, 4, H, W), dtype=torch.float32, device=self.device)   # module input, batch 1
-        self.t_dev = torch.zeros((1,), dtype=torch.float32, device=self.device)
         # trunk
         self.s2d = self._fat(H2, W2, 48)
         self.f1 = self._fat(H2, W2, 96)
@@ -366,7 +388,12 @@ class Engine(Plan):
         self.gate = self._thin(2)
         self.aF = self._fat(H, W, 64, 2)
         self.overlay = self._thin(3)
-        # per t
+
+    def _alloc_t(self):
+        H, W, N = self.H, self.W, self.N
+        H2, W2, H4, W4, H8, W8 = H // 2, W // 2, H // 4, W // 4, H // 8, W // 8
+        self.t_dev = torch.zeros((1,), dtype=torch.float32, device=self.device)
+        self._keep.append(self.t_dev)
         self.cfr_acc = torch.zeros((6 * H * W,), dtype=torch.int64, device=self.device)
         self._keep.append(self.cfr_acc)
         self.ft = self._thin(4)                       # flow_t0, flow_t1
@@ -431,7 +458,7 @@ class Engine(Plan):
                             range(cin0 + 3 * f, cin0 + 3 * f + 3)))
         return out
 
-    def _build(self):
+    def _build_trunk(self):
         H, W, N = self.H, self.W, self.N
         H2, W2, H4, W4, H8, W8 = H // 2, W // 2, H // 4, W // 4, H // 8, W // 8
         R, T, S = L.ACT_RELU, L.ACT_TANH, L.ACT_SIGMOID
@@ -480,6 +507,13 @@ class Engine(Plan):
                       [D(self.fview(self.wg, b=b), range(64), R)], H, W)
             self.conv(tr, fg + '.w_gen_2', [self.fsrc(self.wg, 0, b=b)], [D(self.tview(self.gate, b), [0], S)], H, W)
             tr.append(('gate', b))
+
+    def _build_t(self):
+        H, W, N = self.H, self.W, self.N
+        H2, W2, H4, W4, H8, W8 = H // 2, W // 2, H // 4, W // 4, H // 8, W // 8
+        R, T, S = L.ACT_RELU, L.ACT_TANH, L.ACT_SIGMOID
+        D = _Dst
+        enc = self.enc
         # ============================ per-t head: CFR, FWB, refinement, D1, Ch_Reducer ======================
         th = self.seg_t_head
         th.append(('cfr',))

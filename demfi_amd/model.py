@@ -57,17 +57,18 @@ class DeMFInet(nn.Module):
         self._weights_version += 1
         return r
 
-    def engine(self, H, W, num_update):
-        """Engine for a frame size (built on first use: weight repack + buffer allocation)."""
+    def engine(self, H, W, num_update, n_ctx=1):
+        """Engine for a frame size (built on first use: weight repack + buffer allocation).  n_ctx: independent per-t
+        buffer sets (WindowRunner runs two time instants concurrently)."""
         from .engine import Engine
         if not torch.cuda.is_available():
             raise RuntimeError('demfi_amd.DeMFInet.forward needs an MI355X: the forward path is HIP-only '
                                '(no CPU fallback)')
         key = (H, W, self.path_dtype)
         eng = self._engines.get(key)
-        if eng is None or eng.N < num_update:
+        if eng is None or eng.N < num_update or eng.n_ctx < n_ctx:
             sd = {k: v.detach() for k, v in self.state_dict().items()}
-            eng = Engine(sd, H, W, self.path_dtype, self.device, max(num_update, 3), self.hp)
+            eng = Engine(sd, H, W, self.path_dtype, self.device, max(num_update, 3), self.hp, n_ctx=n_ctx)
             self._engines[key] = eng
         return eng
 

@@ -18,11 +18,15 @@ class WindowRunner:
         self.h, self.w = height, width
         H = (height + 31) // 32 * 32
         W = (width + 31) // 32 * 32
-        self.engine = model.engine(H, W, n_tst)
+        # two per-t contexts: consecutive time instants run concurrently on two streams (they only share the trunk's
+        # outputs), which fills the launch gaps and the tails of the ~107 kernels of a per-t pass
+        self.n_ctx = 2 if (use_graph and mfi > 2) else 1
+        self.engine = model.engine(H, W, n_tst, n_ctx=self.n_ctx)
         self.n_tst, self.mfi = n_tst, mfi
         self.ts = [float(t) for t in t_schedule(mfi)]
         dev = self.engine.device
         self.stream = torch.cuda.Stream(dev)
+        self.t_streams = [self.stream] + [torch.cuda.Stream(dev) for _ in range(self.n_ctx - 1)]
         self.out = torch.zeros((mfi - 1, 3, height, width), dtype=torch.float32, device=dev)   # St per t
         self.s01 = torch.zeros((2, 3, height, width), dtype=torch.float32, device=dev)          # S0, S1 (first t)
         self.t_all = torch.tensor(self.ts, dtype=torch.float32, device=dev)
@@ -31,8 +35,8 @@ class WindowRunner:
         self._g_trunk = None
         self._g_t = None
 
-    def _capture(self, fn):
-        h = self.stream.cuda_stream
+    def _capture(self, fn, stream=None):
+        h = (stream or self.stream).cuda_stream
         L.check(self.lib.demfi_graph_begin(h), 'graph_begin')
         try:
             fn(h)
@@ -40,6 +44,44 @@ class WindowRunner:
             g = C.c_void_p()
             L.check(self.lib.demfi_graph_end(h, C.byref(g)), 'graph_end')
         return g
+
+    def _prepare_graphs(self, h):
+        e = self.engine
+        if self._g_trunk is not None:
+            return
+        e.run_trunk(h)                              # warm (module load, attributes) before capture
+        for c in range(self.n_ctx):
+            e.use_ctx(c)
+            e.run_t(h, self.n_tst)
+        self.stream.synchronize()
+        self._g_trunk = self._capture(e.run_trunk)
+        self._g_t = []
+        for c in range(self.n_ctx):
+            e.use_ctx(c)
+            self._g_t.append(self._capture(lambda s: e.run_t(s, self.n_tst), self.t_streams[c]))
+        e.use_ctx(0)
+
+    def _per_t(self, emit):
+        """Run the M-1 time instants, alternating over the per-t contexts / streams; emit(k, finals, stream_handle) copies
+        the outputs of instant k out of the context's buffers (on that context's stream)."""
+        e = self.engine
+        for s in self.t_streams[1:]:
+            s.wait_stream(self.stream)              # trunk outputs ready
+        for k in range(self.mfi - 1):
+            c = k % self.n_ctx
+            st = self.t_streams[c]
+            ctx = e._ctx[c]
+            with torch.cuda.stream(st):
+                ctx['t_dev'].copy_(self.t_all[k:k + 1], non_blocking=True)
+                if self.use_graph:
+                    L.check(self.lib.demfi_graph_launch(self._g_t[c], st.cuda_stream), 'graph_launch')
+                else:
+                    e.use_ctx(c)
+                    e.run_t(st.cuda_stream, self.n_tst)
+                emit(k, ctx['finals'][self.n_tst - 1], st.cuda_stream)
+        for s in self.t_streams[1:]:
+            self.stream.wait_stream(s)
+        e.use_ctx(0)
 
     def run_window(self, x):
         """x: [1,3,4,h,w] fp32 on the GPU.  Returns (St [M-1,3,h,w], S0S1 [2,3,h,w]) -- views of reused buffers."""
@@ -56,25 +98,17 @@ class WindowRunner:
             else:
                 e.x.copy_(x[0], non_blocking=True)
             if self.use_graph:
-                if self._g_trunk is None:
-                    e.run_trunk(h)                      # warm (module load, attributes) before capture
-                    e.run_t(h, self.n_tst)
-                    self.stream.synchronize()
-                    self._g_trunk = self._capture(e.run_trunk)
-                    self._g_t = self._capture(lambda s: e.run_t(s, self.n_tst))
+                self._prepare_graphs(h)
                 L.check(self.lib.demfi_graph_launch(self._g_trunk, h), 'graph_launch')
             else:
                 e.run_trunk(h)
-            for k in range(self.mfi - 1):
-                e.t_dev.copy_(self.t_all[k:k + 1], non_blocking=True)
-                if self.use_graph:
-                    L.check(self.lib.demfi_graph_launch(self._g_t, h), 'graph_launch')
-                else:
-                    e.run_t(h, self.n_tst)
-                self.out[k].copy_(e.finals[self.n_tst - 1, 2, :, :self.h, :self.w], non_blocking=True)
+
+            def emit(k, fin, sh):
+                self.out[k].copy_(fin[2, :, :self.h, :self.w], non_blocking=True)
                 if k == 0:
-                    self.s01[0].copy_(e.finals[self.n_tst - 1, 0, :, :self.h, :self.w], non_blocking=True)
-                    self.s01[1].copy_(e.finals[self.n_tst - 1, 1, :, :self.h, :self.w], non_blocking=True)
+                    self.s01[0].copy_(fin[0, :, :self.h, :self.w], non_blocking=True)
+                    self.s01[1].copy_(fin[1, :, :self.h, :self.w], non_blocking=True)
+            self._per_t(emit)
         cur.wait_stream(self.stream)
         return self.out, self.s01
 
@@ -94,34 +128,25 @@ class WindowRunner:
         with torch.cuda.stream(self.stream):
             h = self.stream.cuda_stream
             L.check(self.lib.demfi_u8_to_window(ptrs, self.h, self.w, e.x.data_ptr(), e.H, e.W, h), 'u8_to_window')
-            if self.use_graph and self._g_trunk is None:
-                e.run_trunk(h)
-                e.run_t(h, self.n_tst)
-                self.stream.synchronize()
-                self._g_trunk = self._capture(e.run_trunk)
-                self._g_t = self._capture(lambda s: e.run_t(s, self.n_tst))
             if self.use_graph:
+                self._prepare_graphs(h)
                 L.check(self.lib.demfi_graph_launch(self._g_trunk, h), 'graph_launch')
             else:
                 e.run_trunk(h)
-            fin = e.finals[self.n_tst - 1]
-            for k in range(self.mfi - 1):
-                e.t_dev.copy_(self.t_all[k:k + 1], non_blocking=True)
-                if self.use_graph:
-                    L.check(self.lib.demfi_graph_launch(self._g_t, h), 'graph_launch')
-                else:
-                    e.run_t(h, self.n_tst)
-                L.check(self.lib.demfi_frame_to_u8(fin[2].data_ptr(), self._out_u8[k].data_ptr(), self.h, self.w, e.H, e.W, h), 'to_u8')
+
+            def emit(k, fin, sh):
+                L.check(self.lib.demfi_frame_to_u8(fin[2].data_ptr(), self._out_u8[k].data_ptr(), self.h, self.w, e.H, e.W, sh), 'to_u8')
                 if k == 0:
                     for i in range(2):
                         L.check(self.lib.demfi_frame_to_u8(fin[i].data_ptr(), self._s01_u8[i].data_ptr(), self.h, self.w, e.H,
-                                                           e.W, h), 'to_u8')
+                                                           e.W, sh), 'to_u8')
+            self._per_t(emit)
         cur.wait_stream(self.stream)
         return self._out_u8, self._s01_u8
 
     def __del__(self):
         try:
-            for g in (self._g_trunk, self._g_t):
+            for g in [self._g_trunk] + list(self._g_t or []):
                 if g is not None:
                     self.lib.demfi_graph_destroy(g)
         except Exception:

@@ -160,6 +160,67 @@ def test_conv_multi_piece_routing_upsample_shuffle(dtype):
     assert (nchw(hn) - ((1 - nchw(zb)) * nchw(h) + nchw(zb) * qv)).abs().max() < tol
 
 
+NARROW_CASES = [
+    # pieces (channels of each NHWC input; 'p8' = 8-channel buffer of which 5 are used), cout, res, act
+    ((32,), 32, False, L.ACT_RELU),            # Mixer conv_delta2
+    ((32,), 64, True, L.ACT_NONE),             # conv_blend2 shape, with a residual
+    ((32, 32), 32, False, L.ACT_RELU),         # conv_blend1: two pieces in one 128-byte record
+    (('p8',), 32, False, L.ACT_RELU),          # conv_delta1: 5 of 8 channels, record padded to one k-step
+    ((16,), 64, False, L.ACT_NONE),
+    ((48, 16), 64, True, L.ACT_RELU),
+    ((16, 8), 32, False, L.ACT_NONE),          # 48-byte chunk padded to 64
+]
+
+
+@pytest.mark.parametrize('case', NARROW_CASES)
+@pytest.mark.parametrize('H,W,batch', [(8, 32, 1), (37, 75, 2), (64, 96, 1), (19, 130, 1)])
+def test_narrow_persistent_conv(case, H, W, batch):
+    """3x3 layers with <= 64 input channels (Mixer, DeMFInet.py:800-836) through the narrow persistent kernel:
+    record sizes 32 / 64 / 128 B, two-piece records, zero-padded records, ragged tile edges, batch > 1."""
+    pieces, cout, res, act = case
+    torch.manual_seed(3)
+    pl = Plan(H, W, torch.float16, DEV)
+    srcs, xs, cin = [], [], 0
+    for pc in pieces:
+        if pc == 'p8':
+            b = pl._fat(H, W, 8, batch)
+            b.copy_(torch.randn(b.shape, device=DEV))
+            srcs.append(pl.fsrc_map(b, [cin + i for i in range(5)] + [-1] * 3) if batch == 1 else None)
+            xs.append(b[..., :5])
+            cin += 5
+        else:
+            b = pl._fat(H, W, pc, batch)
+            b.copy_(torch.randn(b.shape, device=DEV))
+            srcs.append(pl.fsrc(b, cin))
+            xs.append(b)
+            cin += pc
+    if any(s is None for s in srcs):
+        pytest.skip('fsrc_map pins one image')
+    out = pl._fat(H, W, cout, batch)
+    r = pl._fat(H, W, cout, batch) if res else None
+    if res:
+        r.copy_(torch.randn(r.shape, device=DEV))
+    wt = torch.randn(cout, cin, 3, 3) * (1.0 / (cin * 9) ** 0.5)
+    bs = torch.randn(cout) * 0.1
+    seg = []
+    pl.conv(seg, 'narrow', srcs, [_Dst(pl.fview(out), range(cout), act, res=pl.fview(r) if res else None)], H, W, batch=batch,
+            weight=wt, bias=bs)
+    pl._upload()
+    for rep in range(2):
+        out.zero_()
+        pl.launch_conv(0, _stream())
+    torch.cuda.synchronize()
+    F = torch.nn.functional
+    nchw = lambda t: t.permute(0, 3, 1, 2).double().cpu()
+    ref = F.conv2d(torch.cat([nchw(x) for x in xs], 1), wt.half().double(), bs.double(), padding=1)
+    if res:
+        ref = ref + nchw(r)
+    if act == L.ACT_RELU:
+        ref = torch.relu(ref)
+    err = (nchw(out) - ref).abs().max().item()
+    assert err < 4e-3 * max(1.0, ref.abs().max().item()), (case, err)
+
+
 @pytest.mark.parametrize('kh,kw', [(1, 5), (5, 1)])
 @pytest.mark.parametrize('H,W,batch', [(8, 32, 1), (37, 75, 2), (64, 96, 1), (100, 45, 1), (33, 8, 3)])
 def test_sep_gru_persistent_kernel(kh, kw, H, W, batch):

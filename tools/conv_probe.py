@@ -62,6 +62,24 @@ def main():
                     [_Dst(pl.fview(hn), range(64), mode=L.MODE_GRU, res=pl.fview(hb), aux=pl.fview(zb))], H, W,
                     weight=torch.randn(64, 128, kh, kw) * 0.04, bias=torch.zeros(64))
             cases.append(('gru q %dx%d 128->64' % (kh, kw), 2.0 * 64 * 128 * 5 * H * W))
+    if case in ('narrow', 'all'):                        # Mixer-shaped 3x3 layers (narrow persistent kernel)
+        for nm, chs, cout in (('n8p->32', ('p8',), 32), ('n32->32', (32,), 32), ('n32->64', (32,), 64), ('n32+32->32', (32, 32), 32)):
+            srcs, cin = [], 0
+            for c in chs:
+                if c == 'p8':
+                    b = pl._fat(H, W, 8)
+                    b.copy_(torch.randn(b.shape, device=DEV))
+                    srcs.append(pl.fsrc_map(b, [0, 1, 2, 3, 4, -1, -1, -1]))
+                    cin += 5
+                else:
+                    b = pl._fat(H, W, c)
+                    b.copy_(torch.randn(b.shape, device=DEV))
+                    srcs.append(pl.fsrc(b, cin))
+                    cin += c
+            o = pl._fat(H, W, cout)
+            pl.conv([], nm, srcs, [_Dst(pl.fview(o), range(cout), L.ACT_RELU)], H, W, weight=torch.randn(cout, cin, 3, 3) * 0.05,
+                    bias=torch.zeros(cout))
+            cases.append((nm, 2.0 * cout * cin * 9 * H * W))
     if case in ('c1x1', 'all'):
         cases.append(('c1x1 1152->96 half', conv_case(pl, 'c1x1', 1152, 96, 1, 1, h=H // 2, w=W // 2, act=L.ACT_NONE)))
     if case in ('c3x3_32', 'all'):
