@@ -142,8 +142,10 @@ def main():
                                      ('conv3x3_c64_persist_kernel<2>' if a.dtype == 'fp16' else 'conv_kernel<float,2>', len(grp)), 'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak,
                            'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
                            # HBM bytes per launch from rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE, gfx950 correction),
-                           # profiles/r01c_pmc_dominant_conv_and_warp.txt; algorithmic = 723.5 MB (in + out once)
-                           'traffic': 738.1e6 if a.dtype == 'fp16' and (eng.H, eng.W) == (736, 1280) else None,
+                           # profiles/r01e_pmc_conv_gru_warp.txt: 738.1 MB for the 5 launches without residual (algorithmic
+                           # 723.5 MB = in + out once) and 1122.0 MB for the 5 with residual (algorithmic 1085.2 MB): mean
+                           'traffic': 930.1e6 if a.dtype == 'fp16' and (eng.H, eng.W) == (736, 1280) else None,
+                           'algorithmic_bytes': 904.4e6 if a.dtype == 'fp16' and (eng.H, eng.W) == (736, 1280) else None,
                            'avg_launch_ms': round(g_ms, 4), 'flop_per_launch': g_fl,
                            'all_convs_TFLOPs': round(tot_conv_fl / (tot_conv_ms * 1e-3) / 1e12, 2),
                            'slowest_conv': '%s %.3f ms' % (dom[2], dom[3])}

@@ -453,7 +453,7 @@ template <int NCO> struct FragSet { uint4 a[2][NCO]; uint4 b[2][2]; };
 
 // PIPE (NCO == 2 only; EXPERIMENT, instantiated only in -DDEMFI_ABLATION builds with DEMFI_PERSIST_VARIANT=6): the two
 // 32-cout subtiles are computed in two half-phases per tile and the register epilogue of one subtile is interleaved,
-// a few instructions at a time, between the MFMAs of the other.  Measured 0.32 ms vs 0.29 ms for the plain version
+// a few instructions at a time, between the MFMAs of the other.  Measured 0.30 ms vs 0.28 ms for the plain version (both with raw barriers; residual loads issued through inline asm with one manual vmcnt wait per half-phase)
 // (3x3 64->64, 736x1280, batch 3): halving the A-fragment reuse (3 ds_reads per 2 MFMAs) costs more than the hidden
 // epilogue gains.
 template <int NCO, int VAR, bool PIPE = false, bool RES = true>   // RES: the segment has a residual input (compile time: keeps the loads free of phis).  VAR: 0 = product; 1 no epilogue, 2 no MFMA phase, 3 no tile DMA, 4 epilogue only (ablation builds)
