@@ -1591,6 +1591,15 @@ __device__ __forceinline__ void sep_mfma_waves(const demfi_conv* __restrict__ d,
                 }
             };
             if constexpr (VAR == 2) return;
+            // the 8 ds_reads of the next tap are interleaved 1:1 with the 8 MFMAs of the current one
+            auto interleave = [&]() {
+#pragma unroll
+                for (int q8 = 0; q8 < 8; ++q8) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            };
             FragSet<NCO> f0, f1;
             load_tap(f0, 0);
             __builtin_amdgcn_sched_barrier(0);
@@ -1599,17 +1608,14 @@ __device__ __forceinline__ void sep_mfma_waves(const demfi_conv* __restrict__ d,
             mma_tap(f0);
             __builtin_amdgcn_sched_barrier(0);
             load_tap(f0, 2);
-            __builtin_amdgcn_sched_barrier(0);
             mma_tap(f1);
-            __builtin_amdgcn_sched_barrier(0);
+            interleave();
             load_tap(f1, 3);
-            __builtin_amdgcn_sched_barrier(0);
             mma_tap(f0);
-            __builtin_amdgcn_sched_barrier(0);
+            interleave();
             load_tap(f0, 4);
-            __builtin_amdgcn_sched_barrier(0);
             mma_tap(f1);
-            __builtin_amdgcn_sched_barrier(0);
+            interleave();
             mma_tap(f0);
             __builtin_amdgcn_sched_barrier(0);
         });
