@@ -102,13 +102,16 @@ def main():
     # synthetic clip: each rank gets its own windows (weak scaling), resident in HBM before the timed region
     nwin = a.steps + a.warmup
     windows = [synthetic_window(a.height, a.width, seed=1000 * rank + i).to(dev) for i in range(min(nwin, 4))]
-    for i in range(a.warmup):
-        runner.run_window(windows[i % len(windows)])
+    # a step = one window (trunk once + 7 time instants x N_tst boosts); the K steps are handed to the scheduler together so
+    # that it can run the trunk of window w+1 under the last time instants of window w (WindowRunner.run_windows)
+    out_buf = torch.empty((a.steps, a.mfi - 1, 3, a.height, a.width), dtype=torch.float32, device=dev)
+    s01_buf = torch.empty((a.steps, 2, 3, a.height, a.width), dtype=torch.float32, device=dev)
+    if a.warmup:
+        runner.run_windows([windows[i % len(windows)] for i in range(a.warmup)])
     torch.cuda.synchronize()
     D.barrier()
     t0 = time.perf_counter()
-    for i in range(a.steps):
-        runner.run_window(windows[(a.warmup + i) % len(windows)])
+    runner.run_windows([windows[(a.warmup + i) % len(windows)] for i in range(a.steps)], out=out_buf, s01=s01_buf)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     dt = D.max_over_ranks(dt, dev)

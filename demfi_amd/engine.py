@@ -330,7 +330,13 @@ class Engine(Plan):
                 'dec_b', 'sharp1', 'frec', 're1', 'ref_enc', 'de1', 'de2', 'bl1', 'xb', 'zb', 'rh', 'h1', 'fo1', 'stnew',
                 'misc16', 'ref32', 'agg3s', 'agg3d', 'delta8', 'g_a', 'g_t', 'g_b', 'finals', 'seg_t_head', 'seg_iter')
 
-    def __init__(self, state_dict, H, W, dtype=torch.float16, device='cuda:0', max_updates=3, hp=None, n_ctx=1):
+    # trunk state: the window input, every buffer the trunk segment writes and its launch list.  ``n_trunk`` > 1 builds
+    # several trunk contexts, each with its own set of per-t contexts, so that the trunk of the next window can run while
+    # the time instants of the current one are still in flight (WindowRunner.run_windows).
+    _TR_ATTRS = ('x', 's2d', 'f1', 'x0', 'grow', 'gffcat', 'g0', 'g1', 'up', 'F01', 'ffo', 'enc_a', 'enc_t', 'enc_b', 'rk',
+                 'smp', 'E', 'wg', 'gate', 'aF', 'overlay', 'enc', 'seg_trunk')
+
+    def __init__(self, state_dict, H, W, dtype=torch.float16, device='cuda:0', max_updates=3, hp=None, n_ctx=1, n_trunk=1):
         if H % 8 or W % 8:
             raise ValueError('DeMFI-Net needs H, W multiples of 8 (the harness pads to 32): got %dx%d' % (H, W))
         super().__init__(H, W, dtype, device, state_dict)
@@ -339,25 +345,40 @@ class Engine(Plan):
             raise NotImplementedError('the HIP path is built for nf=64, scale_factor=2 (the released configuration)')
         self.N = max_updates
         self.table = layer_table(self.hp)
-        self.seg_trunk = []
-        self._alloc_trunk()
-        self._build_trunk()
-        self._ctx = []
-        for _ in range(max(1, n_ctx)):
-            self.seg_t_head, self.seg_iter = [], []
-            self._alloc_t()
-            self._build_t()
-            self._ctx.append({k: getattr(self, k) for k in self._T_ATTRS})
+        self._trunks, self._ctxs = [], []              # _ctxs[k][c]: per-t context c reading trunk context k
+        for _ in range(max(1, n_trunk)):
+            self.seg_trunk = []
+            self._alloc_trunk()
+            self._build_trunk()
+            self._trunks.append({k: getattr(self, k) for k in self._TR_ATTRS})
+            ctxs = []
+            for _ in range(max(1, n_ctx)):
+                self.seg_t_head, self.seg_iter = [], []
+                self._alloc_t()
+                self._build_t()
+                ctxs.append({k: getattr(self, k) for k in self._T_ATTRS})
+            self._ctxs.append(ctxs)
         self.use_ctx(0)
         self._upload()
 
     @property
     def n_ctx(self):
-        return len(self._ctx)
+        return len(self._ctxs[0])
 
-    def use_ctx(self, c):
-        """Bind per-t context c (buffers + launch lists) to this engine's attributes."""
-        self.__dict__.update(self._ctx[c])
+    @property
+    def n_trunk(self):
+        return len(self._trunks)
+
+    @property
+    def _ctx(self):
+        return self._ctxs[self.trunk]
+
+    def use_ctx(self, c, trunk=None):
+        """Bind trunk context ``trunk`` (default: the current one) and its per-t context c to this engine's attributes."""
+        if trunk is not None or not hasattr(self, 'trunk'):
+            self.trunk = trunk or 0
+            self.__dict__.update(self._trunks[self.trunk])
+        self.__dict__.update(self._ctxs[self.trunk][c])
         self.ctx = c
 
     # ------------------------------------------------------------------------------------------------

@@ -57,7 +57,7 @@ class DeMFInet(nn.Module):
         self._weights_version += 1
         return r
 
-    def engine(self, H, W, num_update, n_ctx=1):
+    def engine(self, H, W, num_update, n_ctx=1, n_trunk=1):
         """Engine for a frame size (built on first use: weight repack + buffer allocation).  n_ctx: independent per-t
         buffer sets (WindowRunner runs two time instants concurrently)."""
         from .engine import Engine
@@ -66,9 +66,9 @@ class DeMFInet(nn.Module):
                                '(no CPU fallback)')
         key = (H, W, self.path_dtype)
         eng = self._engines.get(key)
-        if eng is None or eng.N < num_update or eng.n_ctx < n_ctx:
+        if eng is None or eng.N < num_update or eng.n_ctx < n_ctx or eng.n_trunk < n_trunk:
             sd = {k: v.detach() for k, v in self.state_dict().items()}
-            eng = Engine(sd, H, W, self.path_dtype, self.device, max(num_update, 3), self.hp, n_ctx=n_ctx)
+            eng = Engine(sd, H, W, self.path_dtype, self.device, max(num_update, 3), self.hp, n_ctx=n_ctx, n_trunk=n_trunk)
             self._engines[key] = eng
         return eng
 

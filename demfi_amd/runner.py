@@ -1,13 +1,18 @@
-"""Window scheduler: runs x M interpolation of one 4-frame window on one GPU.
+"""Window scheduler: runs x M interpolation of 4-frame windows on one GPU.
 
 Counterpart of the inner loop of test_custom (/root/reference/main.py:1121-1178) without the PNG codec: the
 unpadded window is reflect-padded straight into the engine's input buffer, the t-independent trunk runs once,
-then the per-t segment runs for t = k/M.  The per-t launch sequence (~130 launches) is captured once into a
-hipGraph through the C ABI and replayed (t lives in device memory, so one graph serves every t)."""
+then the per-t segment runs for t = k/M.  Launch sequences are captured once into hipGraphs through the C ABI and
+replayed (t lives in device memory, so one graph serves every t).
+
+Concurrency (all on ONE GPU, results identical to the sequential order):
+  * the time instants of a window only share the trunk's outputs: ``n_ctx`` per-t contexts (buffer set + descriptors +
+    graph) run consecutive t on separate streams, filling the launch gaps and tails of the ~107 kernels of a pass;
+  * ``run_windows`` pipelines windows over ``n_trunk`` = 2 trunk contexts: the trunk of window w+1 runs while the last
+    time instants of window w are in flight."""
 import ctypes as C
 import os
 
-import numpy as np
 import torch
 
 from . import _lib as L
@@ -19,25 +24,28 @@ class WindowRunner:
         self.h, self.w = height, width
         H = (height + 31) // 32 * 32
         W = (width + 31) // 32 * 32
-        # two per-t contexts: consecutive time instants run concurrently on two streams (they only share the trunk's
-        # outputs), which fills the launch gaps and the tails of the ~107 kernels of a per-t pass
-        self.n_ctx = int(os.environ.get("DEMFI_NCTX", 3)) if (use_graph and mfi > 2) else 1
-        self.engine = model.engine(H, W, n_tst, n_ctx=self.n_ctx)
+        self.n_ctx = int(os.environ.get('DEMFI_NCTX', 3)) if (use_graph and mfi > 2) else 1
+        self.n_trunk = int(os.environ.get('DEMFI_NTRUNK', 2)) if use_graph else 1
+        self.engine = model.engine(H, W, n_tst, n_ctx=self.n_ctx, n_trunk=self.n_trunk)
         self.n_tst, self.mfi = n_tst, mfi
         self.ts = [float(t) for t in t_schedule(mfi)]
         dev = self.engine.device
-        self.stream = torch.cuda.Stream(dev)
-        self.t_streams = [self.stream] + [torch.cuda.Stream(dev) for _ in range(self.n_ctx - 1)]
-        self.out = torch.zeros((mfi - 1, 3, height, width), dtype=torch.float32, device=dev)   # St per t
+        self.stream = torch.cuda.Stream(dev)                                   # trunk stream
+        self.t_streams = [torch.cuda.Stream(dev) for _ in range(self.n_ctx)]   # one per per-t context
+        self.out = torch.zeros((mfi - 1, 3, height, width), dtype=torch.float32, device=dev)   # St per t (run_window)
         self.s01 = torch.zeros((2, 3, height, width), dtype=torch.float32, device=dev)          # S0, S1 (first t)
         self.t_all = torch.tensor(self.ts, dtype=torch.float32, device=dev)
         self.lib = L.load()
         self.use_graph = use_graph
         self._g_trunk = None
         self._g_t = None
+        self._next_ctx = 0
+        self._next_trunk = 0
+        self._t_done = [None] * self.n_trunk        # events: the per-t work that last read trunk context k
 
-    def _capture(self, fn, stream=None):
-        h = (stream or self.stream).cuda_stream
+    # ---------------------------------------------------------------------------------------------------------
+    def _capture(self, fn, stream):
+        h = stream.cuda_stream
         L.check(self.lib.demfi_graph_begin(h), 'graph_begin')
         try:
             fn(h)
@@ -46,72 +54,135 @@ class WindowRunner:
             L.check(self.lib.demfi_graph_end(h, C.byref(g)), 'graph_end')
         return g
 
-    def _prepare_graphs(self, h):
+    def _prepare_graphs(self):
         e = self.engine
-        if self._g_trunk is not None:
+        if self._g_trunk is not None or not self.use_graph:
             return
-        e.run_trunk(h)                              # warm (module load, attributes) before capture
-        for c in range(self.n_ctx):
-            e.use_ctx(c)
-            e.run_t(h, self.n_tst)
+        h = self.stream.cuda_stream
+        for k in range(self.n_trunk):                # warm every context (module load, attributes) before capture
+            e.use_ctx(0, trunk=k)
+            e.run_trunk(h)
+            for c in range(self.n_ctx):
+                e.use_ctx(c)
+                e.run_t(h, self.n_tst)
         self.stream.synchronize()
-        self._g_trunk = self._capture(e.run_trunk)
-        self._g_t = []
-        for c in range(self.n_ctx):
-            e.use_ctx(c)
-            self._g_t.append(self._capture(lambda s: e.run_t(s, self.n_tst), self.t_streams[c]))
-        e.use_ctx(0)
+        self._g_trunk, self._g_t = [], []
+        for k in range(self.n_trunk):
+            e.use_ctx(0, trunk=k)
+            self._g_trunk.append(self._capture(e.run_trunk, self.stream))
+            gs = []
+            for c in range(self.n_ctx):
+                e.use_ctx(c)
+                gs.append(self._capture(lambda s: e.run_t(s, self.n_tst), self.t_streams[c]))
+            self._g_t.append(gs)
+        for s in self.t_streams:
+            s.synchronize()
+        e.use_ctx(0, trunk=0)
 
-    def _per_t(self, emit):
-        """Run the M-1 time instants, alternating over the per-t contexts / streams; emit(k, finals, stream_handle) copies
-        the outputs of instant k out of the context's buffers (on that context's stream)."""
+    def _window(self, load, emit):
+        """One window: load(engine, stream_handle) fills the bound trunk context's input on the trunk stream;
+        emit(j, finals, stream_handle) copies the outputs of time instant j out of a per-t context on that context's stream."""
         e = self.engine
-        for s in self.t_streams[1:]:
-            s.wait_stream(self.stream)              # trunk outputs ready
-        for k in range(self.mfi - 1):
-            c = k % self.n_ctx
+        k = self._next_trunk
+        self._next_trunk = (k + 1) % self.n_trunk
+        if self._t_done[k] is not None:              # the time instants that last read trunk context k must be done
+            for ev in self._t_done[k]:
+                self.stream.wait_event(ev)
+        e.use_ctx(0, trunk=k)
+        with torch.cuda.stream(self.stream):
+            h = self.stream.cuda_stream
+            load(e, h)
+            if self.use_graph:
+                L.check(self.lib.demfi_graph_launch(self._g_trunk[k], h), 'graph_launch')
+            else:
+                e.run_trunk(h)
+            ev_trunk = torch.cuda.Event()
+            ev_trunk.record(self.stream)
+        used = set()
+        for j in range(self.mfi - 1):
+            c = self._next_ctx
+            self._next_ctx = (c + 1) % self.n_ctx
             st = self.t_streams[c]
-            ctx = e._ctx[c]
+            ctx = e._ctxs[k][c]
+            if c not in used:
+                st.wait_event(ev_trunk)
+                used.add(c)
             with torch.cuda.stream(st):
-                ctx['t_dev'].copy_(self.t_all[k:k + 1], non_blocking=True)
+                ctx['t_dev'].copy_(self.t_all[j:j + 1], non_blocking=True)
                 if self.use_graph:
-                    L.check(self.lib.demfi_graph_launch(self._g_t[c], st.cuda_stream), 'graph_launch')
+                    L.check(self.lib.demfi_graph_launch(self._g_t[k][c], st.cuda_stream), 'graph_launch')
                 else:
                     e.use_ctx(c)
                     e.run_t(st.cuda_stream, self.n_tst)
-                emit(k, ctx['finals'][self.n_tst - 1], st.cuda_stream)
-        for s in self.t_streams[1:]:
-            self.stream.wait_stream(s)
-        e.use_ctx(0)
+                emit(j, ctx['finals'][self.n_tst - 1], st.cuda_stream)
+        evs = []
+        for c in used:
+            ev = torch.cuda.Event()
+            ev.record(self.t_streams[c])
+            evs.append(ev)
+        self._t_done[k] = evs
 
-    def run_window(self, x):
-        """x: [1,3,4,h,w] fp32 on the GPU.  Returns (St [M-1,3,h,w], S0S1 [2,3,h,w]) -- views of reused buffers."""
-        e = self.engine
+    def _begin(self):
+        cur = torch.cuda.current_stream(self.engine.device)
+        self.stream.wait_stream(cur)                 # inputs produced on the caller's stream
+        for s in self.t_streams:
+            s.wait_stream(cur)                       # output buffers may still be read there
+        self._prepare_graphs()
+        return cur
+
+    def _end(self, cur):
+        cur.wait_stream(self.stream)
+        for s in self.t_streams:
+            cur.wait_stream(s)
+        self.engine.use_ctx(0, trunk=0)
+
+    def _loader(self, x):
         if tuple(x.shape) != (1, 3, 4, self.h, self.w):
-            raise ValueError('run_window expects [1,3,4,%d,%d], got %s' % (self.h, self.w, tuple(x.shape)))
-        x = x.contiguous().float()                  # the pad kernel reads raw [3,4,h,w] memory
-        cur = torch.cuda.current_stream(e.device)
-        self.stream.wait_stream(cur)
-        with torch.cuda.stream(self.stream):
-            h = self.stream.cuda_stream
+            raise ValueError('expected a [1,3,4,%d,%d] window, got %s' % (self.h, self.w, tuple(x.shape)))
+        x = x.contiguous().float()                   # the pad kernel reads raw [3,4,h,w] memory
+
+        def load(e, h):
             if (self.h, self.w) != (e.H, e.W):
                 L.check(self.lib.demfi_reflect_pad(x.data_ptr(), e.x.data_ptr(), 12, self.h, self.w, e.H, e.W, h), 'pad')
             else:
                 e.x.copy_(x[0], non_blocking=True)
-            if self.use_graph:
-                self._prepare_graphs(h)
-                L.check(self.lib.demfi_graph_launch(self._g_trunk, h), 'graph_launch')
-            else:
-                e.run_trunk(h)
+        return load
 
-            def emit(k, fin, sh):
-                self.out[k].copy_(fin[2, :, :self.h, :self.w], non_blocking=True)
-                if k == 0:
-                    self.s01[0].copy_(fin[0, :, :self.h, :self.w], non_blocking=True)
-                    self.s01[1].copy_(fin[1, :, :self.h, :self.w], non_blocking=True)
-            self._per_t(emit)
-        cur.wait_stream(self.stream)
+    # ---------------------------------------------------------------------------------------------------------
+    def run_window(self, x):
+        """x: [1,3,4,h,w] fp32 on the GPU.  Returns (St [M-1,3,h,w], S0S1 [2,3,h,w]) -- views of reused buffers."""
+        load = self._loader(x)
+        cur = self._begin()
+
+        def emit(j, fin, sh):
+            self.out[j].copy_(fin[2, :, :self.h, :self.w], non_blocking=True)
+            if j == 0:
+                self.s01[0].copy_(fin[0, :, :self.h, :self.w], non_blocking=True)
+                self.s01[1].copy_(fin[1, :, :self.h, :self.w], non_blocking=True)
+        self._window(load, emit)
+        self._end(cur)
         return self.out, self.s01
+
+    def run_windows(self, xs, out=None, s01=None):
+        """Pipelined run of several windows (list of [1,3,4,h,w] fp32 GPU tensors, all ready on the current stream).
+        Returns (St [n,M-1,3,h,w], S0S1 [n,2,3,h,w]); pass preallocated ``out`` / ``s01`` to reuse memory."""
+        n = len(xs)
+        dev = self.engine.device
+        if out is None:
+            out = torch.empty((n, self.mfi - 1, 3, self.h, self.w), dtype=torch.float32, device=dev)
+        if s01 is None:
+            s01 = torch.empty((n, 2, 3, self.h, self.w), dtype=torch.float32, device=dev)
+        loads = [self._loader(x) for x in xs]
+        cur = self._begin()
+        for w in range(n):
+            def emit(j, fin, sh, w=w):
+                out[w, j].copy_(fin[2, :, :self.h, :self.w], non_blocking=True)
+                if j == 0:
+                    s01[w, 0].copy_(fin[0, :, :self.h, :self.w], non_blocking=True)
+                    s01[w, 1].copy_(fin[1, :, :self.h, :self.w], non_blocking=True)
+            self._window(loads[w], emit)
+        self._end(cur)
+        return out, s01
 
     def run_window_u8(self, frames_u8):
         """uint8 in / uint8 out: frames_u8 = 4 BGR uint8 [h,w,3] GPU tensors in the order (B0,B1,B-1,B2).  Returns
@@ -124,30 +195,27 @@ class WindowRunner:
         assert len(frames_u8) == 4 and all(f.dtype == torch.uint8 and tuple(f.shape) == (self.h, self.w, 3) and f.is_contiguous()
                                            for f in frames_u8)
         ptrs = (C.c_void_p * 4)(*[f.data_ptr() for f in frames_u8])
-        cur = torch.cuda.current_stream(e.device)
-        self.stream.wait_stream(cur)
-        with torch.cuda.stream(self.stream):
-            h = self.stream.cuda_stream
-            L.check(self.lib.demfi_u8_to_window(ptrs, self.h, self.w, e.x.data_ptr(), e.H, e.W, h), 'u8_to_window')
-            if self.use_graph:
-                self._prepare_graphs(h)
-                L.check(self.lib.demfi_graph_launch(self._g_trunk, h), 'graph_launch')
-            else:
-                e.run_trunk(h)
 
-            def emit(k, fin, sh):
-                L.check(self.lib.demfi_frame_to_u8(fin[2].data_ptr(), self._out_u8[k].data_ptr(), self.h, self.w, e.H, e.W, sh), 'to_u8')
-                if k == 0:
-                    for i in range(2):
-                        L.check(self.lib.demfi_frame_to_u8(fin[i].data_ptr(), self._s01_u8[i].data_ptr(), self.h, self.w, e.H,
-                                                           e.W, sh), 'to_u8')
-            self._per_t(emit)
-        cur.wait_stream(self.stream)
+        def load(eng, h):
+            L.check(self.lib.demfi_u8_to_window(ptrs, self.h, self.w, eng.x.data_ptr(), eng.H, eng.W, h), 'u8_to_window')
+
+        def emit(j, fin, sh):
+            L.check(self.lib.demfi_frame_to_u8(fin[2].data_ptr(), self._out_u8[j].data_ptr(), self.h, self.w, e.H, e.W, sh), 'to_u8')
+            if j == 0:
+                for i in range(2):
+                    L.check(self.lib.demfi_frame_to_u8(fin[i].data_ptr(), self._s01_u8[i].data_ptr(), self.h, self.w, e.H,
+                                                       e.W, sh), 'to_u8')
+        cur = self._begin()
+        self._window(load, emit)
+        self._end(cur)
         return self._out_u8, self._s01_u8
 
     def __del__(self):
         try:
-            for g in [self._g_trunk] + list(self._g_t or []):
+            gs = list(self._g_trunk or [])
+            for row in (self._g_t or []):
+                gs += list(row)
+            for g in gs:
                 if g is not None:
                     self.lib.demfi_graph_destroy(g)
         except Exception:

@@ -152,6 +152,32 @@ def test_window_runner_graph_replay_matches_module(model16):
                 assert torch.equal(s01[0], ref[1][N - 1][0][0]) and torch.equal(s01[1], ref[1][N - 1][1][0])
 
 
+def test_window_runner_pipelined_windows_match_module(model16):
+    """run_windows (trunk of window w+1 under the last time instants of window w, several time instants in flight on
+    separate streams, two trunk contexts x three per-t contexts) returns bit-identical frames to one forward per (window, t)."""
+    from demfi_amd.harness import t_schedule
+    from demfi_amd.runner import WindowRunner
+    h, w, N, M = 40, 72, 2, 8
+    xs = [synthetic_window(h, w, 30 + i).to(DEV) for i in range(5)]
+    runner = WindowRunner(model16, h, w, n_tst=N, mfi=M, use_graph=True)
+    assert runner.n_trunk == 2 and runner.n_ctx == 3
+    for rep in range(2):
+        st, s01 = runner.run_windows(xs)
+        torch.cuda.synchronize()
+        for wi, x in enumerate(xs):
+            for k, tv in enumerate(t_schedule(M)):
+                if rep == 1 and (wi + k) % 3:              # second pass: spot check
+                    continue
+                ref = pad_forward_crop(model16, x, torch.tensor([[float(tv)]], device=DEV), N)
+                assert torch.equal(st[wi, k], ref[1][N - 1][2][0]), (wi, k)
+                if k == 0:
+                    assert torch.equal(s01[wi, 0], ref[1][N - 1][0][0]) and torch.equal(s01[wi, 1], ref[1][N - 1][1][0])
+    # the single-window entry point shares the contexts with the pipelined one
+    st1, _ = runner.run_window(xs[3])
+    torch.cuda.synchronize()
+    assert torch.equal(st1, st[3])
+
+
 def test_full_size_720p_fp16_properties(model16):
     """BASELINE config 2 shape (720p -> 736x1280, N_tst=3): size-independent properties -- finite outputs, run-to-run
     bit-identical results (deterministic splat + fixed MFMA accumulation order, also across the persistent kernel's
