@@ -872,322 +872,6 @@ int launch_persist(const demfi_conv* h, const demfi_conv* dev, hipStream_t st)
 
 
 // ======================================================================================================
-// "Z" variant of the 64 -> 64 channel 3x3 persistent kernel (NCO == 2): the register epilogue of tile n-1 is interleaved,
-// a few instructions at a time, between the MFMAs of tile n.  That needs a second accumulator set (+64 VGPRs), more than the
-// 256 VGPRs a 5-wave workgroup leaves per wave, so this kernel has FOUR waves (512 VGPRs each) and no DMA wave:
-//   * every wave issues its quarter (11 of 44 instructions) of the next tile's LDS-DMA itself, through inline asm -- the
-//     compiler's waitcnt pass never sees a VMEM load, so it inserts no vmcnt waits of its own in front of LDS reads;
-//   * residual loads go through inline asm as well; ONE `s_waitcnt vmcnt(0); s_barrier` per tile retires everything:
-//     at that point the DMA of tile n+1 has had the whole MFMA phase of tile n to land, the residual loads are a phase
-//     old and the stores of tile n-1's epilogue were issued in the first half of the phase;
-//   * LDS: 72 KiB weights + 2 x 44 KiB tiles = exactly 160 KiB, so the bias lives in registers, pre-arranged in the
-//     accumulator layout, and the accumulators START from it (no bias add in the epilogue);
-//   * the residual is added with v_fma_mix_f32 (fp16 operand * 1.0 + fp32 accumulator: same rounding as cvt + add).
-// ======================================================================================================
-constexpr int Z_NI = 44;
-constexpr int Z_TILE_BYTES = Z_NI * 1024;
-constexpr int Z_WBYTES = 9 * 4 * 2 * 1024;
-constexpr int Z_LDS_BYTES = Z_WBYTES + 2 * Z_TILE_BYTES;        // 163,840 B
-static_assert(Z_LDS_BYTES <= 160 * 1024, "Z kernel LDS");
-
-__device__ __forceinline__ void dma16_to_lds_z(const void* gsrc, unsigned lds_dst)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(gsrc), "s"(lds_dst)
-                 : "memory");
-#endif
-}
-
-__device__ __forceinline__ float fma_mix_lo_1(unsigned a, float c)      // (float)a.lo * 1.0 + c
-{
-    float dd = 0.0f;
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(dd) : "v"(a), "v"(c));
-#endif
-    return dd;
-}
-__device__ __forceinline__ float fma_mix_hi_1(unsigned a, float c)      // (float)a.hi * 1.0 + c
-{
-    float dd = 0.0f;
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(dd) : "v"(a), "v"(c));
-#endif
-    return dd;
-}
-
-template <bool RES>
-__global__ __launch_bounds__(NT, 1) void conv3x3_c64_z_kernel(const demfi_conv* __restrict__ d)
-{
-    constexpr int NCO = 2, NKS = 4;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int hi = lane >> 5, lx = lane & 31;
-    const int H = d->H, W = d->W;
-    const int tiles_x = (W + TW - 1) / TW;
-    const int tiles_y = (H + TH - 1) / TH;
-    const int tiles_img = tiles_x * tiles_y;
-    const int total = tiles_img * d->batch;
-    const int G = gridDim.x;
-    int t_first, t_end, t_step;
-    if ((G & 7) == 0 && total >= G) {
-        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-        const int q = total >> 3, r = total & 7;
-        const int lo = xcd * q + min(xcd, r);
-        t_first = lo + idx;
-        t_end = lo + q + (xcd < r ? 1 : 0);
-        t_step = G >> 3;
-    } else {
-        t_first = blockIdx.x;
-        t_end = total;
-        t_step = G;
-    }
-    if (t_first >= t_end) return;
-    const int ntile = (t_end - t_first + t_step - 1) / t_step;
-    auto tile_coords = [&](int t, int& bimg, int& oy0, int& ox0) {
-        bimg = t / tiles_img;
-        const int rem = t - bimg * tiles_img;
-        const int ty = rem / tiles_x;
-        oy0 = ty * TH;
-        ox0 = (rem - ty * tiles_x) * TW;
-    };
-    // ---- descriptor fields, hoisted ------------------------------------------------------------------------------
-    const demfi_piece& pc = d->pieces[0];
-    const char* const src = (const char*)pc.v.ptr;
-    const int64_t sx = pc.v.sx * 2, sy = pc.v.sy * 2, sb = pc.v.sb * 2;
-    const char* const zeros = (const char*)d->zero_page;
-    const demfi_seg& sg0 = d->segs[d->sub_seg[0]];
-    half_t* const dstp = (half_t*)sg0.dst.ptr;
-    const half_t* const resp = (const half_t*)sg0.res.ptr;
-    const int64_t d_sx = sg0.dst.sx, d_sy = sg0.dst.sy, d_sb = sg0.dst.sb;
-    const int64_t r_sx = sg0.res.sx, r_sy = sg0.res.sy, r_sb = sg0.res.sb;
-    const float act_floor = sg0.act == DEMFI_ACT_RELU ? 0.0f : -__builtin_huge_valf();
-    const int ch0 = d->oct_ch[0];
-    // bias in the accumulator layout: element i of subtile s <-> cout s*32 + (i & 3) + 8*(i >> 2) + 4*hi
-    f16x_t bias_acc[NCO];
-#pragma unroll
-    for (int s2 = 0; s2 < NCO; ++s2) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f4_t b = *gcp<f4_t>(d->bias + s2 * 32 + 8 * g + 4 * hi);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) bias_acc[s2][g * 4 + j] = b[j];
-        }
-    }
-    // ---- this wave's share of a tile DMA: instructions i = wave + 4j; lane -> (pixel 8i + lane/8, slot lane%8) ----
-    int off[11], lyx[11];
-#pragma unroll
-    for (int j = 0; j < 11; ++j) {
-        const int i = wave + 4 * j;
-        const int px = i * 8 + (lane >> 3);
-        const int ly = px / P_LW;
-        const int lxx = px - ly * P_LW;
-        const int v = (lane & 7) ^ ((lxx >> 1) & 7);
-        off[j] = (int)(ly * sy + lxx * sx) + v * 16;
-        lyx[j] = px < P_NP ? (ly | (lxx << 8)) : 0xffff;
-    }
-    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-    auto issue_tile = [&](int t, int buf) {
-        int bimg, oy0, ox0;
-        tile_coords(t, bimg, oy0, ox0);
-        const char* base = src + (int64_t)bimg * sb + (int64_t)(oy0 - 1) * sy + (int64_t)(ox0 - 1) * sx;
-        const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + Z_WBYTES + buf * Z_TILE_BYTES + wave * 1024);
-        const bool interior = oy0 >= 1 && oy0 + TH + 1 <= H && ox0 >= 1 && ox0 + TW + 1 <= W;
-#pragma unroll
-        for (int j = 0; j < 11; ++j) {
-            const int iy = oy0 - 1 + (lyx[j] & 255), ix = ox0 - 1 + (lyx[j] >> 8);
-            const bool ok = lyx[j] != 0xffff && (interior || (iy >= 0 && iy < H && ix >= 0 && ix < W));
-            const char* g = ok ? base + off[j] : zeros;
-            dma16_to_lds_z(g, dst + j * 4096);
-        }
-    };
-    int boff[12];
-#pragma unroll
-    for (int g = 0; g < 12; ++g) {
-        const int col = lx + (g >> 2);
-        boff[g] = col * 128 + ((((g & 3) * 2 + hi) ^ ((col >> 1) & 7)) << 4);
-    }
-    // make the compiler retire its own (bias) loads before the first asm DMA: it must not carry pending loads into the loop
-#pragma unroll
-    for (int s2 = 0; s2 < NCO; ++s2) asm volatile("" : "+v"(bias_acc[s2]));
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    {
-        const uint4* wsrc = (const uint4*)d->wpack;
-        for (int j = 0; j < 18; ++j) {
-            const int i = wave + 4 * j;
-            dma16_to_lds_z(wsrc + i * 64 + lane, __builtin_amdgcn_readfirstlane(lds0 + i * 1024));
-        }
-    }
-    issue_tile(t_first, 0);
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");   // weights + tile 0 landed, for every wave
-    const char* const wl = smem + lane * 16;
-    const char* const tbuf = smem + Z_WBYTES;
-
-    f16x_t acc[2][NCO][2];                                      // [tile parity][subtile][row]
-    u4_t rr[2][NCO][2][2];                                      // residual [tile parity][subtile][row][m2]
-    int cb[2], cy[2], cx[2];                                    // tile coordinates per parity
-    float v[8];                                                 // epilogue unit in flight
-    // one epilogue unit u = (s, m2, p) of the tile held in parity Q: 8 consecutive couts of pixel (row p, column lx)
-    auto epi_chunk = [&](auto Q_, auto CH_) {
-        constexpr int Q = decltype(Q_)::value, CH = decltype(CH_)::value;
-        constexpr int unit = CH >> 2, chunk = CH & 3, s2 = unit >> 2, m2 = (unit >> 1) & 1, p = unit & 1;
-        auto& aq = acc[Q];
-        auto& rq = rr[Q];
-        if constexpr (chunk == 0) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float qa = aq[s2][p][(2 * m2) * 4 + j];
-                float qb = aq[s2][p][(2 * m2 + 1) * 4 + j];
-#if defined(__HIP_DEVICE_COMPILE__)
-                asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(qa), "+v"(qb));
-#endif
-                v[j] = qa;
-                v[4 + j] = qb;
-            }
-        } else if constexpr (chunk == 1) {
-            if constexpr (RES) {
-                const u4_t r = rq[s2][p][m2];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    v[2 * q] = fma_mix_lo_1(r[q], v[2 * q]);
-                    v[2 * q + 1] = fma_mix_hi_1(r[q], v[2 * q + 1]);
-                }
-            }
-        } else if constexpr (chunk == 2) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], act_floor);
-        } else {
-            const int oy = cy[Q] + wave * 2 + p, oxx = cx[Q] + lx;
-            if (oy < H && oxx < W)
-                store8<half_t>(dstp + cb[Q] * d_sb + oy * d_sy + oxx * d_sx + ch0 + s2 * 32 + m2 * 16 + hi * 8, v);
-        }
-    };
-    auto phase = [&](auto P_, int n) {
-        constexpr int P = decltype(P_)::value;
-        const int t = t_first + n * t_step;
-        int bimg, oy0, ox0;
-        tile_coords(t, bimg, oy0, ox0);
-        cb[P] = bimg; cy[P] = oy0; cx[P] = ox0;
-        if (n + 1 < ntile) issue_tile(t + t_step, P ^ 1);      // buffer P^1: its readers passed the barrier that ended tile n-1
-        if constexpr (RES) {
-            auto& rp = rr[P];
-#pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                const int oy = min(oy0 + wave * 2 + p, H - 1), oxx = min(ox0 + lx, W - 1);
-                const half_t* g0 = resp + bimg * r_sb + oy * r_sy + oxx * r_sx + ch0 + hi * 8;
-#pragma unroll
-                for (int s2 = 0; s2 < NCO; ++s2) {
-#pragma unroll
-                    for (int m2 = 0; m2 < 2; ++m2) {
-                        const half_t* g = g0 + s2 * 32 + m2 * 16;
-#if defined(__HIP_DEVICE_COMPILE__)
-                        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rp[s2][p][m2]) : "v"(g) : "memory");
-#endif
-                    }
-                }
-            }
-        }
-        auto& ap = acc[P];
-#pragma unroll
-        for (int s2 = 0; s2 < NCO; ++s2) { ap[s2][0] = bias_acc[s2]; ap[s2][1] = bias_acc[s2]; }
-        const char* tb = tbuf + P * Z_TILE_BYTES + (wave * 2) * (P_LW * 128);
-        const bool have_prev = n > 0;
-        auto load_pair = [&](FragSet<NCO>& f, int pair) {
-            const int tap = pair >> 1, ks0 = (pair & 1) * 2;
-            const int ky = tap / 3, kx = tap % 3;
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const int ks = ks0 + k;
-#pragma unroll
-                for (int s2 = 0; s2 < NCO; ++s2) f.a[k][s2] = *(const uint4*)(wl + ((tap * NKS + ks) * NCO + s2) * 1024);
-                const char* p0 = tb + boff[kx * 4 + ks];
-                f.b[k][0] = *(const uint4*)(p0 + ky * (P_LW * 128));
-                f.b[k][1] = *(const uint4*)(p0 + (ky + 1) * (P_LW * 128));
-            }
-        };
-        // 8 MFMAs of a k-step pair with up to four epilogue chunks of the PREVIOUS tile between them
-        auto mma_pair = [&](const FragSet<NCO>& f, auto SLOT0_) {
-            constexpr int SLOT0 = decltype(SLOT0_)::value;      // first epilogue chunk index of this pair (4 per pair)
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                static_for<0, NCO>([&](auto S_) {
-                    constexpr int s2 = decltype(S_)::value;
-                    Mma<half_t>::run(ap[s2][0], f.a[k][s2], f.b[k][0]);
-                    Mma<half_t>::run(ap[s2][1], f.a[k][s2], f.b[k][1]);
-                });
-            }
-        };
-        FragSet<NCO> f0, f1;
-        load_pair(f0, 0);
-        static_for<0, 9>([&](auto I) {
-            constexpr int i = decltype(I)::value;
-            load_pair(f1, 2 * i + 1);
-            __builtin_amdgcn_sched_barrier(0);
-            // pair 2i: MFMAs k = 0 | chunk | k = 1 | chunk ...
-            static_for<0, 4>([&](auto Q4) {
-                constexpr int q4 = decltype(Q4)::value;                 // (k, s)
-                Mma<half_t>::run(ap[q4 & 1][0], f0.a[q4 >> 1][q4 & 1], f0.b[q4 >> 1][0]);
-                Mma<half_t>::run(ap[q4 & 1][1], f0.a[q4 >> 1][q4 & 1], f0.b[q4 >> 1][1]);
-                constexpr int CH = (2 * i) * 4 + q4;
-                if constexpr (CH < 32) { if (have_prev) epi_chunk(std::integral_constant<int, P ^ 1>{}, std::integral_constant<int, CH>{}); }
-                __builtin_amdgcn_sched_barrier(0);
-            });
-            if constexpr (i < 8) load_pair(f0, 2 * i + 2);
-            __builtin_amdgcn_sched_barrier(0);
-            static_for<0, 4>([&](auto Q4) {
-                constexpr int q4 = decltype(Q4)::value;
-                Mma<half_t>::run(ap[q4 & 1][0], f1.a[q4 >> 1][q4 & 1], f1.b[q4 >> 1][0]);
-                Mma<half_t>::run(ap[q4 & 1][1], f1.a[q4 >> 1][q4 & 1], f1.b[q4 >> 1][1]);
-                constexpr int CH = (2 * i + 1) * 4 + q4;
-                if constexpr (CH < 32) { if (have_prev) epi_chunk(std::integral_constant<int, P ^ 1>{}, std::integral_constant<int, CH>{}); }
-                __builtin_amdgcn_sched_barrier(0);
-            });
-        });
-        (void)mma_pair;
-        // end of tile n: the DMA of tile n+1, this tile's residual loads and the previous tile's stores are all retired here
-        if constexpr (RES) {
-            auto& rp = rr[P];
-            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier"
-                         : "+v"(rp[0][0][0]), "+v"(rp[0][0][1]), "+v"(rp[0][1][0]), "+v"(rp[0][1][1]),
-                           "+v"(rp[1][0][0]), "+v"(rp[1][0][1]), "+v"(rp[1][1][0]), "+v"(rp[1][1][1])
-                         :: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-        }
-    };
-    for (int n = 0; n < ntile; n += 2) {
-        phase(std::integral_constant<int, 0>{}, n);
-        if (n + 1 < ntile) phase(std::integral_constant<int, 1>{}, n + 1);
-    }
-    // drain: epilogue of the last tile
-    if ((ntile - 1) & 1) static_for<0, 32>([&](auto CH) { epi_chunk(std::integral_constant<int, 1>{}, CH); });
-    else                 static_for<0, 32>([&](auto CH) { epi_chunk(std::integral_constant<int, 0>{}, CH); });
-}
-
-int launch_z(const demfi_conv* h, const demfi_conv* dev, hipStream_t st)
-{
-    static bool attr_done = false;
-    if (!attr_done) {
-        DEMFI_HIP_CHECK(hipFuncSetAttribute((const void*)conv3x3_c64_z_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        DEMFI_HIP_CHECK(hipFuncSetAttribute((const void*)conv3x3_c64_z_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_done = true;
-    }
-    const int total = ((h->W + TW - 1) / TW) * ((h->H + TH - 1) / TH) * h->batch;
-    const int grid = total >= 256 ? 256 : total;
-    if (h->segs[h->sub_seg[0]].res.ptr != nullptr)
-        hipLaunchKernelGGL(conv3x3_c64_z_kernel<true>, dim3(grid), dim3(NT), (size_t)Z_LDS_BYTES, st, dev);
-    else
-        hipLaunchKernelGGL(conv3x3_c64_z_kernel<false>, dim3(grid), dim3(NT), (size_t)Z_LDS_BYTES, st, dev);
-    DEMFI_HIP_CHECK(hipGetLastError());
-    return DEMFI_OK;
-}
-
-
-// ======================================================================================================
 // Persistent 3x3 kernel for the NARROW layers (fp16, stride 1): K = 16, 32 or 64 input channels in ONE chunk made of
 // up to two NHWC pieces (+ zero padding), <= 64 output channels -- Mixer conv_delta1/2, conv_blend1/2
 // (DeMFInet.py:800-836) and every other layer of that shape.  These layers are HBM-bound (2-35 GFLOP on 75-180 MB), and
@@ -1859,286 +1543,9 @@ static int launch_sep(const demfi_conv* h, const demfi_conv* dev, hipStream_t st
 }
 
 
-// ======================================================================================================
-// EXPERIMENT -- only instantiated in -DDEMFI_ABLATION builds (DEMFI_PERSIST_VARIANT=10), not in the product.
-// Measured on MI355X (3x3 64->64, 736x1280, batch 3): 0.33 ms vs 0.31 ms for the LDS-resident-weight kernel above:
-// with ONE wave per SIMD both are bound by single-wave instruction issue (~9 non-MFMA instructions per MFMA), not
-// by LDS or the matrix pipe (PMC: MFMA busy 32 %, VALU active 27 %, issue-wait 36 %).  Kept as the starting
-// point for an 8-wave (2 waves/SIMD) variant.
-// Register-resident-weight persistent kernel for the 3x3, 64 -> 64 channel fp16 layers (NCO == 2).
-// LDS bandwidth, not the matrix cores, bounded the LDS-resident-weight version (A + B fragments = 576 KiB of LDS
-// reads per tile).  Here:
-//   * wave w owns ONE 32-cout subtile (w & 1) for FOUR output rows (4*(w >> 1) ..): its 36 A fragments (36 KiB per
-//     wave) live in 144 VGPRs for the whole launch -- weights never touch LDS;
-//   * per (kx, k-step) the wave reads 6 input-row fragments from LDS and issues 12 MFMAs (row reuse across ky):
-//     288 KiB of LDS reads per tile instead of 576;
-//   * the freed LDS holds THREE swizzled tile buffers: every wave DMAs its share (11 of 44 instructions) of tile n+2
-//     while tile n is on the matrix cores.  The DMA is issued through inline asm and tracked with a counted
-//     s_waitcnt vmcnt(11): loads retire in order, so "at most 11 VMEM ops outstanding" proves that tile n's loads
-//     (older than the 11 loads of tile n+1) have landed, while this wave's epilogue stores may still be in flight;
-//   * one raw s_barrier per tile; the epilogue transposes through a wave-private LDS area that does not alias
-//     the tiles.
-// ======================================================================================================
-constexpr int R_NI = 44;                                        // DMA instructions per tile (4 waves x 11)
-constexpr int R_TILE_BYTES = R_NI * 1024;
-constexpr int R_NBUF = 3;
-constexpr int R_SLD = 36;                                       // staged floats per pixel (32 couts + 4 pad)
-constexpr int R_STAGE_BYTES = 32 * R_SLD * 4;                   // per wave: one 32-pixel row
-constexpr int R_LDS_BYTES = R_NBUF * R_TILE_BYTES + 4 * R_STAGE_BYTES;
-
-__device__ __forceinline__ void dma16_to_lds(const void* gsrc, unsigned lds_dst)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(gsrc), "s"(lds_dst)
-                 : "memory");
+#ifdef DEMFI_ABLATION
+#include "conv_experiments.inc"        // regw and Z kernels: negative results kept for the next round, not in the product build
 #endif
-}
-
-template <int VAR>   // 0 product; ablations: 1 no epilogue, 2 no MFMA phase, 3 no tile DMA, 4 epilogue only
-__global__ __launch_bounds__(NT, 1) void conv3x3_c64_regw_kernel(const demfi_conv* __restrict__ d)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int hi = lane >> 5;
-    const int lx = lane & 31;
-    const int cs = wave & 1;                                    // cout subtile of this wave
-    const int rg = wave >> 1;                                   // output rows 4*rg .. 4*rg+3
-    const int H = d->H, W = d->W;
-    const int tiles_x = (W + TW - 1) / TW;
-    const int tiles_y = (H + TH - 1) / TH;
-    const int tiles_img = tiles_x * tiles_y;
-    const int total = tiles_img * d->batch;
-
-    const int G = gridDim.x;
-    int t_first, t_end, t_step;
-    if ((G & 7) == 0 && total >= G) {
-        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-        const int q = total >> 3, r = total & 7;
-        const int lo = xcd * q + min(xcd, r);
-        t_first = lo + idx;
-        t_end = lo + q + (xcd < r ? 1 : 0);
-        t_step = G >> 3;
-    } else {
-        t_first = blockIdx.x;
-        t_end = total;
-        t_step = G;
-    }
-    if (t_first >= t_end) return;
-    const int ntile = (t_end - t_first + t_step - 1) / t_step;  // tiles of this workgroup
-
-    auto tile_coords = [&](int t, int& bimg, int& oy0, int& ox0) {
-        bimg = t / tiles_img;
-        const int rem = t - bimg * tiles_img;
-        const int ty = rem / tiles_x;
-        oy0 = ty * TH;
-        ox0 = (rem - ty * tiles_x) * TW;
-    };
-
-    // ---- descriptor fields, hoisted (barriers / asm memory clobbers would force re-fetching them per tile) -------
-    const demfi_piece& pc = d->pieces[0];
-    const char* const src = (const char*)pc.v.ptr;
-    const int64_t sx = pc.v.sx * 2, sy = pc.v.sy * 2, sb = pc.v.sb * 2;
-    const char* const zeros = (const char*)d->zero_page;
-    const demfi_seg& sg0 = d->segs[d->sub_seg[0]];
-    half_t* const dstp = (half_t*)sg0.dst.ptr;
-    const half_t* const resp = (const half_t*)sg0.res.ptr;
-    const int64_t d_sx = sg0.dst.sx, d_sy = sg0.dst.sy, d_sb = sg0.dst.sb;
-    const int64_t r_sx = sg0.res.sx, r_sy = sg0.res.sy, r_sb = sg0.res.sb;
-    const float act_floor = sg0.act == DEMFI_ACT_RELU ? 0.0f : -__builtin_huge_valf();
-    const int ch0 = d->oct_ch[0] + 32 * cs;
-    const int e_px = lane >> 2, e_q = lane & 3;                 // store phase: pixel within a 16-pixel pass, 8-channel group
-    float bias8[8];
-    {
-        const f4_t b0 = *gcp<f4_t>(d->bias + 32 * cs + e_q * 8), b1 = *gcp<f4_t>(d->bias + 32 * cs + e_q * 8 + 4);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { bias8[j] = b0[j]; bias8[4 + j] = b1[j]; }
-    }
-    // ---- resident A fragments: [tap][k-step] of this wave's cout subtile ----------------------------------------
-    u4_t areg[9][4];
-    {
-        const uint4* wsrc = (const uint4*)d->wpack;
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) areg[tap][ks] = *gcp<u4_t>(wsrc + ((tap * 4 + ks) * 2 + cs) * 64 + lane);
-        }
-    }
-    // ---- this wave's share of a tile DMA: instructions i = wave + 4j; lane -> (pixel 8i + lane/8, slot lane%8) ----
-    int off[11], lyx[11];
-#pragma unroll
-    for (int j = 0; j < 11; ++j) {
-        const int i = wave + 4 * j;
-        const int px = i * 8 + (lane >> 3);
-        const int ly = px / P_LW;
-        const int lxx = px - ly * P_LW;
-        const int v = (lane & 7) ^ ((lxx >> 1) & 7);            // swizzle by tile COLUMN: identical for every row
-        off[j] = (int)(ly * sy + lxx * sx) + v * 16;
-        lyx[j] = px < P_NP ? (ly | (lxx << 8)) : 0xffff;
-    }
-    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-    auto issue_tile = [&](int t, int buf) {
-        int bimg, oy0, ox0;
-        tile_coords(t, bimg, oy0, ox0);
-        const char* base = src + (int64_t)bimg * sb + (int64_t)(oy0 - 1) * sy + (int64_t)(ox0 - 1) * sx;
-        const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + buf * R_TILE_BYTES + wave * 1024);
-        const bool interior = oy0 >= 1 && oy0 + TH + 1 <= H && ox0 >= 1 && ox0 + TW + 1 <= W;
-#pragma unroll
-        for (int j = 0; j < 11; ++j) {
-            const int iy = oy0 - 1 + (lyx[j] & 255), ix = ox0 - 1 + (lyx[j] >> 8);
-            const bool ok = lyx[j] != 0xffff && (interior || (iy >= 0 && iy < H && ix >= 0 && ix < W));
-            const char* g = ok ? base + off[j] : zeros;
-            dma16_to_lds(g, dst + j * 4096);
-        }
-    };
-#if defined(__HIP_DEVICE_COMPILE__)
-    // Make the COMPILER retire the A-fragment / bias loads here: its waitcnt pass cannot see an asm wait and would
-    // otherwise carry "36 loads pending" into the tile loop and emit counted vmcnt waits in front of every first
-    // use -- waits that the hardware then applies to the (compiler-invisible) tile DMAs and stalls the MFMA phase.
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(areg[tap][ks]));
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(bias8[j]));
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-    issue_tile(t_first, 0);
-    if (ntile > 1) issue_tile(t_first + t_step, 1);
-
-    float* const stg = (float*)(smem + R_NBUF * R_TILE_BYTES + wave * R_STAGE_BYTES);
-    int boff[12];                                               // [kx*4 + ks]: (column lx+kx) record + swizzled 16-byte slot
-#pragma unroll
-    for (int g = 0; g < 12; ++g) {
-        const int col = lx + (g >> 2);
-        boff[g] = col * 128 + ((((g & 3) * 2 + hi) ^ ((col >> 1) & 7)) << 4);
-    }
-
-    for (int n = 0; n < ntile; ++n) {
-        const int t = t_first + n * t_step;
-        const int buf = n % R_NBUF;
-        // tile n has landed once <= 11 of this wave's VMEM ops are outstanding (the 11 younger loads of tile n+1)
-#if defined(__HIP_DEVICE_COMPILE__)
-        if (n + 1 < ntile) asm volatile("s_waitcnt vmcnt(11)\n\ts_barrier" ::: "memory");
-        else               asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-#endif
-        if (VAR != 3 && VAR != 4 && n + 2 < ntile) issue_tile(t + 2 * t_step, (n + 2) % R_NBUF);   // its buffer was last read for tile n-1
-        int bimg, oy0, ox0;
-        tile_coords(t, bimg, oy0, ox0);
-        f16x_t acc[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[r][i] = 0.0f;
-        }
-        const char* tb = smem + buf * R_TILE_BYTES + (rg * 4) * (P_LW * 128);
-        // group g = kx*4 + ks: 6 input-row fragments -> 12 MFMAs; fragments of group g+1 are in flight meanwhile.
-        // boff[g] is this lane's swizzled byte offset inside a tile row (12 loop-invariant VGPRs); the row index is
-        // an immediate of the ds_read.
-        auto load_rows = [&](uint4 (&R)[6], int g) {
-            const char* p0 = tb + boff[g];
-#pragma unroll
-            for (int j = 0; j < 6; ++j) R[j] = *(const uint4*)(p0 + j * (P_LW * 128));
-        };
-        auto mma_rows = [&](const uint4 (&R)[6], int g) {
-            const int kx = g >> 2, ks = g & 3;
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) Mma<half_t>::run(acc[r], __builtin_bit_cast(uint4, areg[ky * 3 + kx][ks]), R[r + ky]);
-            }
-        };
-        uint4 R0[6], R1[6];
-        if (VAR != 2 && VAR != 4) {
-        load_rows(R0, 0);
-        static_for<0, 6>([&](auto I) {
-            constexpr int i = decltype(I)::value;
-            load_rows(R1, 2 * i + 1);
-            __builtin_amdgcn_sched_barrier(0);
-            mma_rows(R0, 2 * i);
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (i < 5) load_rows(R0, 2 * i + 2);
-            __builtin_amdgcn_sched_barrier(0);
-            mma_rows(R1, 2 * i + 1);
-            __builtin_amdgcn_sched_barrier(0);
-        });
-        }
-        if (VAR == 1) {
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) asm volatile("" ::"v"(acc[r]));
-#endif
-            continue;
-        }
-        // residual loads: issued here (not before the MFMA phase): any compiler-visible load whose result is touched
-        // earlier makes the compiler wait vmcnt(0), which the hardware applies to the just-issued tile DMA as well
-        uint4 rreg[4][2];
-        if (resp != nullptr) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-#pragma unroll
-                for (int ps = 0; ps < 2; ++ps) {
-                    const int oy = oy0 + rg * 4 + r, oxx = ox0 + ps * 16 + e_px;
-                    rreg[r][ps] = make_uint4(0, 0, 0, 0);
-                    if (oy < H && oxx < W) rreg[r][ps] = ld_global16(resp + bimg * r_sb + oy * r_sy + oxx * r_sx + ch0 + e_q * 8);
-                }
-            }
-        }
-        // ---- epilogue: one output row at a time through the wave-private staging area ---------------------------
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                f4_t v;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = acc[r][g * 4 + j];
-                *(f4_t*)(stg + lx * R_SLD + g * 8 + 4 * hi) = v;
-            }
-            __builtin_amdgcn_wave_barrier();
-            const int oy = oy0 + rg * 4 + r;
-#pragma unroll
-            for (int ps = 0; ps < 2; ++ps) {
-                const int pxl = ps * 16 + e_px;
-                const int oxx = ox0 + pxl;
-                const f4_t v0 = *(const f4_t*)(stg + pxl * R_SLD + e_q * 8);
-                const f4_t v1 = *(const f4_t*)(stg + pxl * R_SLD + e_q * 8 + 4);
-                float v[8];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { v[j] = v0[j] + bias8[j]; v[4 + j] = v1[j] + bias8[4 + j]; }
-                if (resp != nullptr) {
-                    const h8_t rr = __builtin_bit_cast(h8_t, rreg[r][ps]);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] += (float)rr[j];
-                }
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], act_floor);
-                if (oy < H && oxx < W) store8<half_t>(dstp + bimg * d_sb + oy * d_sy + oxx * d_sx + ch0 + e_q * 8, v);
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-    }
-}
-
-template <int VAR = 0>
-int launch_regw(const demfi_conv* h, const demfi_conv* dev, hipStream_t st)
-{
-    static bool attr_done = false;
-    if (!attr_done) {
-        DEMFI_HIP_CHECK(hipFuncSetAttribute((const void*)conv3x3_c64_regw_kernel<VAR>,
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_done = true;
-    }
-    const int total = ((h->W + TW - 1) / TW) * ((h->H + TH - 1) / TH) * h->batch;
-    const int grid = total >= 256 ? 256 : total;
-    hipLaunchKernelGGL(conv3x3_c64_regw_kernel<VAR>, dim3(grid), dim3(NT), R_LDS_BYTES, st, dev);
-    DEMFI_HIP_CHECK(hipGetLastError());
-    return DEMFI_OK;
-}
 
 // epilogue of the persistent 3x3 kernels: ONE NHWC fp16 destination holding all NCO*32 channels (optional residual)
 static bool persist_out_eligible(const demfi_conv* h);
@@ -2300,9 +1707,9 @@ extern "C" int demfi_conv2d(const demfi_conv* h, const demfi_conv* dev, void* st
         if (h->nco == 2 && var == 9) return launch_persist<2, 9>(h, dev, st);
 #endif
         if (h->nco == 2) {
+#ifdef DEMFI_ABLATION
             static const int zsel = getenv("DEMFI_CONV_Z") ? atoi(getenv("DEMFI_CONV_Z")) : 0;
             if (zsel) return launch_z(h, dev, st);
-#ifdef DEMFI_ABLATION
             if (var == 5) return launch_persist<2>(h, dev, st);
             if (var == 11) return launch_regw<1>(h, dev, st);
             if (var == 12) return launch_regw<2>(h, dev, st);
