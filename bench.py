@@ -120,7 +120,9 @@ def main():
     eng = runner.engine
     if rank == 0:
         out = {
-            'metric': 'interpolated frames/sec @720p x8 MFI (N_tst=3)', 'value': round(frames / dt, 3), 'unit': 'frames/s',
+            # BASELINE.json's metric on its configuration; other --height/--mfi/--n-tst values label themselves
+            'metric': 'interpolated frames/sec @%dp x%d MFI (N_tst=%d)' % (a.height, a.mfi, a.n_tst),
+            'value': round(frames / dt, 3), 'unit': 'frames/s',
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(1e3 * dt / a.steps, 2),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f16' if a.dtype == 'fp16' else 'f32',
             'data': 'synthetic',

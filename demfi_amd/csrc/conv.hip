@@ -898,9 +898,13 @@ template <int REC> struct NarrowCfg {
 
 struct NarrowFrag { uint4 a[2], b0, b1; };
 
-template <int NCO, int REC, bool RES>
+// EPI: 0 = one NHWC fp16 destination, 1 = the same + residual, 2 = THIN: planar fp32 destinations / residuals routed per
+// octet (Dec_last2, Dec_last2_2, flow_occ.conv2, w_gen_2: <= 32 packed couts, NCO == 1)
+template <int NCO, int REC, int EPI>
 __global__ __launch_bounds__(P_NT, 1) void conv3x3_narrow_persist_kernel(const demfi_conv* __restrict__ d)
 {
+    constexpr bool RES = EPI == 1, THIN = EPI == 2;
+    static_assert(!THIN || NCO == 1, "thin epilogue: one 32-cout subtile");
     using Cfg = NarrowCfg<REC>;
     constexpr int NKS = Cfg::NKS, SL = Cfg::SL, NI = Cfg::NI, NBUF = Cfg::NBUF, TILE_BYTES = Cfg::TILE_BYTES;
     constexpr int NSTEP = 9 * NKS;
@@ -1012,7 +1016,7 @@ __global__ __launch_bounds__(P_NT, 1) void conv3x3_narrow_persist_kernel(const d
     // ================= MFMA waves ============================================================================
     const int hi = lane >> 5;
     const int lx = lane & 31;
-    const demfi_seg& sg0 = d->segs[d->sub_seg[0]];
+    const demfi_seg& sg0 = d->segs[THIN ? 0 : d->sub_seg[0]];
     half_t* const dstp = (half_t*)sg0.dst.ptr;
     const half_t* const resp = (const half_t*)sg0.res.ptr;
     const int64_t d_sx = sg0.dst.sx, d_sy = sg0.dst.sy, d_sb = sg0.dst.sb;
@@ -1029,11 +1033,48 @@ __global__ __launch_bounds__(P_NT, 1) void conv3x3_narrow_persist_kernel(const d
         boff[g] = col * REC + ((((g % NKS) * 2 + hi) ^ Cfg::swz(col)) << 4);
     }
     const char* const wl = wlds + lane * 16;
+    // ---- THIN: per octet g (= accumulator quad g) the planar destination / residual of this lane's 4 channels -------
+    // packed cout of accumulator element (g, j) of this lane: 8g + 4hi + j; valid when 4hi + j < oct_n[g]
+    float* t_dst[4];
+    const float* t_res[4];
+    int t_on[4], t_act[4], t_nq[4];
+    int64_t t_dsb[4], t_rsb[4];
+    const int64_t t_sc = (int64_t)H * W;                        // channel stride of every planar view (checked by the host)
+    if constexpr (THIN) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            t_on[g] = d->oct_n[g];
+            const demfi_seg& sg = d->segs[d->oct_seg[g]];
+            t_act[g] = sg.act;
+            t_nq[g] = min(max(t_on[g] - 4 * hi, 0), 4);
+            const int c0 = d->oct_ch[g] + (t_nq[g] > 0 ? 4 * hi : 0);       // lanes without a valid channel shadow channel 0 (never stored)
+            t_dst[g] = (float*)sg.dst.ptr + c0 * t_sc;
+            t_res[g] = sg.res.ptr ? (const float*)sg.res.ptr + c0 * t_sc : nullptr;
+            t_dsb[g] = sg.dst.sb;
+            t_rsb[g] = sg.res.sb;
+        }
+    }
     int slot = 0;
     for (int k = 0; k < n_tiles; ++k) {
         int bimg, oy0, ox0;
         tile_coords(t_first + k * t_step, bimg, oy0, ox0);
         u4_t rreg[NCO][2][2];
+        float tr[4][2][4];                                      // THIN: residual [octet][row][j], prefetched like rreg
+        if constexpr (THIN) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (t_on[g] > 0 && t_res[g] != nullptr) {       // wave-uniform
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) {
+                        const int oy = min(oy0 + wave * 2 + p, H - 1), oxx = min(ox0 + lx, W - 1);
+                        const float* rp = t_res[g] + bimg * t_rsb[g] + (int64_t)oy * W + oxx;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)             // invalid j of this lane: re-read its first channel (value unused)
+                            tr[g][p][j] = *gcp<float>(rp + (j < t_nq[g] ? j : 0) * t_sc);
+                    }
+                }
+            }
+        }
         if constexpr (RES) {
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
@@ -1080,6 +1121,32 @@ __global__ __launch_bounds__(P_NT, 1) void conv3x3_narrow_persist_kernel(const d
                 __builtin_amdgcn_sched_barrier(0);
             });
         }
+        if constexpr (THIN) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (t_on[g] == 0) continue;                     // wave-uniform
+                const f4_t bq = *(const f4_t*)(bias_lds + g * 8 + 4 * hi);
+                const bool hasres = t_res[g] != nullptr;
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    float v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        v[j] = acc[0][p][g * 4 + j] + bq[j];
+                        if (hasres) v[j] = v[j] + tr[g][p][j];
+                    }
+                    apply_act_n<4>(v, t_act[g]);
+                    const int oy = oy0 + wave * 2 + p, oxx = ox0 + lx;
+                    if (oy < H && oxx < W) {
+                        float* dp = t_dst[g] + bimg * t_dsb[g] + (int64_t)oy * W + oxx;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (j < t_nq[g]) *gp<float>(dp + j * t_sc) = v[j];
+                    }
+                }
+            }
+            continue;
+        }
         if constexpr (RES) {
 #pragma unroll
             for (int s = 0; s < NCO; ++s) {
@@ -1125,23 +1192,31 @@ __global__ __launch_bounds__(P_NT, 1) void conv3x3_narrow_persist_kernel(const d
 }
 
 template <int NCO, int REC>
-int launch_narrow(const demfi_conv* h, const demfi_conv* dev, hipStream_t st)
+int launch_narrow(const demfi_conv* h, const demfi_conv* dev, hipStream_t st, bool thin)
 {
     const size_t lds = NarrowCfg<REC>::lds_bytes(NCO);
     static bool attr_done = false;
     if (!attr_done) {
-        DEMFI_HIP_CHECK(hipFuncSetAttribute((const void*)conv3x3_narrow_persist_kernel<NCO, REC, true>,
+        DEMFI_HIP_CHECK(hipFuncSetAttribute((const void*)conv3x3_narrow_persist_kernel<NCO, REC, 1>,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        DEMFI_HIP_CHECK(hipFuncSetAttribute((const void*)conv3x3_narrow_persist_kernel<NCO, REC, false>,
+        DEMFI_HIP_CHECK(hipFuncSetAttribute((const void*)conv3x3_narrow_persist_kernel<NCO, REC, 0>,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        if constexpr (NCO == 1)
+            DEMFI_HIP_CHECK(hipFuncSetAttribute((const void*)conv3x3_narrow_persist_kernel<1, REC, 2>,
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done = true;
     }
     const int total = ((h->W + TW - 1) / TW) * ((h->H + TH - 1) / TH) * h->batch;
     const int grid = total >= 256 ? 256 : total;
-    if (h->segs[h->sub_seg[0]].res.ptr != nullptr)
-        hipLaunchKernelGGL((conv3x3_narrow_persist_kernel<NCO, REC, true>), dim3(grid), dim3(P_NT), lds, st, dev);
+    if (thin) {
+        if constexpr (NCO == 1)
+            hipLaunchKernelGGL((conv3x3_narrow_persist_kernel<1, REC, 2>), dim3(grid), dim3(P_NT), lds, st, dev);
+        else
+            return demfi_set_error(DEMFI_ERR_ARG, "demfi_conv2d: thin epilogue needs nco == 1");
+    } else if (h->segs[h->sub_seg[0]].res.ptr != nullptr)
+        hipLaunchKernelGGL((conv3x3_narrow_persist_kernel<NCO, REC, 1>), dim3(grid), dim3(P_NT), lds, st, dev);
     else
-        hipLaunchKernelGGL((conv3x3_narrow_persist_kernel<NCO, REC, false>), dim3(grid), dim3(P_NT), lds, st, dev);
+        hipLaunchKernelGGL((conv3x3_narrow_persist_kernel<NCO, REC, 0>), dim3(grid), dim3(P_NT), lds, st, dev);
     DEMFI_HIP_CHECK(hipGetLastError());
     return DEMFI_OK;
 }
@@ -1559,6 +1634,24 @@ bool persist_eligible(const demfi_conv* h)
     return persist_out_eligible(h);
 }
 
+// THIN epilogue of the narrow kernel: <= 32 packed couts, every octet routed to a planar fp32 [C,H,W] destination
+// (optional planar fp32 residual), any activation
+static bool thin_out_eligible(const demfi_conv* h)
+{
+    if (h->nco != 1 || h->cout_pad != 32 || !h->zero_page || h->inH != h->H || h->inW != h->W || h->sub_seg[0] >= 0) return false;
+    const int64_t hw = (int64_t)h->H * h->W;
+    bool any = false;
+    for (int g = 0; g < 4; ++g) {
+        if (h->oct_n[g] == 0) continue;
+        any = true;
+        const demfi_seg& sg = h->segs[h->oct_seg[g]];
+        if (sg.mode != DEMFI_MODE_STORE || sg.scale != 1 || sg.dy != 0 || sg.dx != 0) return false;
+        if (!sg.dst.ptr || !sg.dst.is_f32 || sg.dst.sx != 1 || sg.dst.sy != h->W || sg.dst.sc != hw) return false;
+        if (sg.res.ptr && (!sg.res.is_f32 || sg.res.sx != 1 || sg.res.sy != h->W || sg.res.sc != hw)) return false;
+    }
+    return any;
+}
+
 // narrow layers: one chunk of 32 / 64 / 128 bytes built from <= 2 NHWC fp16 pieces + zero padding
 static bool narrow_eligible(const demfi_conv* h)
 {
@@ -1576,7 +1669,7 @@ static bool narrow_eligible(const demfi_conv* h)
         ++nreal;
     }
     if (nreal < 1 || nreal > 2) return false;
-    return persist_out_eligible(h);
+    return persist_out_eligible(h) || thin_out_eligible(h);
 }
 
 static bool persist_out_eligible(const demfi_conv* h)
@@ -1726,13 +1819,16 @@ extern "C" int demfi_conv2d(const demfi_conv* h, const demfi_conv* dev, void* st
 #ifdef DEMFI_ABLATION
         if (!(getenv("DEMFI_NARROW_OFF") && atoi(getenv("DEMFI_NARROW_OFF"))))
 #endif
-        switch (h->chunks[0].nks * 2 + h->nco) {
-        case 1 * 2 + 1: return launch_narrow<1, 32>(h, dev, st);
-        case 1 * 2 + 2: return launch_narrow<2, 32>(h, dev, st);
-        case 2 * 2 + 1: return launch_narrow<1, 64>(h, dev, st);
-        case 2 * 2 + 2: return launch_narrow<2, 64>(h, dev, st);
-        case 4 * 2 + 1: return launch_narrow<1, 128>(h, dev, st);
-        case 4 * 2 + 2: return launch_narrow<2, 128>(h, dev, st);
+        {
+            const bool thin = !persist_out_eligible(h);
+            switch (h->chunks[0].nks * 2 + h->nco) {
+            case 1 * 2 + 1: return launch_narrow<1, 32>(h, dev, st, thin);
+            case 1 * 2 + 2: return launch_narrow<2, 32>(h, dev, st, thin);
+            case 2 * 2 + 1: return launch_narrow<1, 64>(h, dev, st, thin);
+            case 2 * 2 + 2: return launch_narrow<2, 64>(h, dev, st, thin);
+            case 4 * 2 + 1: return launch_narrow<1, 128>(h, dev, st, thin);
+            case 4 * 2 + 2: return launch_narrow<2, 128>(h, dev, st, thin);
+            }
         }
     }
 #ifdef DEMFI_ABLATION

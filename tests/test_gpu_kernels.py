@@ -221,6 +221,60 @@ def test_narrow_persistent_conv(case, H, W, batch):
     assert err < 4e-3 * max(1.0, ref.abs().max().item()), (case, err)
 
 
+THIN_CASES = [
+    # cin, list of (n couts, residual?) per destination tensor, act, batch
+    (64, [(3, True), (3, True), (3, True)], L.ACT_NONE, 1),      # Dec_last2_2: three frames, each + its own residual
+    (64, [(3, False)], L.ACT_NONE, 3),                           # Dec_last2: batch 3 with a batch stride on the planes
+    (32, [(5, True)], L.ACT_NONE, 1),                            # flow_occ.conv2: 5 channels straddle the two lane halves
+    (64, [(1, False)], L.ACT_SIGMOID, 1),                        # w_gen_2
+    (16, [(8, True), (2, False)], L.ACT_TANH, 1),
+]
+
+
+@pytest.mark.parametrize('case', THIN_CASES)
+@pytest.mark.parametrize('H,W', [(8, 32), (37, 75), (64, 96)])
+def test_narrow_persistent_conv_thin_outputs(case, H, W):
+    """3x3 layers writing planar fp32 outputs (frames, flow/occlusion deltas, gates) through the THIN epilogue of the narrow
+    persistent kernel: per-octet routing to several tensors, planar residuals, batch stride, ragged edges."""
+    cin, dsts, act, batch = case
+    torch.manual_seed(17)
+    pl = Plan(H, W, torch.float16, DEV)
+    x = pl._fat(H, W, cin, batch)
+    x.copy_(torch.randn(x.shape, device=DEV))
+    outs, ress, D, c0 = [], [], [], 0
+    for n, has_res in dsts:
+        o = torch.zeros((batch * n, H, W), dtype=torch.float32, device=DEV)
+        r = torch.randn((batch * n, H, W), dtype=torch.float32, device=DEV) if has_res else None
+        outs.append(o)
+        ress.append(r)
+        sb = n * H * W if batch > 1 else 0
+        D.append(_Dst(pl.tview(o, 0, sb=sb), range(c0, c0 + n), act, res=pl.tview(r, 0, sb=sb) if has_res else None))
+        c0 += n
+    cout = c0
+    wt = torch.randn(cout, cin, 3, 3) * (1.0 / (cin * 9) ** 0.5)
+    bs = torch.randn(cout) * 0.1
+    pl.conv([], 'thin', [pl.fsrc(x, 0)], D, H, W, batch=batch, weight=wt, bias=bs)
+    pl._upload()
+    for rep in range(2):
+        for o in outs:
+            o.fill_(-77.0)
+        pl.launch_conv(0, _stream())
+    torch.cuda.synchronize()
+    F = torch.nn.functional
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double().cpu(), wt.half().double(), bs.double(), padding=1)
+    fn = {L.ACT_NONE: lambda z: z, L.ACT_TANH: torch.tanh, L.ACT_SIGMOID: torch.sigmoid}[act]
+    c0 = 0
+    for (n, has_res), o, r in zip(dsts, outs, ress):
+        e = ref[:, c0:c0 + n]
+        if has_res:
+            e = e + r.view(batch, n, H, W).double().cpu()
+        e = fn(e)
+        got = o.view(batch, n, H, W).double().cpu()
+        err = (got - e).abs().max().item()
+        assert err < 4e-3 * max(1.0, e.abs().max().item()), (case, err)
+        c0 += n
+
+
 @pytest.mark.parametrize('kh,kw', [(1, 5), (5, 1)])
 @pytest.mark.parametrize('H,W,batch', [(8, 32, 1), (37, 75, 2), (64, 96, 1), (100, 45, 1), (33, 8, 3)])
 def test_sep_gru_persistent_kernel(kh, kw, H, W, batch):
