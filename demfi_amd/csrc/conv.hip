@@ -1037,7 +1037,7 @@ __global__ __launch_bounds__(P_NT, 1) void conv3x3_narrow_persist_kernel(const d
     // packed cout of accumulator element (g, j) of this lane: 8g + 4hi + j; valid when 4hi + j < oct_n[g]
     float* t_dst[4];
     const float* t_res[4];
-    int t_on[4], t_act[4], t_nq[4];
+    int t_on[4], t_act[4], t_nq[4], t_rmul[4];
     int64_t t_dsb[4], t_rsb[4];
     const int64_t t_sc = (int64_t)H * W;                        // channel stride of every planar view (checked by the host)
     if constexpr (THIN) {
@@ -1049,7 +1049,11 @@ __global__ __launch_bounds__(P_NT, 1) void conv3x3_narrow_persist_kernel(const d
             t_nq[g] = min(max(t_on[g] - 4 * hi, 0), 4);
             const int c0 = d->oct_ch[g] + (t_nq[g] > 0 ? 4 * hi : 0);       // lanes without a valid channel shadow channel 0 (never stored)
             t_dst[g] = (float*)sg.dst.ptr + c0 * t_sc;
-            t_res[g] = sg.res.ptr ? (const float*)sg.res.ptr + c0 * t_sc : nullptr;
+            // no residual (or an empty octet): the prefetch below reads the zero page with all strides multiplied by 0, so
+            // that it stays unconditional (conditional loads leave register copies + an s_waitcnt in front of the MFMAs)
+            const bool hasres = t_on[g] > 0 && sg.res.ptr != nullptr;
+            t_res[g] = hasres ? (const float*)sg.res.ptr + c0 * t_sc : (const float*)d->zero_page;
+            t_rmul[g] = hasres ? 1 : 0;
             t_dsb[g] = sg.dst.sb;
             t_rsb[g] = sg.res.sb;
         }
@@ -1063,15 +1067,13 @@ __global__ __launch_bounds__(P_NT, 1) void conv3x3_narrow_persist_kernel(const d
         if constexpr (THIN) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                if (t_on[g] > 0 && t_res[g] != nullptr) {       // wave-uniform
 #pragma unroll
-                    for (int p = 0; p < 2; ++p) {
-                        const int oy = min(oy0 + wave * 2 + p, H - 1), oxx = min(ox0 + lx, W - 1);
-                        const float* rp = t_res[g] + bimg * t_rsb[g] + (int64_t)oy * W + oxx;
+                for (int p = 0; p < 2; ++p) {
+                    const int oy = min(oy0 + wave * 2 + p, H - 1), oxx = min(ox0 + lx, W - 1);
+                    const float* rp = t_res[g] + (bimg * t_rsb[g] + (int64_t)oy * W + oxx) * t_rmul[g];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j)             // invalid j of this lane: re-read its first channel (value unused)
-                            tr[g][p][j] = *gcp<float>(rp + (j < t_nq[g] ? j : 0) * t_sc);
-                    }
+                    for (int j = 0; j < 4; ++j)                 // invalid j of this lane: re-read its first channel (value unused)
+                        tr[g][p][j] = *gcp<float>(rp + (j < t_nq[g] ? j : 0) * t_sc * t_rmul[g]);
                 }
             }
         }
@@ -1123,18 +1125,19 @@ __global__ __launch_bounds__(P_NT, 1) void conv3x3_narrow_persist_kernel(const d
         }
         if constexpr (THIN) {
 #pragma unroll
+            for (int g = 0; g < 4; ++g) {                       // retire the prefetch here (see the 64-channel kernel)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) asm volatile("" : "+v"(tr[g][q >> 2][q & 3]));
+            }
+#pragma unroll
             for (int g = 0; g < 4; ++g) {
                 if (t_on[g] == 0) continue;                     // wave-uniform
                 const f4_t bq = *(const f4_t*)(bias_lds + g * 8 + 4 * hi);
-                const bool hasres = t_res[g] != nullptr;
 #pragma unroll
                 for (int p = 0; p < 2; ++p) {
                     float v[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        v[j] = acc[0][p][g * 4 + j] + bq[j];
-                        if (hasres) v[j] = v[j] + tr[g][p][j];
-                    }
+                    for (int j = 0; j < 4; ++j) v[j] = (acc[0][p][g * 4 + j] + bq[j]) + tr[g][p][j];   // + 0 without a residual
                     apply_act_n<4>(v, t_act[g]);
                     const int oy = oy0 + wave * 2 + p, oxx = ox0 + lx;
                     if (oy < H && oxx < W) {
