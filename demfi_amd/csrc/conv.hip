@@ -549,7 +549,7 @@ __global__ __launch_bounds__(P_NT, 1) void conv3x3_c64_persist_kernel(const demf
         for (int t = t_first; t < t_end; t += t_step, buf ^= 1) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tile t (and the weights) have landed in LDS
             __syncthreads();                                    // A: hand tile t to the MFMA waves
-            if (VAR != 3 && VAR != 4 && t + t_step < t_end) issue_tile(t + t_step, buf ^ 1);   // streams in under the MFMAs
+            if (VAR != 3 && VAR != 4 && VAR != 10 && t + t_step < t_end) issue_tile(t + t_step, buf ^ 1);   // streams in under the MFMAs
         }
         return;
     }
@@ -749,6 +749,42 @@ __global__ __launch_bounds__(P_NT, 1) void conv3x3_c64_persist_kernel(const demf
                     }
                 }
             };
+            if constexpr (VAR == 11) {
+                // ablation: ring of four k-step fragment sets, loads three k-steps (12 MFMAs) ahead of their use, one ds_read
+                // issued per MFMA
+                struct StepFrag { uint4 a[NCO]; uint4 b[2]; };
+                auto load_step = [&](StepFrag& f, int g) {      // g = tap*4 + ks
+                    const int tap = g >> 2, ks = g & 3;
+                    const int ky = tap / 3, kx = tap % 3;
+#pragma unroll
+                    for (int s = 0; s < NCO; ++s) f.a[s] = *(const uint4*)(wl + (g * NCO + s) * 1024);
+                    const char* p0 = tb + boff[kx * 4 + ks];
+                    f.b[0] = *(const uint4*)(p0 + ky * (P_LW * 128));
+                    f.b[1] = *(const uint4*)(p0 + (ky + 1) * (P_LW * 128));
+                };
+                StepFrag fr[4];
+                load_step(fr[0], 0);
+                load_step(fr[1], 1);
+                load_step(fr[2], 2);
+                __builtin_amdgcn_sched_barrier(0);
+                static_for<0, 36>([&](auto G) {
+                    constexpr int g = decltype(G)::value;
+                    if constexpr (g + 3 < 36) load_step(fr[(g + 3) & 3], g + 3);
+#pragma unroll
+                    for (int s = 0; s < NCO; ++s) {
+                        Mma<half_t>::run(acc[s][0], fr[g & 3].a[s], fr[g & 3].b[0]);
+                        Mma<half_t>::run(acc[s][1], fr[g & 3].a[s], fr[g & 3].b[1]);
+                    }
+                    if constexpr (g + 3 < 36) {
+#pragma unroll
+                        for (int q = 0; q < 2 * NCO; ++q) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            } else {
             FragSet<NCO> f0, f1;
             load_pair(f0, 0);
             if constexpr (VAR == 7) load_pair(f1, 1);           // ablation: fragments loaded once per tile, no LDS traffic below
@@ -784,10 +820,11 @@ __global__ __launch_bounds__(P_NT, 1) void conv3x3_c64_persist_kernel(const demf
                 mma_pair(f1);
                 __builtin_amdgcn_sched_barrier(0);
             });
+            }
         }
         // no second barrier: the epilogue works from registers, and tile t's buffer is only overwritten by the DMA of
         // tile t+2, issued after barrier A of tile t+1, which every MFMA wave reaches after this MFMA phase
-        if (VAR == 1) {
+        if (VAR == 1 || VAR == 10) {                            // 10: MFMA phase only (no tile DMA, no epilogue)
 #pragma unroll
             for (int s = 0; s < NCO; ++s) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1801,6 +1838,8 @@ extern "C" int demfi_conv2d(const demfi_conv* h, const demfi_conv* dev, void* st
         if (h->nco == 2 && var == 4) return launch_persist<2, 4>(h, dev, st);
         if (h->nco == 2 && var == 7) return launch_persist<2, 7>(h, dev, st);
         if (h->nco == 2 && var == 9) return launch_persist<2, 9>(h, dev, st);
+        if (h->nco == 2 && var == 15) return launch_persist<2, 10>(h, dev, st);
+        if (h->nco == 2 && var == 16) return launch_persist<2, 11>(h, dev, st);
 #endif
         if (h->nco == 2) {
 #ifdef DEMFI_ABLATION
