@@ -1843,6 +1843,8 @@ extern "C" int demfi_conv2d(const demfi_conv* h, const demfi_conv* dev, void* st
 #endif
         if (h->nco == 2) {
 #ifdef DEMFI_ABLATION
+            static const int w8sel = getenv("DEMFI_CONV_W8") ? atoi(getenv("DEMFI_CONV_W8")) : 0;
+            if (w8sel) return launch_w8(h, dev, st);
             static const int zsel = getenv("DEMFI_CONV_Z") ? atoi(getenv("DEMFI_CONV_Z")) : 0;
             if (zsel) return launch_z(h, dev, st);
             if (var == 5) return launch_persist<2>(h, dev, st);
