@@ -3,17 +3,34 @@
 set -e
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -I../../include -Wno-unused-result"
-$HIPCC $FLAGS -c conv.hip -o conv.o &
-$HIPCC $FLAGS -c pointwise.hip -o pointwise.o &
-$HIPCC $FLAGS -x hip -c abi.cpp -o abi.o &
-wait
-$HIPCC --offload-arch=gfx950 -shared -fPIC conv.o pointwise.o abi.o -o libdemfi_hip.so
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -I../../include -Wno-unused-result -Wno-pass-failed"
+SRCS_HIP="conv.hip pointwise.hip"
+SRCS_CPP="abi.cpp"
+[ -f metrics.hip ] && SRCS_HIP="$SRCS_HIP metrics.hip"
+[ -f fgac_window.hip ] && SRCS_HIP="$SRCS_HIP fgac_window.hip"
+[ -f ctx.cpp ] && SRCS_CPP="$SRCS_CPP ctx.cpp"
+[ -f png_codec.cpp ] && SRCS_CPP="$SRCS_CPP png_codec.cpp"
+# stale objects must never be linked: a failed compile has to fail the build
+rm -f ./*.o libdemfi_hip.so
+pids=()
+objs=()
+for s in $SRCS_HIP; do
+  o="${s%.hip}.o"; objs+=("$o")
+  $HIPCC $FLAGS -c "$s" -o "$o" & pids+=($!)
+done
+for s in $SRCS_CPP; do
+  o="${s%.cpp}.o"; objs+=("$o")
+  $HIPCC $FLAGS -x hip -c "$s" -o "$o" & pids+=($!)
+done
+for p in "${pids[@]}"; do wait "$p"; done      # 'wait PID' returns that job's status: set -e stops on the first failure
+$HIPCC --offload-arch=gfx950 -shared -fPIC "${objs[@]}" -o libdemfi_hip.so -lz -lpthread
 echo "built $(pwd)/libdemfi_hip.so"
 # --ablation: second library with the ablation variants / experimental kernels (DEMFI_PERSIST_VARIANT, DEMFI_SEP_VARIANT,
 # DEMFI_CONV_Z, ...); use it with DEMFI_HIP_LIB=$(pwd)/libdemfi_hip_abl.so.  Never loaded by default.
 if [ "$1" = "--ablation" ]; then
   $HIPCC $FLAGS -DDEMFI_ABLATION -c conv.hip -o conv_abl.o
-  $HIPCC --offload-arch=gfx950 -shared -fPIC conv_abl.o pointwise.o abi.o -o libdemfi_hip_abl.so
+  abl=()
+  for o in "${objs[@]}"; do [ "$o" = conv.o ] && abl+=(conv_abl.o) || abl+=("$o"); done
+  $HIPCC --offload-arch=gfx950 -shared -fPIC "${abl[@]}" -o libdemfi_hip_abl.so -lz -lpthread
   echo "built $(pwd)/libdemfi_hip_abl.so"
 fi

@@ -569,6 +569,11 @@ extern "C" int demfi_warp_blend(const demfi_view* A, const float* fa, const demf
         int f32 = 0;
         const int sh = fat_lpp_shift(A, C, "demfi_warp_blend", &f32);
         if (sh < 0) return sh;
+        // the kernel keeps the corner byte offsets of A / B as 32-bit ints (WarpRec): refuse images they cannot address
+        const int64_t elt = f32 ? 4 : 2;
+        if (((int64_t)(H - 1) * A->sy + (int64_t)(W - 1) * A->sx + C) * elt >= ((int64_t)1 << 31) ||
+            ((int64_t)(H - 1) * B->sy + (int64_t)(W - 1) * B->sx + C) * elt >= ((int64_t)1 << 31))
+            return demfi_set_error(DEMFI_ERR_ARG, "demfi_warp_blend: image spans >= 2^31 bytes (32-bit corner offsets)");
         // 4-row x 64-pixel tiles, 8 XCD bands of ceil(ntile / 8) tiles each
         const unsigned nblk = 8u * (unsigned)((((W + 63) / 64) * ((H + 3) / 4) + 7) / 8);
         if (f32)

@@ -53,9 +53,14 @@ class DeMFInet(nn.Module):
     # any state_dict load invalidates the repacked weights
     def load_state_dict(self, *a, **k):
         r = super().load_state_dict(*a, **k)
+        self.invalidate_weights()
+        return r
+
+    def invalidate_weights(self):
+        """Call after changing parameters in place (``p.copy_``, ``p.mul_`` ...): the engines hold REPACKED copies of the
+        weights; this drops them so the next forward / WindowRunner call repacks (load_state_dict does it itself)."""
         self._engines = {}
         self._weights_version += 1
-        return r
 
     def engine(self, H, W, num_update, n_ctx=1, n_trunk=1):
         """Engine for a frame size (built on first use: weight repack + buffer allocation).  n_ctx: independent per-t
@@ -86,6 +91,9 @@ class DeMFInet(nn.Module):
             raise ValueError('x must be [B,3,4,H,W], got %s' % (tuple(x.shape),))
         if not x.is_cuda:
             raise RuntimeError('demfi_amd.DeMFInet: input must live on the GPU (HIP-only path)')
+        if x.device != self.device:
+            # the reference builds its grids on args.gpu's device too (DeMFInet.py:18-19, 749): same contract, but loud
+            raise RuntimeError('demfi_amd.DeMFInet: input on %s, model built for %s (args.gpu)' % (x.device, self.device))
 
     @torch.no_grad()
     def forward(self, x, t_value, num_update=None, is_training=None, clone_outputs=True):

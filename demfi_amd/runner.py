@@ -26,7 +26,10 @@ class WindowRunner:
         W = (width + 31) // 32 * 32
         self.n_ctx = int(os.environ.get('DEMFI_NCTX', 3)) if (use_graph and mfi > 2) else 1
         self.n_trunk = int(os.environ.get('DEMFI_NTRUNK', 2)) if use_graph else 1
+        self.model = model
+        self._HW = (H, W)
         self.engine = model.engine(H, W, n_tst, n_ctx=self.n_ctx, n_trunk=self.n_trunk)
+        self._weights_version = model._weights_version
         self.n_tst, self.mfi = n_tst, mfi
         self.ts = [float(t) for t in t_schedule(mfi)]
         dev = self.engine.device
@@ -44,6 +47,21 @@ class WindowRunner:
         self._t_done = [None] * self.n_trunk        # events: the per-t work that last read trunk context k
 
     # ---------------------------------------------------------------------------------------------------------
+    def _check_device(self, t, what):
+        """Raw device pointers go straight to the kernels: a host tensor or one on another GPU must fail in Python."""
+        if not (isinstance(t, torch.Tensor) and t.is_cuda and t.device == self.engine.device):
+            raise ValueError('demfi_amd.WindowRunner: %s must be a tensor on %s (got %s)' %
+                             (what, self.engine.device, getattr(t, 'device', type(t))))
+
+    def _check_u8_frames(self, frames_u8):
+        if len(frames_u8) != 4:
+            raise ValueError('expected 4 uint8 frames (B0,B1,B-1,B2), got %d' % len(frames_u8))
+        for f in frames_u8:
+            self._check_device(f, 'uint8 frame')
+            if f.dtype != torch.uint8 or tuple(f.shape) != (self.h, self.w, 3) or not f.is_contiguous():
+                raise ValueError('uint8 frames must be contiguous [%d,%d,3] uint8 tensors, got %s %s' %
+                                 (self.h, self.w, f.dtype, tuple(f.shape)))
+
     def _capture(self, fn, stream):
         h = stream.cuda_stream
         L.check(self.lib.demfi_graph_begin(h), 'graph_begin')
@@ -122,7 +140,23 @@ class WindowRunner:
             evs.append(ev)
         self._t_done[k] = evs
 
+    def _destroy_graphs(self):
+        gs = list(self._g_trunk or [])
+        for row in (self._g_t or []):
+            gs += list(row)
+        for g in gs:
+            if g is not None:
+                self.lib.demfi_graph_destroy(g)
+        self._g_trunk = self._g_t = None
+
     def _begin(self):
+        if self.model._weights_version != self._weights_version:
+            # the model's weights were reloaded: the old engine's blob (and the graphs pointing at it) are stale
+            torch.cuda.synchronize(self.engine.device)
+            self._destroy_graphs()
+            self.engine = self.model.engine(self._HW[0], self._HW[1], self.n_tst, n_ctx=self.n_ctx, n_trunk=self.n_trunk)
+            self._weights_version = self.model._weights_version
+            self._t_done = [None] * self.n_trunk
         cur = torch.cuda.current_stream(self.engine.device)
         self.stream.wait_stream(cur)                 # inputs produced on the caller's stream
         for s in self.t_streams:
@@ -139,6 +173,7 @@ class WindowRunner:
     def _loader(self, x):
         if tuple(x.shape) != (1, 3, 4, self.h, self.w):
             raise ValueError('expected a [1,3,4,%d,%d] window, got %s' % (self.h, self.w, tuple(x.shape)))
+        self._check_device(x, 'window')
         x = x.contiguous().float()                   # the pad kernel reads raw [3,4,h,w] memory
 
         def load(e, h):
@@ -192,8 +227,7 @@ class WindowRunner:
         if getattr(self, '_out_u8', None) is None:
             self._out_u8 = torch.zeros((self.mfi - 1, self.h, self.w, 3), dtype=torch.uint8, device=e.device)
             self._s01_u8 = torch.zeros((2, self.h, self.w, 3), dtype=torch.uint8, device=e.device)
-        assert len(frames_u8) == 4 and all(f.dtype == torch.uint8 and tuple(f.shape) == (self.h, self.w, 3) and f.is_contiguous()
-                                           for f in frames_u8)
+        self._check_u8_frames(frames_u8)
         ptrs = (C.c_void_p * 4)(*[f.data_ptr() for f in frames_u8])
 
         def load(eng, h):
@@ -212,11 +246,6 @@ class WindowRunner:
 
     def __del__(self):
         try:
-            gs = list(self._g_trunk or [])
-            for row in (self._g_t or []):
-                gs += list(row)
-            for g in gs:
-                if g is not None:
-                    self.lib.demfi_graph_destroy(g)
+            self._destroy_graphs()
         except Exception:
             pass

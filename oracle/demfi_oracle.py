@@ -435,3 +435,53 @@ def frame_to_u8(pred):
     (utils.py:718-721) -> [h,w,3] -> astype(uint8) (truncation)."""
     p = np.asarray(pred, dtype=np.float64)
     return np.transpose(denorm255(p), [1, 2, 0]).astype(np.uint8)
+
+
+def gaussian_window(ksize=11, sigma=1.5):
+    """cv2.getGaussianKernel(11, 1.5) outer itself (utils.py:669-670): normalised exp(-(i - (k-1)/2)^2 / (2 sigma^2))."""
+    i = np.arange(ksize, dtype=np.float64) - (ksize - 1) / 2.0
+    k = np.exp(-(i * i) / (2.0 * sigma * sigma))
+    k = k / k.sum()
+    return np.outer(k, k)
+
+
+def _filter_valid(img, window):
+    """cv2.filter2D(img, -1, window)[5:-5, 5:-5] (utils.py:672-673): correlation, 'valid' interior only."""
+    k = window.shape[0]
+    h, w = img.shape[0] - k + 1, img.shape[1] - k + 1
+    out = np.zeros((h, w) + img.shape[2:], np.float64)
+    for dy in range(k):
+        for dx in range(k):
+            out += window[dy, dx] * img[dy:dy + h, dx:dx + w]
+    return out
+
+
+def ssim_matlab(img1, img2):
+    """ssim_matlab_func (utils.py:663-683): img [h,w] or [h,w,c] in [0,255], float64 throughout, mean over the valid
+    11x11-Gaussian interior (all channels at once for a 3-D input, as the reference calls it, utils.py:699-701)."""
+    C1, C2 = (0.01 * 255) ** 2, (0.03 * 255) ** 2
+    a, b = np.asarray(img1, np.float64), np.asarray(img2, np.float64)
+    win = gaussian_window()
+    mu1, mu2 = _filter_valid(a, win), _filter_valid(b, win)
+    s1 = _filter_valid(a * a, win) - mu1 * mu1
+    s2 = _filter_valid(b * b, win) - mu2 * mu2
+    s12 = _filter_valid(a * b, win) - mu1 * mu2
+    m = ((2 * mu1 * mu2 + C1) * (2 * s12 + C2)) / ((mu1 * mu1 + mu2 * mu2 + C1) * (s1 + s2 + C2))
+    return float(m.mean())
+
+
+def psnr255(img1, img2):
+    """psnr (utils.py:652-660) on [0,255] images."""
+    mse = np.mean((np.asarray(img1, np.float64) - np.asarray(img2, np.float64)) ** 2)
+    return float('inf') if mse == 0 else 20 * np.log10(255.0 / np.sqrt(mse))
+
+
+def eval_frame(pred, gt, round_gt=False):
+    """What test() computes per frame (main.py:762-770): pred, gt [3,h,w] in [-1,1] -> (psnr, ssim) of the [0,255] HWC
+    images; the prediction is rounded (np.around), the target is not (it came from an 8-bit PNG); crop_8x8
+    (utils.py:625-642) returns the image uncropped; the BGR->RGB flip does not change either metric."""
+    a = np.around(denorm255(np.transpose(np.asarray(pred, np.float64), [1, 2, 0])))
+    b = denorm255(np.transpose(np.asarray(gt, np.float64), [1, 2, 0]))
+    if round_gt:
+        b = np.around(b)
+    return psnr255(b, a), ssim_matlab(b, a)

@@ -1,0 +1,261 @@
+"""BASELINE.json configurations at FULL size on a real MI355X (round-2 additions):
+
+  configs[0]  256x256, N_tst=1, x2            -> fp32 HIP forward vs the frozen reference fixture
+  configs[1]  720p fp16 N_tst=3 x8            -> asserted PSNR bounds against the fp32 oracle on the full window
+  configs[3]  720p fp32 N_tst=5               -> the strict |dPSNR| <= 1e-3 dB criterion at full size
+  configs[4]  1080p (1088x1920) fp16 x16      -> WindowRunner(mfi=16) properties + one-t PSNR against the oracle
+plus the integer index maps of the warps / splat at W = 1280 and W = 1920 (323-367 columns move in the
+fp32 coordinate round trip at these widths), bit-identical to the oracle's step-by-step numpy emulation.
+
+The oracle (CPU fp32 restatement pinned to the reference fixtures) is run ONCE per size here; the N_tst=5 run also yields
+the N_tst=3 reference (the recursion is sequential: finals[2] of an N=5 forward is the N=3 result)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from demfi_amd import DeMFInet, HyperParams, synthetic_state_dict, synthetic_window   # noqa: E402
+from demfi_amd import _lib as L                                                       # noqa: E402
+from demfi_amd.harness import pad_forward_crop, t_schedule                            # noqa: E402
+from oracle import demfi_oracle as O                                                  # noqa: E402
+
+DEV = 'cuda:0'
+
+
+def _model(dtype):
+    m = DeMFInet(HyperParams(), dtype=dtype)
+    m.load_state_dict(synthetic_state_dict(0))
+    return m.to(DEV).eval()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+# ------------------------------------------------------------------------------------------------------
+# configs[0]
+# ------------------------------------------------------------------------------------------------------
+def test_config1_256_fp32_vs_reference_fixture(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'cfg1_256x256_t0500_n1.npz'))
+    x = synthetic_window(256, 256, int(g['seed']))
+    m = _model(torch.float32)
+    d1, fin, flows, occs, ov = m(x.to(DEV), torch.tensor([[0.5]], device=DEV), 1)
+    st = fin[0][2][0].cpu().numpy()
+    gt = x[0, :, 0].numpy()
+    assert abs(O.psnr(st, gt) - float(g['psnr_St_vs_B0'])) <= 1e-3                  # north-star tolerance
+    assert O.psnr(st, g['St']) > 60.0
+    assert np.median(np.abs(st - g['St'])) < 2e-5
+    assert np.median(np.abs(flows[-1][0].cpu().numpy() - g['flows_last'])) < 2e-4
+    for i in range(3):
+        d = np.abs(np.around(O.denorm255(fin[0][i][0].cpu().numpy())).astype(np.int32) - g['finals_u8'][i].astype(np.int32))
+        assert (d > 0).mean() < 2e-3 and np.percentile(d, 99.99) <= 1
+
+
+# ------------------------------------------------------------------------------------------------------
+# configs[1] + configs[3]: one oracle run on the full 736x1280 window
+# ------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope='module')
+def oracle_720p_n5():
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    x = synthetic_window(736, 1280, 1)
+    t = torch.tensor([[0.5]])
+    with torch.no_grad():
+        ref = O.forward(synthetic_state_dict(0), x, t, 5)
+    return x, t, ref
+
+
+def test_config4_720p_fp32_n5_strict_psnr(oracle_720p_n5):
+    """The strict-parity configuration at FULL size: fp32 path, N_tst = 5, |dPSNR| <= 1e-3 dB against a fixed pseudo
+    ground truth for every frame the module returns, and the direct PSNR(build, oracle) well above 60 dB."""
+    x, t, ref = oracle_720p_n5
+    m = _model(torch.float32)
+    d1, fin, flows, occs, ov = m(x.to(DEV), t.to(DEV), 5)
+    gt = x[0, :, 0].numpy()
+    for it in range(5):
+        for i in range(3):
+            got = fin[it][i][0].cpu().numpy()
+            exp = ref[1][it][i][0].numpy()
+            assert abs(O.psnr(got, gt) - O.psnr(exp, gt)) <= 1e-3, (it, i)
+            assert O.psnr(got, exp) > 60.0, (it, i)
+    for i in range(3):
+        assert abs(O.psnr(d1[i][0].cpu().numpy(), gt) - O.psnr(ref[0][i][0].numpy(), gt)) <= 1e-3
+    assert np.median(np.abs(flows[5][0].cpu().numpy() - ref[2][5][0].numpy())) < 2e-4
+    del m
+    torch.cuda.empty_cache()
+
+
+def test_config2_720p_fp16_n3_psnr_bounds(oracle_720p_n5):
+    """fp16 has no reference oracle (the reference crashes under .half()): it is stated against the fp32
+    oracle.  Gate: PSNR(St, fp32) >= 44 dB and |dPSNR vs pseudo-GT| <= 5e-3 dB on the full window
+    (round-1 measurement: 45.6 dB / +0.0021 dB) -- looser than the fp32 tolerance by contract, but asserted."""
+    x, t, ref = oracle_720p_n5
+    m = _model(torch.float16)
+    d1, fin, flows, occs, ov = m(x.to(DEV), t.to(DEV), 3)
+    gt = x[0, :, 0].numpy()
+    for i in range(3):
+        got = fin[2][i][0].cpu().numpy()
+        exp = ref[1][2][i][0].numpy()
+        ps, dps = O.psnr(got, exp), O.psnr(got, gt) - O.psnr(exp, gt)
+        print('720p fp16 N=3 frame %d: PSNR vs fp32 oracle %.2f dB, dPSNR vs pseudo-GT %+.4f dB' % (i, ps, dps))
+        assert np.isfinite(got).all()
+        assert ps >= 44.0 and abs(dps) <= 5e-3, (i, ps, dps)
+    del m
+    torch.cuda.empty_cache()
+
+
+# ------------------------------------------------------------------------------------------------------
+# configs[4]: 1080p -> 1088x1920, x16 (15 time instants, t_schedule(16)), N_tst = 3, fp16
+# ------------------------------------------------------------------------------------------------------
+def test_config5_1080p_x16_runner_properties_and_psnr():
+    from demfi_amd.runner import WindowRunner
+    h, w, N, M = 1080, 1920, 3, 16
+    m = _model(torch.float16)
+    xs = [synthetic_window(h, w, 50 + i).to(DEV) for i in range(2)]
+    runner = WindowRunner(m, h, w, n_tst=N, mfi=M)
+    assert runner.engine.H == 1088 and runner.engine.W == 1920 and len(runner.ts) == 15
+    assert np.allclose(runner.ts, np.arange(1, 16) / 16.0)
+    st_a, s01_a = runner.run_windows(xs)
+    st_a, s01_a = st_a.clone(), s01_a.clone()
+    st_b, s01_b = runner.run_windows(xs)
+    torch.cuda.synchronize()
+    assert tuple(st_a.shape) == (2, 15, 3, h, w)
+    assert torch.isfinite(st_a).all() and torch.isfinite(s01_a).all()
+    assert torch.equal(st_a, st_b) and torch.equal(s01_a, s01_b)                   # run-to-run bit-identical
+    # the pipelined scheduler == one pad -> forward -> crop per (window, t), on three t of each window
+    ts = t_schedule(M)
+    for wi in range(2):
+        for k in (0, 7, 14):
+            ref = pad_forward_crop(m, xs[wi], torch.tensor([[float(ts[k])]], device=DEV), N)
+            assert torch.equal(st_a[wi, k], ref[1][N - 1][2][0]), (wi, k)
+            if k == 0:
+                assert torch.equal(s01_a[wi, 0], ref[1][N - 1][0][0]) and torch.equal(s01_a[wi, 1], ref[1][N - 1][1][0])
+    # one time instant against the fp32 oracle on the padded 1088x1920 window (t = 9/16)
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    xp = torch.nn.functional.pad(xs[0].cpu().reshape(1, 12, h, w), [0, 0, 0, 8], mode='reflect').reshape(1, 3, 4, 1088, w)
+    tv = torch.tensor([[float(ts[8])]])
+    with torch.no_grad():
+        ref = O.forward(synthetic_state_dict(0), xp, tv, N)
+    exp = ref[1][N - 1][2][0, :, :h].numpy()
+    got = st_a[0, 8].cpu().numpy()
+    gt = xs[0][0, :, 0].cpu().numpy()
+    ps, dps = O.psnr(got, exp), O.psnr(got, gt) - O.psnr(exp, gt)
+    print('1080p x16 fp16 t=9/16: PSNR vs fp32 oracle %.2f dB, dPSNR vs pseudo-GT %+.4f dB' % (ps, dps))
+    assert ps >= 44.0 and abs(dps) <= 5e-3
+
+
+# ------------------------------------------------------------------------------------------------------
+# integer index maps at the full widths (H = 8 rows is enough: the round trip is per axis)
+# ------------------------------------------------------------------------------------------------------
+def _wide_flows(H, W, seed):
+    g = torch.Generator().manual_seed(seed)
+    xs = torch.arange(W).view(1, W).float()
+    ys = torch.arange(H).view(H, 1).float()
+    fams = {
+        'zeros': torch.zeros(2, H, W),                                        # pure round-trip flips (F11)
+        'ints': torch.randint(-20, 21, (2, H, W), generator=g).float(),
+        'halves': torch.randint(-20, 21, (2, H, W), generator=g).float() + 0.5,
+        'smooth': torch.nn.functional.avg_pool2d(torch.randn(1, 2, H + 8, W + 8, generator=g) * 25, 9, 1)[0],
+        'large': torch.randn(2, H, W, generator=g) * (2.0 * W),
+    }
+    e = torch.zeros(2, H, W)                                                  # samples landing exactly on W-1 / H-1 / -1 / 0
+    e[0] = torch.where((ys % 4) == 0, (W - 1) - xs, torch.where((ys % 4) == 1, -1 - xs, -xs))
+    e[1] = torch.where((xs % 4) == 0, (H - 1) - ys, torch.where((xs % 4) == 1, -1 - ys, -ys))
+    fams['edges'] = e
+    return {k: v.contiguous() for k, v in fams.items()}
+
+
+def _warp_maps_expected(flo, H, W):
+    m = O.backward_warp_maps(flo)
+    inb = sum((m['inb'][k].astype(np.int32) << k) for k in range(4)) | (m['valid'].astype(np.int32) << 4)
+    return np.clip(m['ix0'], -4, W + 4).astype(np.int32), np.clip(m['iy0'], -4, H + 4).astype(np.int32), inb
+
+
+@pytest.mark.parametrize('W', [1280, 1920])
+def test_index_maps_bit_exact_at_full_width(W):
+    H = 8
+    lib = L.load()
+    fams = _wide_flows(H, W, 100 + W)
+    names = list(fams)
+    # the round trip really is lossy at this width (otherwise the test would not test the emulation)
+    z = O.backward_warp_maps(np.zeros((2, H, W), np.float32))
+    moved = int((z['ix0'][0] != np.arange(W)).sum())
+    assert moved > 100, moved
+    t = torch.tensor([0.375], device=DEV)
+    # ---- demfi_warp_blend: fat (NHWC fp16, C = 64) and thin (planar fp32, C = 3) ---------------------------------
+    A16 = torch.tanh(torch.randn(H, W, 64, device=DEV)).half()
+    A3 = torch.rand(3, H, W, device=DEV) * 2 - 1
+    logit = torch.randn(H, W, device=DEV)
+    for na, nb in zip(names, names[1:] + names[:1]):
+        fa, fb = fams[na].to(DEV), fams[nb].to(DEV)
+        exp = [_warp_maps_expected(fams[n].numpy(), H, W) for n in (na, nb)]
+        for fat in (True, False):
+            dbg = torch.zeros(2, 3, H * W, dtype=torch.int32, device=DEV)
+            if fat:
+                out = torch.zeros(H, W, 64, device=DEV, dtype=torch.float16)
+                va = L.View(A16.data_ptr(), 64, W * 64, 1, 0, 0, 0)
+                vo = L.View(out.data_ptr(), 64, W * 64, 1, 0, 0, 0)
+                L.check(lib.demfi_warp_blend(C.byref(va), fa.data_ptr(), C.byref(va), fb.data_ptr(), logit.data_ptr(),
+                                             t.data_ptr(), C.byref(vo), 64, H, W, None, dbg.data_ptr(), _stream()))
+            else:
+                out = torch.zeros(3, H, W, device=DEV)
+                va = L.View(A3.data_ptr(), 1, W, H * W, 0, 1, 0)
+                vo = L.View(out.data_ptr(), 1, W, H * W, 0, 1, 0)
+                L.check(lib.demfi_warp_blend(C.byref(va), fa.data_ptr(), C.byref(va), fb.data_ptr(), logit.data_ptr(),
+                                             t.data_ptr(), C.byref(vo), 3, H, W, None, dbg.data_ptr(), _stream()))
+            torch.cuda.synchronize()
+            for which in range(2):
+                x0, y0, inb = exp[which]
+                got = dbg[which].cpu().numpy().reshape(3, H, W)
+                assert np.array_equal(got[2], inb), (na, nb, fat, which)
+                anyin = (inb & 15) != 0
+                assert np.array_equal(got[0][anyin], x0[anyin]) and np.array_equal(got[1][anyin], y0[anyin]), (na, nb, fat)
+            if not fat:                                                         # values, thin path, exact fp32 steps
+                ref = O.warp_blend(A3.cpu()[None], fams[na][None], A3.cpu()[None], fams[nb][None], logit.cpu()[None, None],
+                                   t.cpu().view(1, 1, 1, 1))
+                assert (out.cpu() - ref[0]).abs().max() < 3e-6, (na, nb)
+    # ---- demfi_fgac_gather: absolute coordinates up to and beyond W-1 --------------------------------------------
+    src = torch.tanh(torch.randn(H, W, 64, device=DEV)).half()
+    g = torch.Generator().manual_seed(W)
+    fl_abs = {'inrange': torch.rand(2, H, W, generator=g) * torch.tensor([W - 1.0, H - 1.0]).view(2, 1, 1),
+              'ints': torch.stack([torch.arange(W).float().expand(H, W), torch.arange(H).float().view(H, 1).expand(H, W)]),
+              'mixed': torch.randn(2, H, W, generator=g) * torch.tensor([W / 2.0, 6.0]).view(2, 1, 1)}
+    for name, fl in fl_abs.items():
+        fl = fl.contiguous()
+        out = torch.zeros(H, W, 64, device=DEV, dtype=torch.float16)
+        dbg = torch.zeros(3, H * W, dtype=torch.int32, device=DEV)
+        vs = L.View(src.data_ptr(), 64, W * 64, 1, 0, 0, 0)
+        vo = L.View(out.data_ptr(), 64, W * 64, 1, 0, 0, 0)
+        L.check(lib.demfi_fgac_gather(C.byref(vs), fl.to(DEV).data_ptr(), C.byref(vo), 64, H, W, dbg.data_ptr(), _stream()))
+        torch.cuda.synchronize()
+        m = O.sample_maps(fl[0].numpy(), fl[1].numpy(), H, W)
+        inb = sum((m['inb'][k].astype(np.int32) << k) for k in range(4))
+        got = dbg.cpu().numpy().reshape(3, H, W)
+        assert np.array_equal(got[2] & 15, inb), name
+        anyin = inb != 0
+        assert np.array_equal(got[0][anyin], m['ix0'][anyin].astype(np.int32)), name
+        assert np.array_equal(got[1][anyin], m['iy0'][anyin].astype(np.int32)), name
+    # ---- demfi_cfr_flow_align: splat target indices / masks ------------------------------------------------------
+    for (na, nb), tv in zip((('smooth', 'ints'), ('halves', 'large'), ('edges', 'smooth')), (0.125, 0.5, 0.875)):
+        f01, f10 = fams[na].to(DEV), fams[nb].to(DEV)
+        tt = torch.tensor([tv], device=DEV)
+        acc = torch.zeros(6 * H * W, dtype=torch.int64, device=DEV)
+        out = torch.zeros(4, H, W, device=DEV)
+        dbg = torch.zeros(2, 4, H * W, dtype=torch.int32, device=DEV)
+        L.check(lib.demfi_cfr_flow_align(f01.data_ptr(), f10.data_ptr(), tt.data_ptr(), H, W, acc.data_ptr(), out.data_ptr(),
+                                         dbg.data_ptr(), _stream()))
+        torch.cuda.synchronize()
+        t32 = np.float32(tv)
+        for k, (fl, s) in enumerate(((fams[na].numpy(), t32), (fams[nb].numpy(), np.float32(1) - t32))):
+            maps = O.splat_maps((fl * s).astype(np.float32), H, W)
+            for c, mm in enumerate(maps):
+                exp = np.where(mm['mask'], mm['row'] * W + mm['col'], -1).astype(np.int32).reshape(-1)
+                assert np.array_equal(dbg[k, c].cpu().numpy(), exp), (na, nb, k, c)
+        a, b = O.cfr_flow_align(fams[na][None], fams[nb][None], torch.tensor(tv).view(1, 1, 1, 1))
+        ref = torch.cat([a[0], b[0]], 0)
+        scale = max(1.0, float(ref.abs().max()))
+        assert (out.cpu() - ref).abs().max() < 2e-5 * scale, (na, nb)
+        assert int(acc.abs().max()) == 0                                         # workspace left clean

@@ -107,3 +107,41 @@ def test_fgac_ignores_conv_source_k(synthetic_sd):
         sd['FAC_FB_Module.shared_FGAC.conv_source_k.weight'] = sd['FAC_FB_Module.shared_FGAC.conv_source_k.weight'] * 100
         b = O.forward(sd, x, torch.tensor([[0.5]]), 1)
     assert torch.equal(a[1][0][2], b[1][0][2])
+
+
+def test_config1_fixture_256(golden_dir, synthetic_sd):
+    """BASELINE.json configs[0]: N_tst=1, x2 (t=0.5), 256x256, CPU fp32 -- the reference's own CPU-runnable case."""
+    g = _load(golden_dir, 'cfg1_256x256_t0500_n1')
+    x = synthetic_window(int(g['H']), int(g['W']), int(g['seed']))
+    with torch.no_grad():
+        d1, fin, flows, occs, ov = O.forward(synthetic_sd, x, torch.tensor([[float(g['t'])]]), int(g['N']))
+    assert (fin[0][2][0].numpy() - g['St']).__abs__().max() < 5e-5
+    assert np.abs(flows[-1][0].numpy() - g['flows_last']).max() < 5e-4
+    assert np.abs(occs[-1][0].numpy() - g['occ_last']).max() < 5e-5
+    gt = x[0, :, 0].numpy()
+    p_or = O.psnr(fin[0][2][0].numpy(), gt)
+    assert abs(p_or - float(g['psnr_St_vs_B0'])) <= 1e-3                       # the north-star tolerance
+    for i in range(3):                                                          # rounded 8-bit frames: off by <= 1 level, rarely
+        d = np.abs(np.around(O.denorm255(fin[0][i][0].numpy())).astype(np.int32) - g['finals_u8'][i].astype(np.int32))
+        assert d.max() <= 1 and (d > 0).mean() < 1e-3
+
+
+def test_uint8_loader_and_writer_fixture(golden_dir):
+    """RGBframes_np2Tensor (utils.py:224-238) and the writer's denorm255_np + astype(uint8) truncation
+    (utils.py:718-721, main.py:1165-1178): oracle helpers bit-identical to the frozen reference outputs."""
+    g = _load(golden_dir, 'u8io_20x28')
+    assert np.array_equal(O.frames_u8_to_tensor(list(g['frames'])).numpy(), g['tensor'])
+    assert np.array_equal(O.frame_to_u8(g['pred']), g['out_u8'])
+
+
+def test_psnr_ssim_fixture(golden_dir):
+    """psnr (utils.py:652-660) and ssim / ssim_matlab_func (utils.py:663-705) against values computed by the reference
+    code (cv2.getGaussianKernel / filter2D stubbed with their documented formulas, tools/make_goldens.py)."""
+    g = _load(golden_dir, 'metrics_96x128')
+    ia = np.around(O.denorm255(np.transpose(g['a'].astype(np.float64), [1, 2, 0])))
+    ib = np.around(O.denorm255(np.transpose(g['b'].astype(np.float64), [1, 2, 0])))
+    assert abs(O.psnr255(ia, ib) - float(g['psnr'])) < 1e-9
+    assert abs(O.ssim_matlab(ia, ib) - float(g['ssim'])) < 1e-9
+    assert O.psnr255(ia, ia) == float('inf') and abs(O.ssim_matlab(ia, ia) - 1.0) < 1e-12
+    p, s = O.eval_frame(g['a'], g['b'], round_gt=True)
+    assert abs(p - float(g['psnr'])) < 1e-9 and abs(s - float(g['ssim'])) < 1e-9

@@ -158,5 +158,94 @@ def main():
     print('worst e2e oracle-vs-reference diff %.3e' % worst)
 
 
+def load_reference_utils():
+    """utils.py of the reference as a module: it does not parse as shipped (TabError at
+    utils.py:271,273 -> expandtabs) and imports cv2 / skimage / torchvision, absent here.  The two cv2 functions its SSIM
+    uses are given their documented formulas (getGaussianKernel: normalised exp(-(i-(k-1)/2)^2 / (2 sigma^2));
+    filter2D: correlation, anchor at the kernel centre -- only the [5:-5] "valid" interior is read, so the border mode
+    does not matter) -- stated in tests/golden/README as "reference code, stubbed cv2 primitives"."""
+    import scipy.ndimage
+    cv2 = types.ModuleType('cv2')
+
+    def getGaussianKernel(ksize, sigma):
+        i = np.arange(ksize, dtype=np.float64) - (ksize - 1) / 2.0
+        k = np.exp(-(i * i) / (2.0 * sigma * sigma))
+        return (k / k.sum()).reshape(ksize, 1)
+
+    def filter2D(img, ddepth, kernel):
+        img, kernel = np.asarray(img, np.float64), np.asarray(kernel, np.float64)
+        if img.ndim == 3:                                     # cv2 filters every channel of an [h,w,c] image with the 2-D kernel
+            kernel = kernel[:, :, None]
+        return scipy.ndimage.correlate(img, kernel, mode='mirror')
+    cv2.getGaussianKernel, cv2.filter2D = getGaussianKernel, filter2D
+    sys.modules['cv2'] = cv2
+    for name in ['skimage', 'skimage.metrics', 'torchvision', 'torchvision.models', 'torchvision.transforms']:
+        sys.modules[name] = types.ModuleType(name)
+    sys.modules['skimage.metrics'].structural_similarity = None
+    sys.modules['torchvision'].models = sys.modules['torchvision.models']
+    sys.modules['torchvision'].transforms = sys.modules['torchvision.transforms']
+    U = types.ModuleType('utils_ref')
+    exec(compile(open('/root/reference/utils.py').read().expandtabs(8), 'utils_ref', 'exec'), U.__dict__)
+    return U
+
+
+def round2():
+    """Fixtures added in round 2 (the round-1 files above are not rewritten): config 1 of BASELINE.json, the uint8
+    conversions of the loader / writer, PSNR + SSIM of the reference's evaluation."""
+    sd = synthetic_state_dict(0)
+    net = R.DeMFInet(ARGS).eval()
+    net.load_state_dict(sd)
+    U = load_reference_utils()
+    # ---- config 1: 256x256, N_tst = 1, x2 (t = 0.5), CPU fp32 (SURVEY.md section 8d) ------------------------------
+    H = W = 256
+    x = synthetic_window(H, W, 1)
+    t = torch.tensor([[0.5]], dtype=torch.float32)
+    with torch.no_grad():
+        d1, fin, flows, occs, ov = net(x, t, 1)
+        mine = O.forward(sd, x, t, 1)
+    gt = x[0, :, 0].numpy()                                  # fixed pseudo ground truth (B0)
+    u8 = lambda z: np.around(U.denorm255_np(z.numpy().astype(np.float64))).astype(np.uint8)
+    rec = dict(H=H, W=W, seed=1, t=np.float32(0.5), N=1, weight_seed=0,
+               St=fin[0][2][0].numpy(), flows_last=flows[-1][0].numpy(), occ_last=occs[-1][0].numpy(),
+               finals_u8=np.stack([u8(z[0]) for z in fin[0]]), d1_u8=np.stack([u8(z[0]) for z in d1]),
+               psnr_St_vs_B0=np.float64(U.psnr(np.around(U.denorm255_np(fin[0][2][0].numpy().astype(np.float64))),
+                                               np.around(U.denorm255_np(gt.astype(np.float64))))))
+    np.savez_compressed(os.path.join(OUT, 'cfg1_256x256_t0500_n1.npz'), **rec)
+    print('cfg1_256x256           oracle-vs-reference max|diff| = %.3e   psnr(St,B0) = %.4f dB' %
+          (max(float((a - b).abs().max()) for a, b in zip(fin[0], mine[1][0])), rec['psnr_St_vs_B0']))
+
+    # ---- uint8 conversions: loader (utils.py:224-238) and writer (utils.py:718-721 + main.py:1165-1178) ---------
+    g = np.random.RandomState(7)
+    frames = g.randint(0, 256, size=(4, 20, 28, 3)).astype(np.uint8)
+    frames[0, 0, :8, 0] = [0, 1, 2, 127, 128, 253, 254, 255]           # the end points and the middle, explicitly
+    ten = U.RGBframes_np2Tensor(frames, 3)                        # [3,T,h,w] fp32
+    assert torch.equal(ten, O.frames_u8_to_tensor(list(frames)))
+    # writer input: fp32 frames around every rounding boundary k/255 and outside [-1,1]
+    k = np.arange(0, 256, dtype=np.float64)
+    edge = (k / 255.0) * 2 - 1
+    vals = np.concatenate([edge, np.nextafter(edge, -9), np.nextafter(edge, 9), edge + 1e-4, edge - 1e-4,
+                           [-1.5, 1.5, -1.0000001, 1.0000001, 0.0, -0.0]]).astype(np.float32)
+    pred = np.resize(np.concatenate([vals, g.uniform(-1.1, 1.1, 3 * 20 * 28 - vals.size).astype(np.float32)]),
+                     (3, 20, 28)).astype(np.float32)
+    out_s = np.transpose(np.squeeze(U.denorm255_np(pred.astype(np.float64)[None])), [1, 2, 0]).astype(np.uint8)   # S0/S1 path
+    out_t = U.denorm255_np(np.transpose(pred.astype(np.float64), [1, 2, 0])[:, :, ::-1]).astype(np.uint8)[:, :, ::-1]   # St path
+    assert np.array_equal(out_s, out_t) and np.array_equal(out_s, O.frame_to_u8(pred))
+    np.savez_compressed(os.path.join(OUT, 'u8io_20x28.npz'), frames=frames, tensor=ten.numpy(), pred=pred, out_u8=out_s)
+    print('u8io                   loader / writer oracle helpers == reference: True')
+
+    # ---- evaluation: psnr (utils.py:652-660), ssim (utils.py:663-705) on np.around(denorm255_np(.)) frames --------
+    a = fin[0][2][0].numpy()[:, 40:136, 60:188]
+    b = np.clip(a + g.normal(0, 0.05, a.shape).astype(np.float32), -1.2, 1.2)
+    ia = np.around(U.denorm255_np(np.transpose(a.astype(np.float64), [1, 2, 0])))
+    ib = np.around(U.denorm255_np(np.transpose(b.astype(np.float64), [1, 2, 0])))
+    np.savez_compressed(os.path.join(OUT, 'metrics_96x128.npz'), a=a, b=b, psnr=np.float64(U.psnr(ia, ib)),
+                        ssim=np.float64(U.ssim(ia, ib)), psnr_same=np.float64(U.psnr(ia, ia)), ssim_same=np.float64(U.ssim(ia, ia)))
+    print('metrics                psnr %.6f dB  ssim %.8f' % (U.psnr(ia, ib), U.ssim(ia, ib)))
+
+
 if __name__ == '__main__':
-    main()
+    if '--round2' in sys.argv:
+        round2()
+    else:
+        main()
+        round2()
