@@ -10,6 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('DEMFI_HIP_LIB') or os.path.join(_HERE, 'csrc', 'libdemfi_hip.so')   # override: ablation builds
 
 F16, F32 = 0, 1
+ABI_VERSION = 2
 ACT_NONE, ACT_RELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3
 MODE_STORE, MODE_MUL, MODE_GRU = 0, 1, 2
 MAX_PIECES, MAX_CHUNKS, MAX_SEGS, MAX_OCTS = 48, 40, 8, 32
@@ -58,6 +59,7 @@ _SIGS = {
     'demfi_space_to_depth': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'demfi_reflect_pad': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'demfi_overlay_mean': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    'demfi_cfr_workspace_bytes': (C.c_int64, [C.c_int, C.c_int]),
     'demfi_cfr_flow_align': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p]),
     'demfi_warp_blend': (C.c_int, [C.POINTER(View), C.c_void_p, C.POINTER(View), C.c_void_p, C.c_void_p, C.c_void_p,
@@ -97,7 +99,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the library lacks a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.demfi_abi_version() != 1:
+    if lib.demfi_abi_version() != ABI_VERSION:
         raise RuntimeError('demfi_amd: ABI version mismatch')
     _lib = lib
     return lib

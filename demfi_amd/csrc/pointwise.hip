@@ -57,13 +57,61 @@ __global__ void overlay_kernel(const float* __restrict__ x, float* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------------
-// Forward splat of CFR (fwarp / sample_one, DeMFInet.py:625-729).  One thread per SOURCE pixel and flow.
-// acc layout: [flow k][3 = img0, img1, weight][H*W] int64, 2^-32 fixed point -> order-independent sums.
+// Forward splat of CFR (fwarp / sample_one, DeMFInet.py:625-729) + the linear combination / normalisation
+// (CFR_flow_t_align, 606-622).
+//
+// Sums are accumulated in 2^-32 fixed point (64-bit integers): exact, hence independent of the order of the adds and
+// bit-reproducible run to run (the reference's GPU path uses float atomics).  Round 1 did all 24 adds per source pixel
+// as device-scope atomics -- those bypass the XCD L2s and run at fabric rate (0.59 ms at 720p, 0.6 % of the HBM
+// roofline).  Now the work is partitioned by TARGET: one workgroup owns a CFR_TH x CFR_TW tile of target pixels, scans
+// the source pixels of the tile + a halo of CFR_R pixels, and accumulates the contributions that land in its tile with
+// LDS atomics (ds_add_u64); the finish (Eq. 614-620) runs from LDS and writes each output once.  No global accumulator
+// is touched on this path.  Exactness for arbitrary flows: a source whose scaled displacement has floor() outside
+// [-CFR_R, CFR_R-1] ("far", rare) cannot be seen by every tile it hits; cfr_far_kernel (one thread per source, which
+// also writes the debug index maps) adds exactly those sources into the global int64 planes and flags the target
+// tiles; a flagged tile adds its slice of the planes in the finish and leaves it zeroed.  near/far is a function of
+// the source value alone, so every source is counted exactly once.
 constexpr double FIX = 4294967296.0;
+constexpr int CFR_TH = 16, CFR_TW = 64, CFR_R = 32;
 
-__global__ void cfr_splat_kernel(const float* __restrict__ flow01, const float* __restrict__ flow10,
-                                 const float* __restrict__ tptr, int H, int W, long long* __restrict__ acc,
-                                 int* __restrict__ dbg)
+struct CfrSrc {
+    float v0, v1, fx, fy, x1, y1;
+    bool far_;
+};
+
+__device__ __forceinline__ CfrSrc cfr_source(const float* __restrict__ fl, int64_t hw, int64_t pix, float sc)
+{
+    CfrSrc s;
+    s.v0 = fl[pix];
+    s.v1 = fl[hw + pix];
+    s.fy = sc * s.v0;                                        // "y": column displacement (flo[:,0], 647)
+    s.fx = sc * s.v1;                                        // "x": row displacement    (flo[:,1], 648)
+    s.x1 = floorf(s.fx);
+    s.y1 = floorf(s.fy);
+    // !(a >= lo && a <= hi) is also true for NaN: such sources take the far path, whose range test drops them
+    s.far_ = !(s.x1 >= (float)-CFR_R && s.x1 <= (float)(CFR_R - 1) && s.y1 >= (float)-CFR_R && s.y1 <= (float)(CFR_R - 1));
+    return s;
+}
+
+// flat target index of corner cidx ((x1,y1) (x1,y2) (x2,y1) (x2,y2): 663-666) of a source at (y, x), -1 when masked (716)
+__device__ __forceinline__ int cfr_target(const CfrSrc& s, int cidx, int y, int x, int H, int W, float& w)
+{
+    const float xs = s.x1 + (float)(cidx >> 1), ys = s.y1 + (float)(cidx & 1);
+    const float dx = s.fx - xs, dy = s.fy - ys;
+    w = expf(-(dx * dx + dy * dy));                          // get_gaussian_weights, 674-680
+    if (fabsf(xs) < 1.0e9f && fabsf(ys) < 1.0e9f) {
+        const long long r = (long long)xs + y, c = (long long)ys + x;     // idxx / idxy, 712-713
+        if (r >= 0 && r < H && c >= 0 && c < W) return (int)(r * W + c);  // mask, 716
+    }
+    return -1;
+}
+
+__device__ __forceinline__ unsigned long long cfr_fix(float p) { return (unsigned long long)__double2ll_rn((double)p * FIX); }
+
+// One thread per SOURCE pixel and flow: debug index maps for every source, global accumulation for the far ones only.
+__global__ void cfr_far_kernel(const float* __restrict__ flow01, const float* __restrict__ flow10,
+                               const float* __restrict__ tptr, int H, int W, long long* __restrict__ acc,
+                               int* __restrict__ tile_flag, int* __restrict__ dbg)
 {
     const int64_t hw = (int64_t)H * W;
     const int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x;
@@ -72,65 +120,135 @@ __global__ void cfr_splat_kernel(const float* __restrict__ flow01, const float* 
     const int64_t pix = i - k * hw;
     const int y = (int)(pix / W), x = (int)(pix - (int64_t)y * W);
     const float t = *tptr;
-    const float sc = k == 0 ? t : 1.0f - t;                 // fwarp(flow_01, t*flow_01), fwarp(flow_10, (1-t)*flow_10)
-    const float* fl = k == 0 ? flow01 : flow10;
-    const float v0 = fl[pix], v1 = fl[hw + pix];
-    const float fy = sc * v0;                               // "y": column displacement (flo[:,0], 647)
-    const float fx = sc * v1;                               // "x": row displacement    (flo[:,1], 648)
-    const float x1 = floorf(fx), y1 = floorf(fy);
+    const CfrSrc s = cfr_source(k == 0 ? flow01 : flow10, hw, pix, k == 0 ? t : 1.0f - t);   // fwarp(f01, t f01), fwarp(f10, (1-t) f10)
+    if (!s.far_ && !dbg) return;
     long long* a = acc + (int64_t)k * 3 * hw;
+    const int tiles_x = (W + CFR_TW - 1) / CFR_TW;
 #pragma unroll
-    for (int cidx = 0; cidx < 4; ++cidx) {                  // (x1,y1) (x1,y2) (x2,y1) (x2,y2): 663-666
-        const float xs = x1 + (float)(cidx >> 1), ys = y1 + (float)(cidx & 1);
-        const float dx = fx - xs, dy = fy - ys;
-        const float w = expf(-(dx * dx + dy * dy));         // get_gaussian_weights, 674-680
-        int flat = -1;
-        if (fabsf(xs) < 1.0e9f && fabsf(ys) < 1.0e9f) {
-            const long long r = (long long)xs + y, c = (long long)ys + x;     // idxx / idxy, 712-713
-            if (r >= 0 && r < H && c >= 0 && c < W) flat = (int)(r * W + c);  // mask, 716
-        }
+    for (int cidx = 0; cidx < 4; ++cidx) {
+        float w;
+        const int flat = cfr_target(s, cidx, y, x, H, W, w);
         if (dbg) dbg[((int64_t)k * 4 + cidx) * hw + pix] = flat;
-        if (flat >= 0) {
-            const float p0 = v0 * w, p1 = v1 * w;           // flat_img * flat_weight (fp32), 724
-            atomicAdd((unsigned long long*)(a + flat), (unsigned long long)__double2ll_rn((double)p0 * FIX));
-            atomicAdd((unsigned long long*)(a + hw + flat), (unsigned long long)__double2ll_rn((double)p1 * FIX));
-            atomicAdd((unsigned long long*)(a + 2 * hw + flat), (unsigned long long)__double2ll_rn((double)w * FIX));
+        if (s.far_ && flat >= 0) {
+            atomicAdd((unsigned long long*)(a + flat), cfr_fix(s.v0 * w));             // flat_img * flat_weight (fp32), 724
+            atomicAdd((unsigned long long*)(a + hw + flat), cfr_fix(s.v1 * w));
+            atomicAdd((unsigned long long*)(a + 2 * hw + flat), cfr_fix(w));
+            const int r = flat / W, c = flat - r * W;
+            tile_flag[(r / CFR_TH) * tiles_x + c / CFR_TW] = 1;                        // benign race: every writer stores 1
         }
     }
 }
 
-// Linear combination + normalisation of CFR (DeMFInet.py:614-620), every op one fp32 rounding.
-__global__ void cfr_finish_kernel(long long* __restrict__ acc, const float* __restrict__ tptr, int64_t hw,
-                                  float* __restrict__ out)
+// One workgroup per TARGET tile: LDS accumulation of the near sources + finish (DeMFInet.py:614-620, one fp32 rounding
+// per op) + the far partial sums of flagged tiles.
+__global__ __launch_bounds__(NT) void cfr_tile_kernel(const float* __restrict__ flow01, const float* __restrict__ flow10,
+                                                      const float* __restrict__ tptr, int H, int W,
+                                                      long long* __restrict__ acc, int* __restrict__ tile_flag,
+                                                      float* __restrict__ out)
 {
-    const int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x;
-    if (i >= hw) return;
+    __shared__ unsigned long long lacc[6][CFR_TH * CFR_TW];       // [flow k][img0, img1, weight] -> 48 KiB
+    const int64_t hw = (int64_t)H * W;
+    const int tiles_x = (W + CFR_TW - 1) / CFR_TW;
+    const int ntile = tiles_x * ((H + CFR_TH - 1) / CFR_TH);
+    // XCD x = blockIdx & 7 owns a contiguous band of tiles: neighbouring tiles share their halos through one L2
+    const int per = (ntile + 7) >> 3;
+    const int tile = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if (tile >= ntile || (blockIdx.x >> 3) >= per) return;
+    const int ty0 = (tile / tiles_x) * CFR_TH, tx0 = (tile % tiles_x) * CFR_TW;
+    for (int i = threadIdx.x; i < 6 * CFR_TH * CFR_TW; i += NT) (&lacc[0][0])[i] = 0ull;
+    __syncthreads();
     const float t = *tptr;
     const float omt = 1.0f - t;
-    const double inv = 1.0 / FIX;
-    float f01[2], f10[2];
-    f01[0] = (float)((double)acc[i] * inv);
-    f01[1] = (float)((double)acc[hw + i] * inv);
-    const float n0 = (float)((double)acc[2 * hw + i] * inv);
-    f10[0] = (float)((double)acc[3 * hw + i] * inv);
-    f10[1] = (float)((double)acc[4 * hw + i] * inv);
-    const float n1 = (float)((double)acc[5 * hw + i] * inv);
-    // leave the accumulators zeroed for the next call (no memset node: under hipGraph replay a hipMemsetAsync
-    // captured between kernels was observed not to be ordered before the splat)
+    // scanned source window, clipped to the image
+    const int sy0 = max(ty0 - CFR_R, 0), sy1 = min(ty0 + CFR_TH + CFR_R, H);
+    const int sx0 = max(tx0 - CFR_R, 0), sx1 = min(tx0 + CFR_TW + CFR_R, W);
+    const int sw = sx1 - sx0, n = sw * (sy1 - sy0);
+    for (int k = 0; k < 2; ++k) {
+        const float* fl = k == 0 ? flow01 : flow10;
+        const float sc = k == 0 ? t : omt;
+        // 4 sources per thread and step: the 8 flow loads are issued together (the loop is latency-bound otherwise)
+        for (int i0 = threadIdx.x; i0 < n; i0 += 4 * NT) {
+            float v0[4], v1[4];
+            int yy[4], xx[4];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) acc[k * hw + i] = 0;
-    const float norm = omt * n0 + t * n1;                                   // 617
-    const float m = norm > 0.0f ? 1.0f : 0.0f;                              // 618
-    const float ca = (-omt) * t, cb = t * t, cc = omt * omt, cd = t * omt;
+            for (int u = 0; u < 4; ++u) {
+                const int i = min(i0 + u * NT, n - 1);
+                const int ry = i / sw;
+                yy[u] = sy0 + ry;
+                xx[u] = sx0 + (i - ry * sw);
+                const int64_t pix = (int64_t)yy[u] * W + xx[u];
+                v0[u] = fl[pix];
+                v1[u] = fl[hw + pix];
+            }
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        float ft0 = ca * f01[c] + cb * f10[c];                              // 614
-        float ft1 = cc * f01[c] - cd * f10[c];                              // 615
-        ft0 = (1.0f - m) * ft0 + m * (ft0 / (norm + (1.0f - m)));           // 619
-        ft1 = (1.0f - m) * ft1 + m * (ft1 / (norm + (1.0f - m)));           // 620
-        out[(int64_t)c * hw + i] = ft0;
-        out[(int64_t)(2 + c) * hw + i] = ft1;
+            for (int u = 0; u < 4; ++u) {
+                if (i0 + u * NT >= n) continue;
+                const int y = yy[u], x = xx[u];
+                CfrSrc s;
+                s.v0 = v0[u]; s.v1 = v1[u];
+                s.fy = sc * s.v0; s.fx = sc * s.v1;
+                s.x1 = floorf(s.fx); s.y1 = floorf(s.fy);
+                if (!(s.x1 >= (float)-CFR_R && s.x1 <= (float)(CFR_R - 1) && s.y1 >= (float)-CFR_R && s.y1 <= (float)(CFR_R - 1)))
+                    continue;                                                           // far: cfr_far_kernel's job
+                // rows y + x1 + {0,1}, columns x + y1 + {0,1}: skip sources whose 2x2 footprint misses the tile
+                const int r0 = y + (int)s.x1 - ty0, c0 = x + (int)s.y1 - tx0;
+                if (r0 < -1 || r0 >= CFR_TH || c0 < -1 || c0 >= CFR_TW) continue;
+#pragma unroll
+                for (int cidx = 0; cidx < 4; ++cidx) {
+                    const int r = r0 + (cidx >> 1), c = c0 + (cidx & 1);
+                    if (r < 0 || r >= CFR_TH || c < 0 || c >= CFR_TW) continue;
+                    if (ty0 + r >= H || tx0 + c >= W) continue;                         // mask (716); >= 0 holds inside a tile
+                    const float xs = s.x1 + (float)(cidx >> 1), ys = s.y1 + (float)(cidx & 1);
+                    const float dx = s.fx - xs, dy = s.fy - ys;
+                    const float w = expf(-(dx * dx + dy * dy));
+                    const int li = r * CFR_TW + c;
+                    atomicAdd(&lacc[3 * k + 0][li], cfr_fix(s.v0 * w));
+                    atomicAdd(&lacc[3 * k + 1][li], cfr_fix(s.v1 * w));
+                    atomicAdd(&lacc[3 * k + 2][li], cfr_fix(w));
+                }
+            }
+        }
     }
+    __syncthreads();
+    const bool flagged = tile_flag[tile] != 0;                   // written by cfr_far_kernel (previous launch on the stream)
+    const double inv = 1.0 / FIX;
+    for (int li = threadIdx.x; li < CFR_TH * CFR_TW; li += NT) {
+        const int r = li / CFR_TW, c = li - r * CFR_TW;
+        const int y = ty0 + r, x = tx0 + c;
+        if (y >= H || x >= W) continue;
+        const int64_t i = (int64_t)y * W + x;
+        long long a6[6];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) a6[q] = (long long)lacc[q][li];
+        if (flagged) {
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+                const long long g = acc[q * hw + i];
+                if (g != 0) { a6[q] += g; acc[q * hw + i] = 0; }  // leave the planes all-zero for the next call
+            }
+        }
+        float f01[2], f10[2];
+        f01[0] = (float)((double)a6[0] * inv);
+        f01[1] = (float)((double)a6[1] * inv);
+        const float n0 = (float)((double)a6[2] * inv);
+        f10[0] = (float)((double)a6[3] * inv);
+        f10[1] = (float)((double)a6[4] * inv);
+        const float n1 = (float)((double)a6[5] * inv);
+        const float norm = omt * n0 + t * n1;                                   // 617
+        const float m = norm > 0.0f ? 1.0f : 0.0f;                              // 618
+        const float ca = (-omt) * t, cb = t * t, cc = omt * omt, cd = t * omt;
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch) {
+            float ft0 = ca * f01[ch] + cb * f10[ch];                            // 614
+            float ft1 = cc * f01[ch] - cd * f10[ch];                            // 615
+            ft0 = (1.0f - m) * ft0 + m * (ft0 / (norm + (1.0f - m)));           // 619
+            ft1 = (1.0f - m) * ft1 + m * (ft1 / (norm + (1.0f - m)));           // 620
+            out[(int64_t)ch * hw + i] = ft0;
+            out[(int64_t)(2 + ch) * hw + i] = ft1;
+        }
+    }
+    __syncthreads();
+    if (flagged && threadIdx.x == 0) tile_flag[tile] = 0;
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -541,6 +659,13 @@ extern "C" int demfi_overlay_mean(const float* x, float* out, int H, int W, void
     return DEMFI_OK;
 }
 
+extern "C" int64_t demfi_cfr_workspace_bytes(int H, int W)
+{
+    if (H <= 0 || W <= 0) return 0;
+    const int64_t tiles = (int64_t)((W + CFR_TW - 1) / CFR_TW) * ((H + CFR_TH - 1) / CFR_TH);
+    return 6 * (int64_t)H * W * 8 + ((tiles * 4 + 255) & ~255ll);
+}
+
 extern "C" int demfi_cfr_flow_align(const float* flow01, const float* flow10, const float* t, int H, int W,
                                     int64_t* acc, float* out, int32_t* dbg_idx, void* stream)
 {
@@ -548,9 +673,12 @@ extern "C" int demfi_cfr_flow_align(const float* flow01, const float* flow10, co
         return demfi_set_error(DEMFI_ERR_ARG, "demfi_cfr_flow_align: bad args");
     hipStream_t st = (hipStream_t)stream;
     const int64_t hw = (int64_t)H * W;
-    hipLaunchKernelGGL(cfr_splat_kernel, dim3(blocks_for(2 * hw)), dim3(NT), 0, st, flow01, flow10, t, H, W,
-                       (long long*)acc, dbg_idx);
-    hipLaunchKernelGGL(cfr_finish_kernel, dim3(blocks_for(hw)), dim3(NT), 0, st, (long long*)acc, t, hw, out);
+    int* tile_flag = (int*)(acc + 6 * hw);                       // behind the six int64 planes (demfi_cfr_workspace_bytes)
+    hipLaunchKernelGGL(cfr_far_kernel, dim3(blocks_for(2 * hw)), dim3(NT), 0, st, flow01, flow10, t, H, W,
+                       (long long*)acc, tile_flag, dbg_idx);
+    const int ntile = ((W + CFR_TW - 1) / CFR_TW) * ((H + CFR_TH - 1) / CFR_TH);
+    hipLaunchKernelGGL(cfr_tile_kernel, dim3(8 * ((ntile + 7) / 8)), dim3(NT), 0, st, flow01, flow10, t, H, W,
+                       (long long*)acc, tile_flag, out);
     DEMFI_HIP_CHECK(hipGetLastError());
     return DEMFI_OK;
 }

@@ -415,7 +415,7 @@ class Engine(Plan):
         H2, W2, H4, W4, H8, W8 = H // 2, W // 2, H // 4, W // 4, H // 8, W // 8
         self.t_dev = torch.zeros((1,), dtype=torch.float32, device=self.device)
         self._keep.append(self.t_dev)
-        self.cfr_acc = torch.zeros((6 * H * W,), dtype=torch.int64, device=self.device)
+        self.cfr_acc = torch.zeros((self.lib.demfi_cfr_workspace_bytes(H, W) // 8,), dtype=torch.int64, device=self.device)
         self._keep.append(self.cfr_acc)
         self.ft = self._thin(4)                       # flow_t0, flow_t1
         self.Ft = self._fat(H, W, 64)

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DEMFI_ABI_VERSION 1
+#define DEMFI_ABI_VERSION 2
 
 enum demfi_dtype { DEMFI_F16 = 0, DEMFI_F32 = 1 };
 
@@ -177,12 +177,14 @@ int demfi_overlay_mean(const float* x, float* out, int H, int W, void* stream);
 
 /* CFR_flow_t_align (DeMFInet.py:606-622) = two forward splats (fwarp 625-671, sample_one 683-729) +
  * the linear combination / normalisation.  flow01, flow10: planar fp32 [2,H,W]; t: device pointer to
- * one fp32; acc: caller workspace of 6*H*W int64 that MUST be all-zero on entry (allocate it zeroed once) and is
- * left all-zero on exit; out: planar fp32 [4,H,W] =
+ * one fp32; acc: caller workspace of demfi_cfr_workspace_bytes(H, W) bytes (six int64 [H,W] planes + per-tile flags)
+ * that MUST be all-zero on entry (allocate it zeroed once) and is left all-zero on exit; out: planar fp32 [4,H,W] =
  * (flow_t0, flow_t1).  The splat accumulates in 64-bit fixed point (2^-32 resolution) so the result
- * does not depend on the order of the atomic adds.  dbg_idx (optional, may be NULL): int32
+ * does not depend on the order of the adds (LDS atomics per target tile; global atomics only for sources displaced
+ * by more than 32 px).  dbg_idx (optional, may be NULL): int32
  * [2 flows][4 corners][H*W] flat target index of every source pixel, -1 where masked off
  * (sample_one's ids / mask, DeMFInet.py:712-719) for the index-parity tests. */
+int64_t demfi_cfr_workspace_bytes(int H, int W);
 int demfi_cfr_flow_align(const float* flow01, const float* flow10, const float* t, int H, int W,
                          int64_t* acc, float* out, int32_t* dbg_idx, void* stream);
 

@@ -401,7 +401,7 @@ def test_cfr_vs_reference_goldens(golden_dir):
         f10 = torch.from_numpy(g['cfr%d_f10' % i]).to(DEV)
         tv = float(g['cfr%d_t' % i])
         t = torch.tensor([tv], device=DEV)
-        acc = torch.zeros(6 * H * W, dtype=torch.int64, device=DEV)
+        acc = torch.zeros(lib.demfi_cfr_workspace_bytes(H, W) // 8, dtype=torch.int64, device=DEV)
         out = torch.zeros(4, H, W, device=DEV)
         dbg = torch.zeros(2, 4, H * W, dtype=torch.int32, device=DEV)
         L.check(lib.demfi_cfr_flow_align(f01.data_ptr(), f10.data_ptr(), t.data_ptr(), H, W, acc.data_ptr(), out.data_ptr(),
@@ -428,7 +428,7 @@ def test_cfr_is_deterministic():
     t = torch.tensor([0.625], device=DEV)
     outs = []
     for _ in range(3):
-        acc = torch.zeros(6 * H * W, dtype=torch.int64, device=DEV)
+        acc = torch.zeros(lib.demfi_cfr_workspace_bytes(H, W) // 8, dtype=torch.int64, device=DEV)
         out = torch.zeros(4, H, W, device=DEV)
         L.check(lib.demfi_cfr_flow_align(f01.data_ptr(), f10.data_ptr(), t.data_ptr(), H, W, acc.data_ptr(), out.data_ptr(),
                                          None, _stream()))

@@ -129,7 +129,7 @@ def main():
     if case in ('cfr', 'all'):
         f01 = (torch.randn(2, H, W, device=DEV) * 8).contiguous()
         f10 = (torch.randn(2, H, W, device=DEV) * 8).contiguous()
-        acc = torch.zeros(6 * H * W, dtype=torch.int64, device=DEV)
+        acc = torch.zeros(lib.demfi_cfr_workspace_bytes(H, W) // 8, dtype=torch.int64, device=DEV)
         out = torch.zeros(4, H, W, device=DEV)
         t = torch.tensor([0.375], device=DEV)
         run = lambda: L.check(lib.demfi_cfr_flow_align(f01.data_ptr(), f10.data_ptr(), t.data_ptr(), H, W, acc.data_ptr(),
