@@ -47,6 +47,26 @@ class Conv(C.Structure):
                 ('lw_magic', C.c_uint32), ('_pad2', C.c_uint32)]
 
 
+class ConvSrc(C.Structure):
+    _fields_ = [('v', View), ('fat', C.c_int32), ('up_shift', C.c_int32), ('nch', C.c_int32), ('_pad', C.c_int32),
+                ('cin', C.POINTER(C.c_int32))]
+
+
+class ConvDst(C.Structure):
+    _fields_ = [('dst', View), ('res', View), ('aux', View), ('act', C.c_int32), ('mode', C.c_int32), ('scale', C.c_int32),
+                ('dy', C.c_int32), ('dx', C.c_int32), ('n', C.c_int32), ('couts', C.POINTER(C.c_int32))]
+
+
+class HParams(C.Structure):
+    _fields_ = [('nf', C.c_int32), ('scale_factor', C.c_int32), ('num_resb_facfb', C.c_int32), ('num_resb_dec', C.c_int32),
+                ('shared_fgac', C.c_int32), ('fgac_rr', C.c_int32), ('fgac_sr', C.c_int32), ('_pad', C.c_int32)]
+
+
+class Op(C.Structure):
+    _fields_ = [('kind', C.c_int32), ('conv', C.c_int32), ('nch', C.c_int32), ('_pad', C.c_int32), ('macs', C.c_int64),
+                ('a', View), ('b', View), ('o', View), ('p', C.c_void_p * 32), ('t', C.c_void_p), ('name', C.c_char * 64)]
+
+
 _SIGS = {
     'demfi_abi_version': (C.c_int, []),
     'demfi_last_error': (C.c_char_p, []),
@@ -71,6 +91,26 @@ _SIGS = {
     'demfi_pack_planes': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
     'demfi_u8_to_window': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     'demfi_frame_to_u8': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    'demfi_conv_build': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                   C.c_int, C.c_int, C.POINTER(ConvSrc), C.c_int, C.POINTER(ConvDst), C.c_int, C.POINTER(Conv),
+                                   C.c_void_p, C.POINTER(C.c_int64), C.c_void_p, C.POINTER(C.c_int32)]),
+    'demfi_ctx_create': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(HParams), C.c_int, C.c_int,
+                                   C.POINTER(C.c_void_p)]),
+    'demfi_ctx_destroy': (C.c_int, [C.c_void_p]),
+    'demfi_load_weight': (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int]),
+    'demfi_ctx_workspace_bytes': (C.c_int64, [C.c_void_p]),
+    'demfi_workspace_bytes': (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    'demfi_ctx_bind': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
+    'demfi_ctx_weight_region': (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    'demfi_ctx_buffer': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int32),
+                                   C.POINTER(C.c_int32)]),
+    'demfi_forward_trunk': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    'demfi_forward_t': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    'demfi_ctx_num_ops': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
+    'demfi_ctx_get_op': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Op)]),
+    'demfi_ctx_num_convs': (C.c_int, [C.c_void_p]),
+    'demfi_ctx_conv_desc': (C.POINTER(Conv), [C.c_void_p, C.c_int]),
+    'demfi_run_op': (C.c_int, [C.c_void_p, C.POINTER(Op), C.c_void_p]),
     'demfi_graph_begin': (C.c_int, [C.c_void_p]),
     'demfi_graph_end': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     'demfi_graph_launch': (C.c_int, [C.c_void_p, C.c_void_p]),

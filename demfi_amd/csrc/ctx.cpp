@@ -1,0 +1,1111 @@
+// Forward context of libdemfi_hip.so: the launch plan of the DeMFI-Net_rb inference forward behind the C ABI.
+//
+// Host logic only.  demfi_ctx_bind lays every activation buffer out inside ONE caller-owned workspace, repacks the
+// state_dict into MFMA fragment order (each layer once, shared by all contexts), builds one demfi_conv descriptor per
+// convolution call site and records the launch sequence of the kernels of conv.hip / pointwise.hip.
+//
+// The plan follows the data flow of DeMFInet.forward (/root/reference/DeMFInet.py:46-179) but not its execution shape:
+//   * every torch.cat is a multi-piece input of the consuming convolution (no concat buffers);
+//   * RDB dense blocks grow in place, LFF outputs land directly in the 1152-channel GFF input;
+//   * PixelShuffle / NN-upsample / tanh / sigmoid / ReLU / residual adds / GRU gate math are epilogues or fused loads;
+//   * the t-independent trunk (FF_RDB + FAC-FB, 37 % of the MACs) is its own segment;
+//   * Mixer.conv_ref1/2 do not depend on the recursion index and are hoisted out of the boosting loop.
+// Flows, occlusion logits and 3-channel frames stay fp32 planar ("thin"); features are NHWC in the path dtype ("fat").
+#include "common.h"
+#include <algorithm>
+#include <map>
+#include <string>
+#include <string.h>
+#include <vector>
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------------
+// convolution descriptor builder (shared by demfi_conv_build and the plan)
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int64_t LDS_BUDGET = 78 * 1024;      // general kernel: haloed tile + 2-tap weight ring, 2 workgroups per CU
+
+struct BuiltConv {
+    demfi_conv d;
+    std::vector<uint8_t> wpack;
+    std::vector<float> bias;
+    int64_t wbytes = 0;        // size of the packed weights (also set when only sizing)
+    int64_t macs = 0;
+};
+
+int build_conv(int dtype, int H, int W, int stride, int batch, const float* w, const float* bias, int cout, int cin, int kh,
+               int kw, const demfi_conv_src* srcs, int n_srcs, const demfi_conv_dst* dsts, int n_dsts, BuiltConv& out,
+               bool size_only, const char* name)
+{
+    if (dtype != DEMFI_F16 && dtype != DEMFI_F32) return demfi_set_error(DEMFI_ERR_ARG, "%s: dtype", name);
+    if (!srcs || !dsts || n_srcs <= 0 || n_dsts <= 0 || n_dsts > DEMFI_MAX_SEGS || (stride != 1 && stride != 2))
+        return demfi_set_error(DEMFI_ERR_ARG, "%s: sources / destinations / stride", name);
+    const int esz = dtype == DEMFI_F32 ? 4 : 2;
+    const int64_t LH = 7 * stride + kh, LW = 31 * stride + kw;
+    int n_oct = 0;
+    for (int i = 0; i < n_dsts; ++i) n_oct += (dsts[i].n + 7) / 8;
+    const int sub = (n_oct + 3) / 4;
+    const int nco = sub <= 5 ? sub : 4;
+    int rec = 128;
+    // the SepConvGRU layers (1x5 / 5x1 over two 64-channel NHWC pieces) run on their own persistent kernel, which wants
+    // the two pieces as two 64-channel chunks whatever the general kernel's LDS budget says
+    bool sep = esz == 2 && stride == 1 && ((kh == 1 && kw == 5) || (kh == 5 && kw == 1)) && n_srcs == 2 && (cout == 64 || cout == 128);
+    for (int i = 0; sep && i < n_srcs; ++i) sep = srcs[i].fat && srcs[i].nch == 64 && !srcs[i].up_shift;
+    while (!sep && rec > 32 && LH * LW * (rec + 16) + 2 * (rec / 32) * nco * 1024 > LDS_BUDGET) rec /= 2;
+
+    // ---- every original input channel must be fed exactly once ------------------------------------------------
+    {
+        std::vector<int> seen(cin, 0);
+        for (int i = 0; i < n_srcs; ++i)
+            for (int j = 0; j < srcs[i].nch; ++j) {
+                const int c = srcs[i].cin[j];
+                if (c >= cin) return demfi_set_error(DEMFI_ERR_ARG, "%s: input map names channel %d >= cin %d", name, c, cin);
+                if (c >= 0) seen[c]++;
+            }
+        for (int c = 0; c < cin; ++c)
+            if (seen[c] != 1) return demfi_set_error(DEMFI_ERR_ARG, "%s: input channel %d fed %d times", name, c, seen[c]);
+    }
+    // ---- pack the input pieces into chunks of <= rec bytes (fat pieces first: 16-byte aligned) -------------------
+    struct P { demfi_view v; int nch, lds_ch, up, fat; };
+    struct Ck { int first, n, nks; };
+    std::vector<P> pieces;
+    std::vector<Ck> chunks;
+    std::vector<int32_t> cin_map;
+    int first = 0, fill = 0;
+    const demfi_view null_view = {nullptr, 0, 0, 0, 0, 0, 0};
+    auto close_chunk = [&]() {
+        if (fill == 0) return;
+        const int padb = (32 - fill % 32) % 32;
+        if (padb) {
+            pieces.push_back({null_view, padb / esz, fill / esz, 0, 0});
+            cin_map.insert(cin_map.end(), padb / esz, -1);
+            fill += padb;
+        }
+        chunks.push_back({first, (int)pieces.size() - first, fill / 32});
+        first = (int)pieces.size();
+        fill = 0;
+    };
+    std::vector<int> order;
+    for (int i = 0; i < n_srcs; ++i) if (srcs[i].fat) order.push_back(i);
+    for (int i = 0; i < n_srcs; ++i) if (!srcs[i].fat) order.push_back(i);
+    for (int si : order) {
+        const demfi_conv_src& s = srcs[si];
+        const int selt = s.v.is_f32 ? 4 : 2;
+        int done = 0;
+        while (done < s.nch) {
+            if (fill >= rec) close_chunk();
+            const int room = (rec - fill) / esz;
+            int take;
+            if (s.fat) {
+                if (fill % 16) {
+                    const int padc = (16 - fill % 16) / esz;
+                    pieces.push_back({null_view, padc, fill / esz, 0, 0});
+                    cin_map.insert(cin_map.end(), padc, -1);
+                    fill += padc * esz;
+                    continue;
+                }
+                take = std::min(s.nch - done, room);
+                int vec = take * esz / 16;
+                if (vec == 0) { close_chunk(); continue; }
+                int p2 = 1;
+                while (p2 * 2 <= vec) p2 *= 2;                       // 1, 2, 4, 8 vectors per pixel
+                take = p2 * 16 / esz;
+            } else {
+                take = std::min(s.nch - done, room);
+            }
+            demfi_view v = s.v;
+            v.ptr = s.v.ptr ? (char*)s.v.ptr + (int64_t)done * s.v.sc * selt : nullptr;
+            pieces.push_back({v, take, fill / esz, s.up_shift, s.fat ? 1 : 0});
+            cin_map.insert(cin_map.end(), s.cin + done, s.cin + done + take);
+            fill += take * esz;
+            done += take;
+        }
+    }
+    close_chunk();
+    if ((int)chunks.size() > DEMFI_MAX_CHUNKS || (int)pieces.size() > DEMFI_MAX_PIECES)
+        return demfi_set_error(DEMFI_ERR_ARG, "%s: %d chunks / %d pieces", name, (int)chunks.size(), (int)pieces.size());
+    // ---- output routing ----------------------------------------------------------------------------------------
+    struct Oct { int seg, n, ch; };
+    std::vector<Oct> octs;
+    std::vector<int32_t> cout_map;
+    for (int si = 0; si < n_dsts; ++si) {
+        const demfi_conv_dst& ds = dsts[si];
+        for (int o = 0; o < ds.n; o += 8) {
+            const int k = std::min(8, ds.n - o);
+            octs.push_back({si, k, o});
+            for (int j = 0; j < 8; ++j) cout_map.push_back(j < k ? ds.couts[o + j] : -1);
+        }
+    }
+    {
+        std::vector<int> seen(cout, 0);
+        for (int c : cout_map) {
+            if (c >= cout) return demfi_set_error(DEMFI_ERR_ARG, "%s: output map names channel %d >= cout %d", name, c, cout);
+            if (c >= 0) seen[c]++;
+        }
+        for (int c = 0; c < cout; ++c)
+            if (seen[c] != 1) return demfi_set_error(DEMFI_ERR_ARG, "%s: output channel %d routed %d times", name, c, seen[c]);
+    }
+    const int cout_pad = (sub + nco - 1) / nco * nco * 32;
+    if (cout_pad > 256) return demfi_set_error(DEMFI_ERR_ARG, "%s: %d packed output channels > 256", name, cout_pad);
+    while ((int)octs.size() < cout_pad / 8) {
+        octs.push_back({0, 0, 0});
+        cout_map.insert(cout_map.end(), 8, -1);
+    }
+    // ---- weights / bias ----------------------------------------------------------------------------------------
+    std::vector<int32_t> nks;
+    for (auto& c : chunks) nks.push_back(c.nks);
+    int64_t nbytes = 0;
+    int st = demfi_pack_conv_weights(w, cout, cin, kh, kw, cin_map.data(), (int)cin_map.size(), nks.data(), (int)nks.size(),
+                                     cout_map.data(), cout_pad, nco, dtype, nullptr, &nbytes);
+    if (st < 0) return st;
+    out.wbytes = nbytes;
+    out.wpack.resize(size_only ? 0 : nbytes);
+    out.bias.assign(cout_pad, 0.0f);
+    if (!size_only) {
+        st = demfi_pack_conv_weights(w, cout, cin, kh, kw, cin_map.data(), (int)cin_map.size(), nks.data(), (int)nks.size(),
+                                     cout_map.data(), cout_pad, nco, dtype, out.wpack.data(), &nbytes);
+        if (st < 0) return st;
+        for (int i = 0; i < cout_pad; ++i)
+            if (cout_map[i] >= 0 && bias) out.bias[i] = bias[cout_map[i]];
+    }
+    // ---- descriptor ----------------------------------------------------------------------------------------------
+    demfi_conv& d = out.d;
+    memset(&d, 0, sizeof(d));
+    d.dtype = dtype; d.H = H; d.W = W;
+    d.inH = stride == 2 ? H * stride : H;
+    d.inW = stride == 2 ? W * stride : W;
+    d.kh = kh; d.kw = kw; d.stride = stride;
+    d.pad_y = stride == 2 ? 1 : kh / 2;
+    d.pad_x = stride == 2 ? 1 : kw / 2;
+    d.batch = batch; d.cout_pad = cout_pad; d.nco = nco; d.rec_bytes = rec;
+    d.n_chunks = (int)chunks.size(); d.n_pieces = (int)pieces.size(); d.n_segs = n_dsts;
+    const int taps = kh * kw;
+    int64_t tot_ks = 0;
+    for (int k : nks) tot_ks += k;
+    d.w_blk_stride = tot_ks * taps * nco * 64;
+    int64_t woff = 0;
+    for (size_t i = 0; i < chunks.size(); ++i) {
+        d.chunks[i].first_piece = chunks[i].first;
+        d.chunks[i].n_pieces = chunks[i].n;
+        d.chunks[i].nks = chunks[i].nks;
+        d.chunks[i].w_off = woff;
+        woff += (int64_t)chunks[i].nks * taps * nco * 64;
+    }
+    for (size_t i = 0; i < pieces.size(); ++i) {
+        d.pieces[i].v = pieces[i].v;
+        d.pieces[i].nch = pieces[i].nch;
+        d.pieces[i].lds_ch = pieces[i].lds_ch;
+        d.pieces[i].up_shift = pieces[i].up;
+        d.pieces[i].fat = pieces[i].fat;
+    }
+    for (int i = 0; i < n_dsts; ++i) {
+        demfi_seg& sg = d.segs[i];
+        sg.dst = dsts[i].dst; sg.res = dsts[i].res; sg.aux = dsts[i].aux;
+        sg.act = dsts[i].act; sg.mode = dsts[i].mode;
+        sg.scale = dsts[i].scale ? dsts[i].scale : 1;
+        sg.dy = dsts[i].dy; sg.dx = dsts[i].dx;
+    }
+    for (size_t i = 0; i < octs.size(); ++i) { d.oct_seg[i] = octs[i].seg; d.oct_n[i] = octs[i].n; d.oct_ch[i] = octs[i].ch; }
+    for (int sb = 0; sb < DEMFI_MAX_OCTS / 4; ++sb) d.sub_seg[sb] = -1;
+    const bool f32 = dtype == DEMFI_F32;
+    auto fat_ok = [&](const demfi_view& v) { return v.ptr && v.sc == 1 && (v.is_f32 != 0) == f32; };
+    for (int sb = 0; sb < cout_pad / 32; ++sb) {
+        const Oct* o4 = &octs[sb * 4];
+        const int si = o4[0].seg;
+        const demfi_conv_dst& ds = dsts[si];
+        bool ok = o4[0].ch % 8 == 0;
+        for (int j = 0; j < 4; ++j) ok = ok && o4[j].seg == si && o4[j].n == 8 && o4[j].ch == o4[0].ch + 8 * j;
+        ok = ok && fat_ok(ds.dst) && (!ds.res.ptr || fat_ok(ds.res));
+        if (ds.mode == DEMFI_MODE_GRU) ok = ok && fat_ok(ds.aux);
+        if (ds.mode != DEMFI_MODE_STORE) ok = ok && ds.res.ptr;
+        if (ok) d.sub_seg[sb] = si;
+    }
+    d.lw_magic = (uint32_t)((0x100000000ull + LW - 1) / LW);
+    out.macs = (int64_t)cout * cin * taps * H * W * batch;
+    return DEMFI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// the context
+// ---------------------------------------------------------------------------------------------------------------
+struct Tensor {
+    int64_t off = -1;
+    int kind = 0;              // 0 fat [B,h,w,C] path dtype, 1 thin [C,h,w] fp32, 2 raw int64
+    int d[4] = {0, 0, 0, 0};   // fat: B,h,w,C; thin: C,h,w,1; raw: n,1,1,1
+    int64_t bytes = 0;
+};
+
+struct Weight { std::vector<float> data; std::vector<int64_t> shape; };
+
+struct Layer { int cout, cin, kh, kw; };
+
+typedef std::map<std::string, Tensor> BufSet;
+typedef std::vector<demfi_op> OpList;
+
+}  // namespace
+
+struct demfi_ctx {
+    int H, W, N, dtype, n_trunk, n_ctx;
+    demfi_hparams hp;
+    std::map<std::string, Weight> weights;
+    std::map<std::string, Layer> table;
+    // layout (computed at create time: offsets are relative to the workspace base)
+    int64_t w_region = 0, w_bytes = 0, desc_off = 0, zero_off = 0, total = 0, n_descs = 0;
+    std::vector<BufSet> tr_bufs;                       // [trunk]
+    std::vector<std::vector<BufSet>> t_bufs;           // [trunk][c]
+    // after bind
+    bool bound = false, on_host = false;
+    char* base = nullptr;
+    std::vector<demfi_conv> descs;
+    std::vector<OpList> tr_ops;                        // [trunk]
+    std::vector<std::vector<OpList>> head_ops;         // [trunk][c]
+    std::vector<std::vector<std::vector<OpList>>> iter_ops;   // [trunk][c][it]
+    std::vector<uint8_t> host_blob;                    // packed weights + biases staged on the host
+    std::map<std::string, std::pair<int64_t, int64_t>> pack_cache;   // layer signature -> (w_off, b_off) inside the blob
+    int64_t blob_fill = 0;
+};
+
+namespace {
+
+int esz_of(const demfi_ctx* c) { return c->dtype == DEMFI_F32 ? 4 : 2; }
+
+void layer_table(demfi_ctx* c)
+{
+    // the reference's registration order and shapes (DeMFInet.py:15-44, 189-231, 319-333, 361-378, 566-584, 770-868;
+    // SURVEY.md Appendix A/B) -- mirrored by demfi_amd/spec.py for the module surface
+    auto& t = c->table;
+    const int nf = c->hp.nf, r2 = c->hp.scale_factor * c->hp.scale_factor;
+    const int G0 = 96, G = 32, Cn = 4, D = 12;
+    auto add = [&](const std::string& n, int cout, int cin, int kh, int kw) { t[n] = {cout, cin, kh, kw}; };
+    std::string p = "FF_RDB_Module.";
+    add(p + "SFENet1", G0, 12 * r2, 5, 5);
+    add(p + "SFENet2", G0, G0, 3, 3);
+    for (int i = 0; i < D; ++i) {
+        for (int k = 0; k < Cn; ++k) add(p + "RDBs." + std::to_string(i) + ".convs." + std::to_string(k) + ".conv.0", G, G0 + k * G, 3, 3);
+        add(p + "RDBs." + std::to_string(i) + ".LFF", G0, G0 + Cn * G, 1, 1);
+    }
+    add(p + "GFF.0", G0, D * G0, 1, 1);
+    add(p + "GFF.1", G0, G0, 3, 3);
+    add(p + "UPNet.0", 256, G0, 3, 3);
+    add(p + "UPNet.2", 2 * nf + 5, 64, 3, 3);
+    p = "FAC_FB_Module.";
+    add(p + "conv_first", nf, nf, 3, 3);
+    for (int i = 0; i < c->hp.num_resb_facfb; ++i) {
+        add(p + "feature_extraction." + std::to_string(i) + ".conv1", nf, nf, 3, 3);
+        add(p + "feature_extraction." + std::to_string(i) + ".conv2", nf, nf, 3, 3);
+    }
+    std::vector<std::string> fg = c->hp.shared_fgac ? std::vector<std::string>{"shared_FGAC"}
+                                                    : std::vector<std::string>{"FGAC_F1toF0", "FGAC_F0toF1"};
+    for (auto& f : fg) {
+        add(p + f + ".conv_ref_k", nf, nf, 1, 1);
+        add(p + f + ".conv_source_k", nf, nf, 1, 1);
+        add(p + f + ".w_gen", nf, 2 * nf, 3, 3);
+        add(p + f + ".w_gen_2", 1, nf, 3, 3);
+        add(p + f + ".fusion", nf, nf, 1, 1);
+    }
+    p = "Refine_Module.";
+    add(p + "enc1", nf, 3 * nf + 9, 4, 4);
+    add(p + "enc2", 2 * nf, nf, 4, 4);
+    add(p + "enc3", 4 * nf, 2 * nf, 4, 4);
+    add(p + "dec0", 4 * nf, 4 * nf, 3, 3);
+    add(p + "dec1", 2 * nf, 6 * nf, 3, 3);
+    add(p + "dec2", nf, 3 * nf, 3, 3);
+    add(p + "dec3", 2 * nf + 5, nf, 3, 3);
+    add("Dec_first", nf, nf, 3, 3);
+    for (int i = 0; i < c->hp.num_resb_dec; ++i) {
+        add("Decoder_res." + std::to_string(i) + ".conv1", nf, nf, 3, 3);
+        add("Decoder_res." + std::to_string(i) + ".conv2", nf, nf, 3, 3);
+    }
+    add("Dec_last1", nf, nf, 3, 3);
+    add("Dec_last2", 3, nf, 3, 3);
+    add("Ch_Reducer", nf, 3 * nf, 7, 7);
+    p = "Booster_Module.";
+    add(p + "Mixer.conv_ref1", nf / 2, 30, 7, 7);
+    add(p + "Mixer.conv_ref2", nf / 2, nf / 2, 3, 3);
+    add(p + "Mixer.conv_delta1", nf / 2, 5, 7, 7);
+    add(p + "Mixer.conv_delta2", nf / 2, nf / 2, 3, 3);
+    add(p + "Mixer.conv_blend1", nf / 2, nf, 3, 3);
+    add(p + "Mixer.conv_blend2", nf, nf / 2, 3, 3);
+    for (const char* g : {"z", "r", "q"}) add(p + "GB.conv" + g + "1", nf, 2 * nf, 1, 5);
+    for (const char* g : {"z", "r", "q"}) add(p + "GB.conv" + g + "2", nf, 2 * nf, 5, 1);
+    add(p + "flow_occ.conv1", nf / 2, nf, 3, 3);
+    add(p + "flow_occ.conv2", 5, nf / 2, 3, 3);
+    add("Dec_first_2", nf, 9 + nf + 9 + 5 + 12, 3, 3);
+    for (int i = 0; i < c->hp.num_resb_dec; ++i) {
+        add("Decoder_res_2." + std::to_string(i) + ".conv1", nf, nf, 3, 3);
+        add("Decoder_res_2." + std::to_string(i) + ".conv2", nf, nf, 3, 3);
+    }
+    add("Dec_last1_2", nf, nf, 3, 3);
+    add("Dec_last2_2", 9, nf, 3, 3);
+}
+
+// ---- buffer layout ---------------------------------------------------------------------------------------------
+struct Layout {
+    demfi_ctx* c;
+    int64_t cur;
+    int64_t take(int64_t bytes) { const int64_t o = cur; cur = (cur + bytes + 255) & ~255ll; return o; }
+    void fat(BufSet& s, const char* n, int h, int w, int ch, int b = 1)
+    {
+        Tensor t; t.kind = 0; t.d[0] = b; t.d[1] = h; t.d[2] = w; t.d[3] = ch;
+        t.bytes = (int64_t)b * h * w * ch * esz_of(c); t.off = take(t.bytes); s[n] = t;
+    }
+    void thin(BufSet& s, const char* n, int ch, int h, int w)
+    {
+        Tensor t; t.kind = 1; t.d[0] = ch; t.d[1] = h; t.d[2] = w; t.d[3] = 1;
+        t.bytes = (int64_t)ch * h * w * 4; t.off = take(t.bytes); s[n] = t;
+    }
+    void raw(BufSet& s, const char* n, int64_t bytes)
+    {
+        Tensor t; t.kind = 2; t.d[0] = (int)(bytes / 8); t.d[1] = t.d[2] = t.d[3] = 1;
+        t.bytes = bytes; t.off = take(bytes); s[n] = t;
+    }
+};
+
+void alloc_trunk(Layout& L, BufSet& s)
+{
+    const int H = L.c->H, W = L.c->W, H2 = H / 2, W2 = W / 2;
+    L.thin(s, "x", 12, H, W);                       // module input [3,4,H,W], batch 1
+    L.fat(s, "s2d", H2, W2, 48);
+    L.fat(s, "f1", H2, W2, 96);
+    L.fat(s, "x0", H2, W2, 96);
+    L.fat(s, "grow", H2, W2, 128);
+    L.fat(s, "gffcat", H2, W2, 1152);
+    L.fat(s, "g0", H2, W2, 96);
+    L.fat(s, "g1", H2, W2, 96);
+    L.fat(s, "up", H, W, 64);
+    L.fat(s, "F01", H, W, 64, 2);
+    L.thin(s, "ffo", 5, H, W);                      // flow_01 (2), flow_10 (2), occ_0 logit (1)
+    L.fat(s, "enc_a", H, W, 64, 2);
+    L.fat(s, "enc_t", H, W, 64, 2);
+    L.fat(s, "enc_b", H, W, 64, 2);
+    L.fat(s, "rk", H, W, 64, 2);
+    L.fat(s, "smp", H, W, 64, 2);
+    L.fat(s, "E", H, W, 64, 2);
+    L.fat(s, "wg", H, W, 64, 2);
+    L.thin(s, "gate", 2, H, W);
+    L.fat(s, "aF", H, W, 64, 2);
+    L.thin(s, "overlay", 3, H, W);
+}
+
+void alloc_t(Layout& L, BufSet& s)
+{
+    const int H = L.c->H, W = L.c->W, N = L.c->N;
+    const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4, H8 = H / 8, W8 = W / 8;
+    L.thin(s, "t", 1, 1, 1);
+    L.raw(s, "cfr_acc", demfi_cfr_workspace_bytes(H, W));
+    L.thin(s, "ft", 4, H, W);                       // flow_t0, flow_t1
+    L.fat(s, "Ft", H, W, 64);
+    L.fat(s, "u1", H2, W2, 64);
+    L.fat(s, "u2", H4, W4, 128);
+    L.fat(s, "u3", H8, W8, 256);
+    L.fat(s, "d0", H8, W8, 256);
+    L.fat(s, "d1", H4, W4, 128);
+    L.fat(s, "d2", H2, W2, 64);
+    L.fat(s, "rF", H, W, 64, 3);                    // rF0, rF1, rFt
+    L.thin(s, "delta", 5 * (N + 1), H, W);          // (flow_t0, flow_t1, occ logit) per step
+    L.thin(s, "occ", N + 1, H, W);                  // sigmoid(occ logit) per step
+    L.fat(s, "dec_a", H, W, 64, 3);
+    L.fat(s, "dec_t", H, W, 64, 3);
+    L.fat(s, "dec_b", H, W, 64, 3);
+    L.thin(s, "sharp1", 9, H, W);                   // S0p, S1p, Stp
+    L.fat(s, "frec0", H, W, 64);
+    L.fat(s, "frec1", H, W, 64);
+    L.fat(s, "re1", H, W, 32);
+    L.fat(s, "ref_enc", H, W, 32);
+    L.fat(s, "de1", H, W, 32);
+    L.fat(s, "de2", H, W, 32);
+    L.fat(s, "bl1", H, W, 32);
+    L.fat(s, "xb", H, W, 64);
+    L.fat(s, "zb", H, W, 64);
+    L.fat(s, "rh", H, W, 64);
+    L.fat(s, "h1", H, W, 64);
+    L.fat(s, "fo1", H, W, 32);
+    L.thin(s, "stnew", 3, H, W);
+    // planar flows / logits / frames packed to NHWC once, so the consuming convs stage them with vector loads
+    L.fat(s, "misc16", H, W, 16);
+    L.fat(s, "ref32", H, W, 32);
+    L.fat(s, "agg3s", H, W, 32);
+    L.fat(s, "agg3d", H, W, 8);
+    L.fat(s, "delta8", H, W, 8);
+    L.fat(s, "g_a", H, W, 64);
+    L.fat(s, "g_t", H, W, 64);
+    L.fat(s, "g_b", H, W, 64);
+    L.thin(s, "finals", 9 * N, H, W);               // [N][3 frames][3 colours]
+}
+
+void compute_layout(demfi_ctx* c, int64_t w_bytes, int64_t n_descs)
+{
+    Layout L{c, 0};
+    c->w_region = L.take(0);
+    c->w_bytes = (w_bytes + 255) & ~255ll;
+    L.take(c->w_bytes);
+    c->zero_off = L.take(256);
+    c->n_descs = n_descs;
+    c->desc_off = L.take(n_descs * (int64_t)sizeof(demfi_conv));
+    c->tr_bufs.assign(c->n_trunk, BufSet());
+    c->t_bufs.assign(c->n_trunk, std::vector<BufSet>(c->n_ctx));
+    for (int k = 0; k < c->n_trunk; ++k) {
+        alloc_trunk(L, c->tr_bufs[k]);
+        for (int q = 0; q < c->n_ctx; ++q) alloc_t(L, c->t_bufs[k][q]);
+    }
+    c->total = L.cur;
+}
+
+// ---- plan builder ----------------------------------------------------------------------------------------------
+struct Src { demfi_view v; int fat, up; std::vector<int32_t> cin; };
+struct Dst { demfi_view dst, res, aux; int act, mode, scale, dy, dx; std::vector<int32_t> couts; };
+
+std::vector<int32_t> range(int a, int b) { std::vector<int32_t> r; for (int i = a; i < b; ++i) r.push_back(i); return r; }
+const demfi_view NOVIEW = {nullptr, 0, 0, 0, 0, 0, 0};
+
+struct Builder {
+    demfi_ctx* c;
+    int esz;
+    bool f32;
+    bool dry;                  // sizing pass of demfi_ctx_create: no weights, nothing is written
+    int status = DEMFI_OK;
+
+    char* ptr(const Tensor& t) const { return c->base + t.off; }
+    // input piece from a fat buffer [B,h,w,C]: channels [c0, c0+nch) feed original cin [cin0, cin0+nch); b < 0 keeps the
+    // batch stride (batched conv), b >= 0 pins image b
+    Src fsrc(const Tensor& t, int cin0, int c0 = 0, int nch = -1, int b = -1, int up = 0) const
+    {
+        const int h = t.d[1], w = t.d[2], Ct = t.d[3];
+        if (nch < 0) nch = Ct - c0;
+        Src s;
+        s.v = {ptr(t) + ((int64_t)c0 + (b < 0 ? 0 : (int64_t)b * h * w * Ct)) * esz, Ct, (int64_t)w * Ct, 1,
+               b < 0 ? (int64_t)h * w * Ct : 0, f32 ? 1 : 0, 0};
+        s.fat = 1; s.up = up; s.cin = range(cin0, cin0 + nch);
+        return s;
+    }
+    // ALL channels of a fat buffer with an explicit channel -> original-cin list (-1 = unused padding channel)
+    Src fsrc_map(const Tensor& t, const std::vector<int32_t>& cin, int b = 0) const
+    {
+        const int h = t.d[1], w = t.d[2], Ct = t.d[3];
+        Src s;
+        s.v = {ptr(t) + (int64_t)b * h * w * Ct * esz, Ct, (int64_t)w * Ct, 1, 0, f32 ? 1 : 0, 0};
+        s.fat = 1; s.up = 0; s.cin = cin;
+        return s;
+    }
+    demfi_view fview(const Tensor& t, int c0 = 0, int b = -1) const
+    {
+        const int h = t.d[1], w = t.d[2], Ct = t.d[3];
+        return {ptr(t) + ((int64_t)c0 + (b < 0 ? 0 : (int64_t)b * h * w * Ct)) * esz, Ct, (int64_t)w * Ct, 1,
+                b < 0 ? (int64_t)h * w * Ct : 0, f32 ? 1 : 0, 0};
+    }
+    demfi_view tview(const Tensor& t, int c0 = 0, int64_t sb = 0) const
+    {
+        const int h = t.d[1], w = t.d[2];
+        return {ptr(t) + (int64_t)c0 * h * w * 4, 1, w, (int64_t)h * w, sb, 1, 0};
+    }
+    const float* plane(const Tensor& t, int ch) const { return (const float*)(ptr(t) + (int64_t)ch * t.d[1] * t.d[2] * 4); }
+    static Dst D(demfi_view v, std::vector<int32_t> couts, int act = DEMFI_ACT_NONE, int mode = DEMFI_MODE_STORE,
+                 demfi_view res = NOVIEW, demfi_view aux = NOVIEW, int scale = 1, int dy = 0, int dx = 0)
+    {
+        return Dst{v, res, aux, act, mode, scale, dy, dx, std::move(couts)};
+    }
+
+    int64_t blob_put(const void* p, int64_t n)
+    {
+        const int64_t off = c->blob_fill;
+        if (!dry) {
+            if (off + n > c->w_bytes) { status = demfi_set_error(DEMFI_ERR_ARG, "demfi_ctx_bind: weight region too small"); return 0; }
+            memcpy(c->host_blob.data() + off, p, n);
+        }
+        c->blob_fill = (off + n + 255) & ~255ll;
+        return off;
+    }
+
+    void conv(OpList& seg, const std::string& name, const std::vector<Src>& srcs, const std::vector<Dst>& dsts, int H, int W,
+              int stride = 1, int batch = 1, const std::vector<float>* wt = nullptr, const std::vector<float>* bs = nullptr,
+              const Layer* shape = nullptr)
+    {
+        if (status < 0) return;
+        Layer l;
+        const float *w, *b;
+        static const float dummy = 0.0f;
+        if (dry) {
+            if (shape) l = *shape;
+            else {
+                auto it = c->table.find(name);
+                if (it == c->table.end()) { status = demfi_set_error(DEMFI_ERR_ARG, "unknown layer '%s'", name.c_str()); return; }
+                l = it->second;
+            }
+            w = b = &dummy;
+        } else if (wt) { w = wt->data(); b = bs->data(); l = *shape; }
+        else {
+            auto it = c->table.find(name);
+            auto iw = c->weights.find(name + ".weight"), ib = c->weights.find(name + ".bias");
+            if (it == c->table.end() || iw == c->weights.end() || ib == c->weights.end()) {
+                status = demfi_set_error(DEMFI_ERR_ARG, "demfi_ctx_bind: weight '%s' was not loaded", name.c_str());
+                return;
+            }
+            l = it->second; w = iw->second.data.data(); b = ib->second.data.data();
+        }
+        std::vector<demfi_conv_src> cs(srcs.size());
+        for (size_t i = 0; i < srcs.size(); ++i) cs[i] = {srcs[i].v, srcs[i].fat, srcs[i].up, (int32_t)srcs[i].cin.size(), 0, srcs[i].cin.data()};
+        std::vector<demfi_conv_dst> cd(dsts.size());
+        for (size_t i = 0; i < dsts.size(); ++i)
+            cd[i] = {dsts[i].dst, dsts[i].res, dsts[i].aux, dsts[i].act, dsts[i].mode, dsts[i].scale, dsts[i].dy, dsts[i].dx,
+                     (int32_t)dsts[i].couts.size(), dsts[i].couts.data()};
+        // the packed blob of a call site depends on its channel maps only (not on buffer addresses): per-t contexts and
+        // the two FGAC directions share one copy
+        std::string sig = name + "|";
+        for (auto& s : srcs) { sig += s.fat ? 'F' : 'T'; for (int32_t ch : s.cin) sig += std::to_string(ch) + ","; sig += ';'; }
+        sig += "|";
+        for (auto& d : dsts) { for (int32_t ch : d.couts) sig += std::to_string(ch) + ","; sig += ';'; }
+        auto hit = c->pack_cache.find(sig);
+        BuiltConv bc;
+        status = build_conv(c->dtype, H, W, stride, batch, w, b, l.cout, l.cin, l.kh, l.kw, cs.data(), (int)cs.size(), cd.data(),
+                            (int)cd.size(), bc, dry || hit != c->pack_cache.end(), name.c_str());
+        if (status < 0) return;
+        int64_t w_off, b_off;
+        if (hit != c->pack_cache.end()) { w_off = hit->second.first; b_off = hit->second.second; }
+        else {
+            w_off = blob_put(bc.wpack.data(), bc.wbytes);
+            b_off = blob_put(bc.bias.data(), (int64_t)bc.bias.size() * 4);
+            if (status < 0) return;
+            c->pack_cache[sig] = {w_off, b_off};
+        }
+        bc.d.wpack = c->base + c->w_region + w_off;
+        bc.d.bias = (const float*)(c->base + c->w_region + b_off);
+        bc.d.zero_page = c->base + c->zero_off;
+        c->descs.push_back(bc.d);
+        demfi_op op;
+        memset(&op, 0, sizeof(op));
+        op.kind = DEMFI_OP_CONV;
+        op.conv = (int)c->descs.size() - 1;
+        op.macs = bc.macs;
+        strncpy(op.name, name.c_str(), sizeof(op.name) - 1);
+        seg.push_back(op);
+    }
+
+    void simple(OpList& seg, int kind, const char* name, demfi_op op)
+    {
+        op.kind = kind;
+        strncpy(op.name, name, sizeof(op.name) - 1);
+        seg.push_back(op);
+    }
+    static demfi_op blank() { demfi_op o; memset(&o, 0, sizeof(o)); return o; }
+
+    void pack(OpList& seg, const std::vector<const float*>& planes, const Tensor& dst)
+    {
+        demfi_op op = blank();
+        op.nch = dst.d[3];
+        for (int i = 0; i < 32; ++i) op.p[i] = i < (int)planes.size() ? planes[i] : nullptr;
+        op.o = fview(dst);
+        simple(seg, DEMFI_OP_PACK, "pack", op);
+    }
+
+    // x_{k+1} = x_k + conv2(relu(conv1(x_k))) ping-ponging between buffers a and b (t = scratch); returns the result buffer
+    const Tensor* resblocks(OpList& seg, const std::string& prefix, int n, const Tensor& a, const Tensor& t, const Tensor& b,
+                            int H, int W, int batch)
+    {
+        const Tensor *cur = &a, *other = &b;
+        for (int i = 0; i < n; ++i) {
+            const std::string p = prefix + "." + std::to_string(i);
+            conv(seg, p + ".conv1", {fsrc(*cur, 0)}, {D(fview(t), range(0, 64), DEMFI_ACT_RELU)}, H, W, 1, batch);
+            conv(seg, p + ".conv2", {fsrc(t, 0)}, {D(fview(*other), range(0, 64), DEMFI_ACT_NONE, DEMFI_MODE_STORE, fview(*cur))},
+                 H, W, 1, batch);
+            std::swap(cur, other);
+        }
+        return cur;
+    }
+
+    void build_trunk(int k)
+    {
+        BufSet& B = c->tr_bufs[k];
+        OpList& tr = c->tr_ops[k];
+        const int H = c->H, W = c->W, H2 = H / 2, W2 = W / 2;
+        const int R = DEMFI_ACT_RELU, T = DEMFI_ACT_TANH, S = DEMFI_ACT_SIGMOID;
+        const int64_t hw4 = (int64_t)H * W * 4;
+        // ============================ trunk: FF_RDB (DeMFInet.py:233-253) ==========================================
+        std::string p = "FF_RDB_Module.";
+        { demfi_op o = blank(); o.p[0] = ptr(B["x"]); o.p[1] = ptr(B["s2d"]); simple(tr, DEMFI_OP_S2D, "s2d", o); }
+        { demfi_op o = blank(); o.p[0] = ptr(B["x"]); o.p[1] = ptr(B["overlay"]); simple(tr, DEMFI_OP_OVERLAY, "overlay", o); }
+        conv(tr, p + "SFENet1", {fsrc(B["s2d"], 0)}, {D(fview(B["f1"]), range(0, 96))}, H2, W2);
+        conv(tr, p + "SFENet2", {fsrc(B["f1"], 0)}, {D(fview(B["x0"]), range(0, 96))}, H2, W2);
+        for (int i = 0; i < 12; ++i) {
+            auto xin = [&]() { return i == 0 ? fsrc(B["x0"], 0) : fsrc(B["gffcat"], 0, 96 * (i - 1), 96); };
+            const demfi_view xres = i == 0 ? fview(B["x0"]) : fview(B["gffcat"], 96 * (i - 1));
+            const std::string rp = p + "RDBs." + std::to_string(i);
+            for (int q = 0; q < 4; ++q) {
+                std::vector<Src> s{xin()};
+                if (q) s.push_back(fsrc(B["grow"], 96, 0, 32 * q));
+                conv(tr, rp + ".convs." + std::to_string(q) + ".conv.0", s, {D(fview(B["grow"], 32 * q), range(0, 32), R)}, H2, W2);
+            }
+            conv(tr, rp + ".LFF", {xin(), fsrc(B["grow"], 96, 0, 128)},
+                 {D(fview(B["gffcat"], 96 * i), range(0, 96), DEMFI_ACT_NONE, DEMFI_MODE_STORE, xres)}, H2, W2);
+        }
+        conv(tr, p + "GFF.0", {fsrc(B["gffcat"], 0)}, {D(fview(B["g0"]), range(0, 96))}, H2, W2);
+        conv(tr, p + "GFF.1", {fsrc(B["g0"], 0)}, {D(fview(B["g1"]), range(0, 96), DEMFI_ACT_NONE, DEMFI_MODE_STORE, fview(B["f1"]))}, H2, W2);
+        // UPNet.0 + PixelShuffle(2): out[c, 2h+i, 2w+j] = conv[c*4 + i*2 + j, h, w]
+        {
+            std::vector<Dst> ds;
+            for (int i = 0; i < 2; ++i)
+                for (int j = 0; j < 2; ++j) {
+                    std::vector<int32_t> co;
+                    for (int ch = 0; ch < 64; ++ch) co.push_back(ch * 4 + i * 2 + j);
+                    ds.push_back(D(fview(B["up"]), co, DEMFI_ACT_NONE, DEMFI_MODE_STORE, NOVIEW, NOVIEW, 2, i, j));
+                }
+            conv(tr, p + "UPNet.0", {fsrc(B["g1"], 0)}, ds, H2, W2);
+        }
+        conv(tr, p + "UPNet.2", {fsrc(B["up"], 0)},
+             {D(fview(B["F01"], 0, 0), range(0, 64), T), D(fview(B["F01"], 0, 1), range(64, 128), T), D(tview(B["ffo"]), range(128, 133))}, H, W);
+        // ============================ trunk: FAC-FB (DeMFInet.py:335-358, 386-452) ================================
+        p = "FAC_FB_Module.";
+        conv(tr, p + "conv_first", {fsrc(B["F01"], 0)}, {D(fview(B["enc_a"]), range(0, 64), R)}, H, W, 1, 2);
+        const Tensor* enc = resblocks(tr, p + "feature_extraction", c->hp.num_resb_facfb, B["enc_a"], B["enc_t"], B["enc_b"], H, W, 2);
+        B["enc"] = *enc;                                             // alias: the buffer holding the encoder output
+        for (int b = 0; b < 2; ++b) {          // b = 0: F1 -> F0 with flow_01 ; b = 1: F0 -> F1 with flow_10 (346-349)
+            const std::string fg = p + (c->hp.shared_fgac ? "shared_FGAC" : (b == 0 ? "FGAC_F1toF0" : "FGAC_F0toF1"));
+            const int ref = 1 - b, src = b;
+            conv(tr, fg + ".conv_ref_k", {fsrc(*enc, 0, 0, -1, ref)}, {D(fview(B["rk"], 0, b), range(0, 64))}, H, W);
+            {
+                demfi_op o = blank();
+                o.nch = 64;
+                o.a = fview(B["rk"], 0, b); o.o = fview(B["smp"], 0, b);
+                o.p[0] = ptr(B["ffo"]) + (b == 0 ? 0 : 2) * hw4;
+                simple(tr, DEMFI_OP_FGAC, "fgac", o);
+            }
+            conv(tr, fg + ".fusion", {fsrc(B["smp"], 0, 0, -1, b)}, {D(fview(B["E"], 0, b), range(0, 64))}, H, W);
+            conv(tr, fg + ".w_gen", {fsrc(*enc, 0, 0, -1, src), fsrc(B["E"], 64, 0, -1, b)}, {D(fview(B["wg"], 0, b), range(0, 64), R)}, H, W);
+            conv(tr, fg + ".w_gen_2", {fsrc(B["wg"], 0, 0, -1, b)}, {D(tview(B["gate"], b), {0}, S)}, H, W);
+            {
+                demfi_op o = blank();
+                o.nch = 64;
+                o.a = fview(*enc, 0, b); o.b = fview(B["E"], 0, b); o.o = fview(B["aF"], 0, b);
+                o.p[0] = ptr(B["gate"]) + b * hw4;
+                simple(tr, DEMFI_OP_GATE, "gate", o);
+            }
+        }
+    }
+
+    void warp(OpList& seg, const char* name, int C, demfi_view A, demfi_view Bv, demfi_view O, const void* fa, const void* fb,
+              const void* logit, const void* occ_out, const void* t)
+    {
+        demfi_op o = blank();
+        o.nch = C; o.a = A; o.b = Bv; o.o = O;
+        o.p[0] = fa; o.p[1] = fb; o.p[2] = logit; o.p[3] = occ_out; o.t = t;
+        simple(seg, DEMFI_OP_WARP, name, o);
+    }
+
+    void build_t(int k, int q)
+    {
+        BufSet& TB = c->tr_bufs[k];
+        BufSet& B = c->t_bufs[k][q];
+        OpList& th = c->head_ops[k][q];
+        const int H = c->H, W = c->W, N = c->N;
+        const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4, H8 = H / 8, W8 = W / 8;
+        const int R = DEMFI_ACT_RELU, T = DEMFI_ACT_TANH;
+        const int64_t hw4 = (int64_t)H * W * 4;
+        const Tensor& ffo = TB["ffo"];
+        const Tensor& aF = TB["aF"];
+        const Tensor& x = TB["x"];
+        const void* tp = ptr(B["t"]);
+        auto delta_v = [&](int step, int ch) { return tview(B["delta"], 5 * step + ch); };
+        auto delta_p = [&](int step, int ch) { return plane(B["delta"], 5 * step + ch); };
+        // ============================ per-t head: CFR, FWB, refinement, D1, Ch_Reducer ==============================
+        {
+            demfi_op o = blank();
+            o.p[0] = ptr(ffo); o.p[1] = ptr(ffo) + 2 * hw4; o.p[2] = ptr(B["cfr_acc"]); o.p[3] = ptr(B["ft"]); o.t = tp;
+            simple(th, DEMFI_OP_CFR, "cfr", o);
+        }
+        warp(th, "warp_fat", 64, fview(TB["F01"], 0, 0), fview(TB["F01"], 0, 1), fview(B["Ft"], 0, 0), ptr(B["ft"]), ptr(B["ft"]) + 2 * hw4,
+             ptr(ffo) + 4 * hw4, nullptr, tp);
+        std::string p = "Refine_Module.";
+        // Agg1 = cat[aF0, aF1, Ft, flow_t0, flow_t1, flow_01, flow_10, occ_0_logit] (DeMFInet.py:77)
+        {
+            std::vector<const float*> pl;
+            for (int i = 0; i < 4; ++i) pl.push_back(plane(B["ft"], i));
+            for (int i = 0; i < 5; ++i) pl.push_back(plane(ffo, i));
+            pack(th, pl, B["misc16"]);
+        }
+        {
+            std::vector<int32_t> m = range(192, 201);
+            m.insert(m.end(), 7, -1);
+            conv(th, p + "enc1", {fsrc(aF, 0, 0, -1, 0), fsrc(aF, 64, 0, -1, 1), fsrc(B["Ft"], 128), fsrc_map(B["misc16"], m)},
+                 {D(fview(B["u1"]), range(0, 64), R)}, H2, W2, 2);
+        }
+        conv(th, p + "enc2", {fsrc(B["u1"], 0)}, {D(fview(B["u2"]), range(0, 128), R)}, H4, W4, 2);
+        conv(th, p + "enc3", {fsrc(B["u2"], 0)}, {D(fview(B["u3"]), range(0, 256), R)}, H8, W8, 2);
+        conv(th, p + "dec0", {fsrc(B["u3"], 0)}, {D(fview(B["d0"]), range(0, 256), R)}, H8, W8);
+        conv(th, p + "dec1", {fsrc(B["d0"], 0, 0, -1, -1, 1), fsrc(B["u2"], 256)}, {D(fview(B["d1"]), range(0, 128), R)}, H4, W4);
+        conv(th, p + "dec2", {fsrc(B["d1"], 0, 0, -1, -1, 1), fsrc(B["u1"], 128)}, {D(fview(B["d2"]), range(0, 64), R)}, H2, W2);
+        // + cat[flow_t0, flow_t1, occ_0_logit, aF0, aF1] (78-80), tanh on the feature part (86-87)
+        conv(th, p + "dec3", {fsrc(B["d2"], 0, 0, -1, -1, 1)},
+             {D(fview(B["rF"], 0, 0), range(5, 69), T, DEMFI_MODE_STORE, fview(aF, 0, 0)),
+              D(fview(B["rF"], 0, 1), range(69, 133), T, DEMFI_MODE_STORE, fview(aF, 0, 1)),
+              D(delta_v(0, 0), range(0, 4), DEMFI_ACT_NONE, DEMFI_MODE_STORE, tview(B["ft"])),
+              D(delta_v(0, 4), {4}, DEMFI_ACT_NONE, DEMFI_MODE_STORE, tview(ffo, 4))}, H, W);
+        warp(th, "warp_fat", 64, fview(B["rF"], 0, 0), fview(B["rF"], 0, 1), fview(B["rF"], 0, 2), delta_p(0, 0), delta_p(0, 2),
+             delta_p(0, 4), plane(B["occ"], 0), tp);                 // rFt -> rF[2], occ[0]
+        // D1 on the three frames (Conv3d depth = batch), DeMFInet.py:95-101
+        conv(th, "Dec_first", {fsrc(B["rF"], 0)}, {D(fview(B["dec_a"]), range(0, 64), R)}, H, W, 1, 3);
+        const Tensor* cur = resblocks(th, "Decoder_res", c->hp.num_resb_dec, B["dec_a"], B["dec_t"], B["dec_b"], H, W, 3);
+        conv(th, "Dec_last1", {fsrc(*cur, 0)}, {D(fview(B["dec_t"]), range(0, 64), R)}, H, W, 1, 3);
+        conv(th, "Dec_last2", {fsrc(B["dec_t"], 0)}, {D(tview(B["sharp1"], 0, 3ll * H * W), range(0, 3))}, H, W, 1, 3);
+        conv(th, "Ch_Reducer", {fsrc(B["rF"], 0, 0, -1, 0), fsrc(B["rF"], 64, 0, -1, 1), fsrc(B["rF"], 128, 0, -1, 2)},
+             {D(fview(B["frec0"]), range(0, 64), T)}, H, W);
+        // Mixer reference branch (iteration-invariant, hoisted): cat[S0p,S1p,Stp,B0,B1,B-1,B2 | flow_10,flow_01 | t_ref]
+        p = "Booster_Module.";
+        std::vector<const float*> xpl;                              // B0, B1, B-1, B2 colour planes (cat order)
+        for (int f = 0; f < 4; ++f)
+            for (int col = 0; col < 3; ++col) xpl.push_back(plane(x, col * 4 + f));
+        {
+            std::vector<const float*> pl;
+            for (int i = 0; i < 9; ++i) pl.push_back(plane(B["sharp1"], i));
+            pl.insert(pl.end(), xpl.begin(), xpl.end());
+            for (int i : {2, 3, 0, 1}) pl.push_back(plane(ffo, i));
+            for (int i = 0; i < 5; ++i) pl.push_back(delta_p(0, i));
+            pack(th, pl, B["ref32"]);
+            std::vector<int32_t> m = range(0, 30);
+            m.insert(m.end(), 2, -1);
+            conv(th, p + "Mixer.conv_ref1", {fsrc_map(B["ref32"], m)}, {D(fview(B["re1"]), range(0, 32), R)}, H, W);
+        }
+        // iteration-invariant part of Agg3 (DeMFInet.py:151-155): S0p,S1p | occ_0 | rflow_t0,t1 | flow_10,flow_01 | frames
+        std::vector<int32_t> agg3s_cin = range(0, 6);
+        {
+            std::vector<const float*> pl;
+            for (int i = 0; i < 6; ++i) pl.push_back(plane(B["sharp1"], i));
+            pl.push_back(plane(B["occ"], 0));
+            for (int i = 0; i < 4; ++i) pl.push_back(delta_p(0, i));
+            for (int i : {2, 3, 0, 1}) pl.push_back(plane(ffo, i));
+            pl.insert(pl.end(), xpl.begin(), xpl.end());
+            pack(th, pl, B["agg3s"]);
+            agg3s_cin.push_back(73);
+            for (int i = 74; i < 82; ++i) agg3s_cin.push_back(i);
+            for (int i = 87; i < 99; ++i) agg3s_cin.push_back(i);
+            agg3s_cin.insert(agg3s_cin.end(), 5, -1);
+        }
+        conv(th, p + "Mixer.conv_ref2", {fsrc(B["re1"], 0)}, {D(fview(B["ref_enc"]), range(0, 32), R)}, H, W);
+        // ============================ recursive boosting, one list per iteration ====================================
+        // SepConvGRU (838-857): z | r share their input -> one 128-cout conv
+        std::vector<float> zrw[2], zrb[2];
+        const Layer zr_shape[2] = {{128, 128, 1, 5}, {128, 128, 5, 1}};
+        for (int s = 0; s < 2 && status >= 0 && !dry; ++s) {
+            const std::string sfx = std::to_string(s + 1);
+            for (const char* g : {"z", "r"}) {
+                auto iw = c->weights.find(p + "GB.conv" + g + sfx + ".weight"), ib = c->weights.find(p + "GB.conv" + g + sfx + ".bias");
+                if (iw == c->weights.end() || ib == c->weights.end()) {
+                    status = demfi_set_error(DEMFI_ERR_ARG, "demfi_ctx_bind: GRU weights were not loaded");
+                    return;
+                }
+                zrw[s].insert(zrw[s].end(), iw->second.data.begin(), iw->second.data.end());
+                zrb[s].insert(zrb[s].end(), ib->second.data.begin(), ib->second.data.end());
+            }
+        }
+        for (int it = 0; it < N; ++it) {
+            OpList& sg = c->iter_ops[k][q][it];
+            const Tensor& hin = B[it % 2 ? "frec1" : "frec0"];
+            const Tensor& hout = B[it % 2 ? "frec0" : "frec1"];
+            {
+                std::vector<const float*> pl;
+                for (int i = 0; i < 5; ++i) pl.push_back(delta_p(it, i));
+                pack(sg, pl, B["delta8"]);
+                std::vector<int32_t> m = range(0, 5);
+                m.insert(m.end(), 3, -1);
+                conv(sg, p + "Mixer.conv_delta1", {fsrc_map(B["delta8"], m)}, {D(fview(B["de1"]), range(0, 32), R)}, H, W);
+            }
+            conv(sg, p + "Mixer.conv_delta2", {fsrc(B["de1"], 0)}, {D(fview(B["de2"]), range(0, 32), R)}, H, W);
+            conv(sg, p + "Mixer.conv_blend1", {fsrc(B["ref_enc"], 0), fsrc(B["de2"], 32)}, {D(fview(B["bl1"]), range(0, 32), R)}, H, W);
+            conv(sg, p + "Mixer.conv_blend2", {fsrc(B["bl1"], 0)}, {D(fview(B["xb"]), range(0, 64), R)}, H, W);
+            const Tensor* h = &hin;
+            for (int s = 0; s < 2; ++s) {
+                const Tensor& hnext = s == 0 ? B["h1"] : hout;
+                const std::string sfx = std::to_string(s + 1);
+                conv(sg, p + "GB.convzr" + sfx, {fsrc(*h, 0), fsrc(B["xb"], 64)},
+                     {D(fview(B["zb"]), range(0, 64), DEMFI_ACT_SIGMOID),
+                      D(fview(B["rh"]), range(64, 128), DEMFI_ACT_NONE, DEMFI_MODE_MUL, fview(*h))}, H, W, 1, 1, &zrw[s], &zrb[s], &zr_shape[s]);
+                conv(sg, p + "GB.convq" + sfx, {fsrc(B["rh"], 0), fsrc(B["xb"], 64)},
+                     {D(fview(hnext), range(0, 64), DEMFI_ACT_NONE, DEMFI_MODE_GRU, fview(*h), fview(B["zb"]))}, H, W);
+                h = &hnext;
+            }
+            conv(sg, p + "flow_occ.conv1", {fsrc(hout, 0)}, {D(fview(B["fo1"]), range(0, 32), R)}, H, W);
+            conv(sg, p + "flow_occ.conv2", {fsrc(B["fo1"], 0)},
+                 {D(delta_v(it + 1, 0), range(0, 5), DEMFI_ACT_NONE, DEMFI_MODE_STORE, delta_v(it, 0))}, H, W);
+            warp(sg, "warp_thin", 3, tview(B["sharp1"], 0), tview(B["sharp1"], 3), tview(B["stnew"]), delta_p(it + 1, 0), delta_p(it + 1, 2),
+                 delta_p(it + 1, 4), plane(B["occ"], it + 1), tp);
+            // Agg3 (DeMFInet.py:151-155)
+            {
+                std::vector<const float*> pl;
+                for (int i = 0; i < 3; ++i) pl.push_back(plane(B["stnew"], i));
+                for (int i = 0; i < 4; ++i) pl.push_back(delta_p(it + 1, i));
+                pl.push_back(plane(B["occ"], it + 1));
+                pack(sg, pl, B["agg3d"]);
+            }
+            conv(sg, "Dec_first_2", {fsrc(hout, 9), fsrc_map(B["agg3s"], agg3s_cin), fsrc_map(B["agg3d"], {6, 7, 8, 82, 83, 84, 85, 86})},
+                 {D(fview(B["g_a"]), range(0, 64), R)}, H, W);
+            const Tensor* g = resblocks(sg, "Decoder_res_2", c->hp.num_resb_dec, B["g_a"], B["g_t"], B["g_b"], H, W, 1);
+            conv(sg, "Dec_last1_2", {fsrc(*g, 0)}, {D(fview(B["g_t"]), range(0, 64), R)}, H, W);
+            conv(sg, "Dec_last2_2", {fsrc(B["g_t"], 0)},
+                 {D(tview(B["finals"], 9 * it + 0), range(0, 3), DEMFI_ACT_NONE, DEMFI_MODE_STORE, tview(B["sharp1"], 0)),
+                  D(tview(B["finals"], 9 * it + 3), range(3, 6), DEMFI_ACT_NONE, DEMFI_MODE_STORE, tview(B["sharp1"], 3)),
+                  D(tview(B["finals"], 9 * it + 6), range(6, 9), DEMFI_ACT_NONE, DEMFI_MODE_STORE, tview(B["stnew"]))}, H, W);
+        }
+    }
+};
+
+int run_builder(demfi_ctx* c, bool dry)
+{
+    c->blob_fill = 0;
+    c->descs.clear();
+    c->pack_cache.clear();
+    c->tr_ops.assign(c->n_trunk, OpList());
+    c->head_ops.assign(c->n_trunk, std::vector<OpList>(c->n_ctx));
+    c->iter_ops.assign(c->n_trunk, std::vector<std::vector<OpList>>(c->n_ctx, std::vector<OpList>(c->N)));
+    Builder b{c, esz_of(c), c->dtype == DEMFI_F32, dry};
+    for (int k = 0; k < c->n_trunk && b.status >= 0; ++k) {
+        b.build_trunk(k);
+        for (int q = 0; q < c->n_ctx && b.status >= 0; ++q) b.build_t(k, q);
+    }
+    return b.status;
+}
+
+int run_ops(demfi_ctx* c, const OpList& ops, void* stream)
+{
+    for (const demfi_op& op : ops) {
+        const int st = demfi_run_op(c, &op, stream);
+        if (st < 0) return st;
+    }
+    return DEMFI_OK;
+}
+
+bool check_idx(const demfi_ctx* c, int trunk, int q)
+{
+    return c && trunk >= 0 && trunk < c->n_trunk && q >= 0 && q < c->n_ctx;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" int demfi_conv_build(int dtype, int H, int W, int stride, int batch, const float* w, const float* bias, int cout, int cin,
+                                int kh, int kw, const demfi_conv_src* srcs, int n_srcs, const demfi_conv_dst* dsts, int n_dsts,
+                                demfi_conv* desc, void* wpack, int64_t* wpack_bytes, float* bias_packed, int32_t* cout_pad)
+{
+    if (!w || !desc || !wpack_bytes || !cout_pad || H <= 0 || W <= 0 || batch <= 0 || cout <= 0 || cin <= 0 || kh <= 0 || kw <= 0)
+        return demfi_set_error(DEMFI_ERR_ARG, "demfi_conv_build: bad arguments");
+    BuiltConv bc;
+    const bool size_only = wpack == nullptr;
+    int st = build_conv(dtype, H, W, stride, batch, w, bias, cout, cin, kh, kw, srcs, n_srcs, dsts, n_dsts, bc, size_only, "demfi_conv_build");
+    if (st < 0) return st;
+    *cout_pad = bc.d.cout_pad;
+    if (size_only) {
+        *wpack_bytes = bc.wbytes;
+        *desc = bc.d;
+        return DEMFI_OK;
+    }
+    *wpack_bytes = (int64_t)bc.wpack.size();
+    memcpy(wpack, bc.wpack.data(), bc.wpack.size());
+    if (bias_packed) memcpy(bias_packed, bc.bias.data(), bc.bias.size() * 4);
+    *desc = bc.d;
+    return DEMFI_OK;
+}
+
+extern "C" int demfi_ctx_create(int H, int W, int max_updates, int dtype, const demfi_hparams* hp, int n_trunk, int n_ctx, demfi_ctx** out)
+{
+    if (!out) return demfi_set_error(DEMFI_ERR_ARG, "demfi_ctx_create: null out");
+    if (H <= 0 || W <= 0 || H % 8 || W % 8)
+        return demfi_set_error(DEMFI_ERR_ARG, "DeMFI-Net needs H, W multiples of 8 (the harness pads to 32): got %dx%d", H, W);
+    if (max_updates < 1 || max_updates > 64 || (dtype != DEMFI_F16 && dtype != DEMFI_F32) || n_trunk < 1 || n_ctx < 1 || n_trunk > 8 || n_ctx > 16)
+        return demfi_set_error(DEMFI_ERR_ARG, "demfi_ctx_create: max_updates / dtype / context counts");
+    demfi_hparams h = {64, 2, 5, 5, 1, 0, 0, 0};
+    if (hp) h = *hp;
+    if (h.nf != 64 || h.scale_factor != 2)
+        return demfi_set_error(DEMFI_ERR_ARG, "the HIP path is built for nf=64, scale_factor=2 (the released configuration)");
+    if (h.num_resb_facfb < 0 || h.num_resb_dec < 0 || h.num_resb_facfb > 32 || h.num_resb_dec > 32)
+        return demfi_set_error(DEMFI_ERR_ARG, "demfi_ctx_create: residual block counts");
+    if (h.fgac_rr != 0 || h.fgac_sr != 0)
+        return demfi_set_error(DEMFI_ERR_ARG, "demfi_ctx_create: the plan runs the released point-wise FGAC (rr = sr = 0, DeMFInet.py:401-402); "
+                                              "the generalised window kernel is exposed as demfi_fgac_window");
+    demfi_ctx* c = new demfi_ctx();
+    c->H = H; c->W = W; c->N = max_updates; c->dtype = dtype; c->n_trunk = n_trunk; c->n_ctx = n_ctx; c->hp = h;
+    layer_table(c);
+    // sizing pass: lay the buffers out, walk the plan without weights to learn the exact size of the packed blob and the
+    // number of descriptors, then lay everything out for real
+    compute_layout(c, 0, 0);
+    int st = run_builder(c, true);
+    if (st < 0) { delete c; return st; }
+    compute_layout(c, c->blob_fill, (int64_t)c->descs.size());
+    c->descs.clear();
+    *out = c;
+    return DEMFI_OK;
+}
+
+extern "C" int demfi_ctx_destroy(demfi_ctx* c)
+{
+    delete c;
+    return DEMFI_OK;
+}
+
+extern "C" int demfi_load_weight(demfi_ctx* c, const char* name, const float* host, const int64_t* shape, int ndim)
+{
+    if (!c || !name || !host || !shape || ndim < 1 || ndim > 5) return demfi_set_error(DEMFI_ERR_ARG, "demfi_load_weight: bad arguments");
+    if (c->bound) return demfi_set_error(DEMFI_ERR_ARG, "demfi_load_weight: context already bound (create a new one to change weights)");
+    std::string n(name);
+    const bool is_w = n.size() > 7 && n.compare(n.size() - 7, 7, ".weight") == 0;
+    const bool is_b = n.size() > 5 && n.compare(n.size() - 5, 5, ".bias") == 0;
+    if (!is_w && !is_b) return demfi_set_error(DEMFI_ERR_ARG, "demfi_load_weight: '%s' is neither a .weight nor a .bias key", name);
+    const std::string layer = n.substr(0, n.size() - (is_w ? 7 : 5));
+    auto it = c->table.find(layer);
+    if (it == c->table.end()) return demfi_set_error(DEMFI_ERR_ARG, "demfi_load_weight: unknown state_dict key '%s'", name);
+    const Layer& l = it->second;
+    int64_t numel = 1;
+    for (int i = 0; i < ndim; ++i) numel *= shape[i];
+    bool ok;
+    if (is_b) ok = ndim == 1 && shape[0] == l.cout;
+    else if (ndim == 4) ok = shape[0] == l.cout && shape[1] == l.cin && shape[2] == l.kh && shape[3] == l.kw;
+    else ok = ndim == 5 && shape[0] == l.cout && shape[1] == l.cin && shape[2] == 1 && shape[3] == l.kh && shape[4] == l.kw;   // Conv3d (1,k,k)
+    if (!ok) return demfi_set_error(DEMFI_ERR_ARG, "demfi_load_weight: shape of '%s' does not match [%d,%d,%d,%d]", name, l.cout, l.cin, l.kh, l.kw);
+    Weight& w = c->weights[n];
+    w.data.assign(host, host + numel);
+    w.shape.assign(shape, shape + ndim);
+    return DEMFI_OK;
+}
+
+extern "C" int64_t demfi_ctx_workspace_bytes(const demfi_ctx* c) { return c ? c->total : 0; }
+
+extern "C" int64_t demfi_workspace_bytes(int H, int W, int max_updates, int dtype, int n_trunk, int n_ctx)
+{
+    demfi_ctx* c = nullptr;
+    if (demfi_ctx_create(H, W, max_updates, dtype, nullptr, n_trunk, n_ctx, &c) < 0) return -1;
+    const int64_t n = c->total;
+    delete c;
+    return n;
+}
+
+extern "C" int demfi_ctx_bind(demfi_ctx* c, void* workspace, int64_t bytes, int on_host, void* stream)
+{
+    if (!c || !workspace) return demfi_set_error(DEMFI_ERR_ARG, "demfi_ctx_bind: null argument");
+    if (c->bound) return demfi_set_error(DEMFI_ERR_ARG, "demfi_ctx_bind: already bound");
+    if (bytes < c->total) return demfi_set_error(DEMFI_ERR_ARG, "demfi_ctx_bind: workspace of %lld B < %lld B", (long long)bytes, (long long)c->total);
+    if (((uintptr_t)workspace) & 255) return demfi_set_error(DEMFI_ERR_ARG, "demfi_ctx_bind: workspace must be 256-byte aligned");
+    c->base = (char*)workspace;
+    c->on_host = on_host != 0;
+    c->host_blob.assign(c->w_bytes, 0);
+    const int st = run_builder(c, false);
+    if (st < 0) return st;
+    const int64_t desc_bytes = (int64_t)c->descs.size() * (int64_t)sizeof(demfi_conv);
+    if ((int64_t)c->descs.size() != c->n_descs || c->blob_fill > c->w_bytes)
+        return demfi_set_error(DEMFI_ERR_ARG, "demfi_ctx_bind: plan differs from the sizing pass (%d descriptors, %lld B of weights)",
+                               (int)c->descs.size(), (long long)c->blob_fill);
+    if (c->on_host) {
+        memcpy(c->base + c->w_region, c->host_blob.data(), c->w_bytes);
+        memcpy(c->base + c->desc_off, c->descs.data(), desc_bytes);
+    } else {
+        hipStream_t st = (hipStream_t)stream;
+        DEMFI_HIP_CHECK(hipMemcpyAsync(c->base + c->w_region, c->host_blob.data(), c->w_bytes, hipMemcpyHostToDevice, st));
+        DEMFI_HIP_CHECK(hipMemcpyAsync(c->base + c->desc_off, c->descs.data(), desc_bytes, hipMemcpyHostToDevice, st));
+        DEMFI_HIP_CHECK(hipStreamSynchronize(st));
+    }
+    c->host_blob.clear();
+    c->host_blob.shrink_to_fit();
+    c->weights.clear();                                          // the fp32 copies are not needed once packed
+    c->bound = true;
+    return DEMFI_OK;
+}
+
+extern "C" int demfi_ctx_weight_region(const demfi_ctx* c, int64_t* offset, int64_t* bytes)
+{
+    if (!c || !offset || !bytes) return demfi_set_error(DEMFI_ERR_ARG, "demfi_ctx_weight_region: null argument");
+    *offset = c->w_region;
+    *bytes = c->w_bytes;
+    return DEMFI_OK;
+}
+
+extern "C" int demfi_ctx_buffer(const demfi_ctx* c, int trunk, int q, const char* name, int64_t* offset, int32_t* kind, int32_t dims[4])
+{
+    if (!c || !name || !offset || trunk < 0 || trunk >= c->n_trunk || q < -1 || q >= c->n_ctx)
+        return demfi_set_error(DEMFI_ERR_ARG, "demfi_ctx_buffer: bad arguments");
+    const BufSet& s = q < 0 ? c->tr_bufs[trunk] : c->t_bufs[trunk][q];
+    auto it = s.find(name);
+    if (it == s.end()) return demfi_set_error(DEMFI_ERR_ARG, "demfi_ctx_buffer: no buffer '%s' in %s context", name, q < 0 ? "the trunk" : "the per-t");
+    *offset = it->second.off;
+    if (kind) *kind = it->second.kind;
+    if (dims) for (int i = 0; i < 4; ++i) dims[i] = it->second.d[i];
+    return DEMFI_OK;
+}
+
+extern "C" int demfi_forward_trunk(demfi_ctx* c, int trunk, const float* x, void* stream)
+{
+    if (!c || !c->bound || c->on_host || trunk < 0 || trunk >= c->n_trunk)
+        return demfi_set_error(DEMFI_ERR_ARG, "demfi_forward_trunk: context not bound to device memory / bad trunk index");
+    const Tensor& xb = c->tr_bufs[trunk]["x"];
+    if (x && (const char*)x != c->base + xb.off)
+        DEMFI_HIP_CHECK(hipMemcpyAsync(c->base + xb.off, x, xb.bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return run_ops(c, c->tr_ops[trunk], stream);
+}
+
+extern "C" int demfi_forward_t(demfi_ctx* c, int trunk, int q, int n_updates, void* stream)
+{
+    if (!c || !c->bound || c->on_host || !check_idx(c, trunk, q))
+        return demfi_set_error(DEMFI_ERR_ARG, "demfi_forward_t: context not bound to device memory / bad context index");
+    if (n_updates < 1 || n_updates > c->N)
+        return demfi_set_error(DEMFI_ERR_ARG, "num_update=%d outside 1..%d the context was built for", n_updates, c->N);
+    int st = run_ops(c, c->head_ops[trunk][q], stream);
+    for (int it = 0; it < n_updates && st >= 0; ++it) st = run_ops(c, c->iter_ops[trunk][q][it], stream);
+    return st;
+}
+
+static const OpList* seg_ops(const demfi_ctx* c, int segment, int trunk, int q, int iter)
+{
+    if (!c || !c->bound || trunk < 0 || trunk >= c->n_trunk) return nullptr;
+    if (segment == DEMFI_SEG_TRUNK) return &c->tr_ops[trunk];
+    if (q < 0 || q >= c->n_ctx) return nullptr;
+    if (segment == DEMFI_SEG_T_HEAD) return &c->head_ops[trunk][q];
+    if (segment == DEMFI_SEG_ITER && iter >= 0 && iter < c->N) return &c->iter_ops[trunk][q][iter];
+    return nullptr;
+}
+
+extern "C" int demfi_ctx_num_ops(const demfi_ctx* c, int segment, int trunk, int q, int iter)
+{
+    const OpList* o = seg_ops(c, segment, trunk, q, iter);
+    if (!o) return demfi_set_error(DEMFI_ERR_ARG, "demfi_ctx_num_ops: bad segment / context (or context not bound)");
+    return (int)o->size();
+}
+
+extern "C" int demfi_ctx_get_op(const demfi_ctx* c, int segment, int trunk, int q, int iter, int index, demfi_op* out)
+{
+    const OpList* o = seg_ops(c, segment, trunk, q, iter);
+    if (!o || !out || index < 0 || index >= (int)o->size()) return demfi_set_error(DEMFI_ERR_ARG, "demfi_ctx_get_op: bad arguments");
+    *out = (*o)[index];
+    return DEMFI_OK;
+}
+
+extern "C" int demfi_ctx_num_convs(const demfi_ctx* c) { return c ? (int)c->descs.size() : 0; }
+
+extern "C" const demfi_conv* demfi_ctx_conv_desc(const demfi_ctx* c, int index)
+{
+    if (!c || index < 0 || index >= (int)c->descs.size()) return nullptr;
+    return &c->descs[index];
+}
+
+extern "C" int demfi_run_op(demfi_ctx* c, const demfi_op* op, void* stream)
+{
+    if (!c || !op || !c->bound || c->on_host) return demfi_set_error(DEMFI_ERR_ARG, "demfi_run_op: context not bound to device memory");
+    const int H = c->H, W = c->W;
+    switch (op->kind) {
+    case DEMFI_OP_CONV:
+        if (op->conv < 0 || op->conv >= (int)c->descs.size()) return demfi_set_error(DEMFI_ERR_ARG, "demfi_run_op: descriptor index");
+        return demfi_conv2d(&c->descs[op->conv], (const demfi_conv*)(c->base + c->desc_off) + op->conv, stream);
+    case DEMFI_OP_PACK:
+        return demfi_pack_planes((const float* const*)op->p, op->nch, op->o.ptr, c->dtype, op->o.sx, H, W, stream);
+    case DEMFI_OP_S2D:
+        return demfi_space_to_depth((const float*)op->p[0], (void*)op->p[1], c->dtype, H, W, stream);
+    case DEMFI_OP_OVERLAY:
+        return demfi_overlay_mean((const float*)op->p[0], (float*)op->p[1], H, W, stream);
+    case DEMFI_OP_FGAC:
+        return demfi_fgac_gather(&op->a, (const float*)op->p[0], &op->o, op->nch, H, W, nullptr, stream);
+    case DEMFI_OP_GATE:
+        return demfi_gate_blend((const float*)op->p[0], &op->a, &op->b, &op->o, op->nch, H, W, stream);
+    case DEMFI_OP_CFR:
+        return demfi_cfr_flow_align((const float*)op->p[0], (const float*)op->p[1], (const float*)op->t, H, W, (int64_t*)op->p[2],
+                                    (float*)op->p[3], nullptr, stream);
+    case DEMFI_OP_WARP:
+        return demfi_warp_blend(&op->a, (const float*)op->p[0], &op->b, (const float*)op->p[1], (const float*)op->p[2],
+                                (const float*)op->t, &op->o, op->nch, H, W, (float*)op->p[3], nullptr, stream);
+    }
+    return demfi_set_error(DEMFI_ERR_ARG, "demfi_run_op: unknown op kind %d", op->kind);
+}

@@ -224,6 +224,104 @@ int demfi_pack_planes(const float* const* planes, int nch, void* dst, int dtype,
 int demfi_u8_to_window(const uint8_t* const* frames, int h, int w, float* x, int H, int W, void* stream);
 int demfi_frame_to_u8(const float* frame, uint8_t* out, int h, int w, int H, int W, void* stream);
 
+/* ---- convolution descriptor builder (host only) ---------------------------------------------------
+ * The ONE implementation of the layout logic behind demfi_conv: packs the logical input-channel concatenation
+ * (replaces torch.cat) into LDS chunks, routes output channels to destination slices, repacks the weights.
+ * Two-call pattern: with wpack == NULL only *wpack_bytes and *cout_pad are written. */
+typedef struct demfi_conv_src {
+    demfi_view v;           /* first channel of the piece                                               */
+    int32_t fat;            /* 1: NHWC view of the path dtype (vector loads), 0: generic (planar fp32 ...) */
+    int32_t up_shift;       /* 1: read through a nearest-neighbour x2 upsample                          */
+    int32_t nch;            /* channels of the piece                                                    */
+    int32_t _pad;
+    const int32_t* cin;     /* [nch] original input channel of each channel, -1 = unused (zero weights)  */
+} demfi_conv_src;
+
+typedef struct demfi_conv_dst {
+    demfi_view dst, res, aux;   /* res / aux: ptr == NULL when absent                                   */
+    int32_t act, mode, scale, dy, dx;
+    int32_t n;              /* output channels routed to this destination                               */
+    const int32_t* couts;   /* [n] original output channel of channel j of the destination slice        */
+} demfi_conv_dst;
+
+/* desc: filled except wpack / bias / zero_page (the caller places the blobs and sets the pointers).
+ * wpack: *wpack_bytes bytes; bias_packed: *cout_pad floats. H, W: OUTPUT size. */
+int demfi_conv_build(int dtype, int H, int W, int stride, int batch, const float* w_oihw, const float* bias,
+                     int cout, int cin, int kh, int kw, const demfi_conv_src* srcs, int n_srcs,
+                     const demfi_conv_dst* dsts, int n_dsts, demfi_conv* desc, void* wpack, int64_t* wpack_bytes,
+                     float* bias_packed, int32_t* cout_pad);
+
+/* ---- forward context: the launch plan of DeMFInet.forward (DeMFInet.py:46-179) behind the C ABI -------
+ * A context owns NO device memory: the caller allocates demfi_workspace_bytes() bytes (zero-filled) and binds them.
+ * Inside the workspace: [packed weights + biases (one flat blob: the buffer a multi-GPU launch may broadcast) |
+ * descriptors | n_trunk trunk buffer sets | n_trunk * n_ctx per-t buffer sets].  n_trunk / n_ctx > 1 build
+ * independent buffer sets so that a scheduler can overlap the trunk of window w+1 with the time instants of window w,
+ * and several time instants of one window on different streams (results do not depend on it).
+ * Re-entrant per context; one context per (GPU, frame size, dtype). */
+typedef struct demfi_ctx demfi_ctx;
+
+typedef struct demfi_hparams {           /* DeMFInet.py:17-21, 32, 42, 326, 328; main.py:88-101 defaults */
+    int32_t nf;                          /* 64 (only value the kernels are built for)                    */
+    int32_t scale_factor;                /* 2                                                            */
+    int32_t num_resb_facfb;              /* 5                                                            */
+    int32_t num_resb_dec;                /* 5                                                            */
+    int32_t shared_fgac;                 /* 1                                                            */
+    int32_t fgac_rr, fgac_sr;            /* 0, 0: the radii hard-coded at DeMFInet.py:401-402 (generalised FGAC when > 0) */
+    int32_t _pad;
+} demfi_hparams;
+
+enum demfi_op_kind {
+    DEMFI_OP_CONV = 0, DEMFI_OP_PACK = 1, DEMFI_OP_S2D = 2, DEMFI_OP_OVERLAY = 3, DEMFI_OP_FGAC = 4, DEMFI_OP_GATE = 5,
+    DEMFI_OP_CFR = 6, DEMFI_OP_WARP = 7, DEMFI_OP_FGAC_WINDOW = 8
+};
+enum demfi_segment { DEMFI_SEG_TRUNK = 0, DEMFI_SEG_T_HEAD = 1, DEMFI_SEG_ITER = 2 };
+
+/* One launch of the plan (introspection for tests / per-launch profiling; pointers are already bound). */
+typedef struct demfi_op {
+    int32_t kind;           /* demfi_op_kind                                                             */
+    int32_t conv;           /* CONV: descriptor index (demfi_ctx_conv_desc)                              */
+    int32_t nch;            /* PACK: channels (multiple of 8); WARP / FGAC / GATE: C                     */
+    int32_t _pad;
+    int64_t macs;           /* CONV: algorithmic multiply-accumulates of the launch                      */
+    demfi_view a, b, o;     /* WARP: A, B, out; FGAC: src, -, out; GATE: source, e, out; PACK: o = dst     */
+    const void* p[32];      /* PACK: plane pointers; WARP: fa, fb, logit, occ_out; FGAC: flow; GATE: w;
+                               CFR: flow01, flow10, acc, out; S2D / OVERLAY: x, out; all: t where needed  */
+    const void* t;          /* device fp32 time instant (CFR, WARP)                                      */
+    char name[64];
+} demfi_op;
+
+int     demfi_ctx_create(int H, int W, int max_updates, int dtype, const demfi_hparams* hp /* NULL = defaults */,
+                         int n_trunk, int n_ctx, demfi_ctx** out);
+int     demfi_ctx_destroy(demfi_ctx* ctx);
+/* name: state_dict key ("FF_RDB_Module.SFENet1.weight" ...), host fp32, shape as in the state_dict (Conv3d weights
+ * [cout,cin,1,3,3] accepted).  All 260 (270 non-shared) tensors must be loaded before demfi_ctx_bind. */
+int     demfi_load_weight(demfi_ctx* ctx, const char* name, const float* host, const int64_t* shape, int ndim);
+int64_t demfi_ctx_workspace_bytes(const demfi_ctx* ctx);
+/* Size without a context: same number as a context created with these arguments reports. */
+int64_t demfi_workspace_bytes(int H, int W, int max_updates, int dtype, int n_trunk, int n_ctx);
+/* Builds the plan into `workspace` (device memory, zero-filled by the caller; on_host != 0: host memory, nothing is
+ * launched -- the CPU plan tests) and uploads weights + descriptors on `stream` (synchronises it before returning). */
+int     demfi_ctx_bind(demfi_ctx* ctx, void* workspace, int64_t bytes, int on_host, void* stream);
+/* Region of the workspace holding the packed weights (offset, bytes): identical on every rank after a broadcast. */
+int     demfi_ctx_weight_region(const demfi_ctx* ctx, int64_t* offset, int64_t* bytes);
+/* Named buffer of trunk context `trunk` / per-t context `c` (c = -1: trunk buffers): byte offset inside the workspace,
+ * element kind (0 path dtype NHWC [B,h,w,C], 1 fp32 planar [C,h,w], 2 int64 raw) and dims[4].  Names: "x" (input
+ * [3,4,H,W] fp32), "overlay", "ffo"; per-t: "t", "sharp1" (S0',S1',St' = D1 frames, 9 planes), "finals" ([N][3 frames][3]),
+ * "delta" ([N+1][5]: flow_t0, flow_t1, occ logit), "occ" ([N+1]) ... every buffer of the plan is addressable. */
+int     demfi_ctx_buffer(const demfi_ctx* ctx, int trunk, int c, const char* name, int64_t* offset, int32_t* kind,
+                         int32_t dims[4]);
+/* t-independent segment (FF_RDB + FAC-FB, DeMFInet.py:59, 74) of trunk context `trunk`; x: device fp32 [3,4,H,W]
+ * copied into the context's input buffer first, or NULL when the caller already filled buffer "x". */
+int     demfi_forward_trunk(demfi_ctx* ctx, int trunk, const float* x, void* stream);
+/* per-t segment (DeMFInet.py:63-165) of per-t context c reading trunk context `trunk`; t is read from buffer "t". */
+int     demfi_forward_t(demfi_ctx* ctx, int trunk, int c, int n_updates, void* stream);
+/* introspection / per-launch execution */
+int     demfi_ctx_num_ops(const demfi_ctx* ctx, int segment, int trunk, int c, int iter);
+int     demfi_ctx_get_op(const demfi_ctx* ctx, int segment, int trunk, int c, int iter, int index, demfi_op* out);
+int     demfi_ctx_num_convs(const demfi_ctx* ctx);
+const demfi_conv* demfi_ctx_conv_desc(const demfi_ctx* ctx, int index);          /* host copy */
+int     demfi_run_op(demfi_ctx* ctx, const demfi_op* op, void* stream);
+
 /* ---- hipGraph capture of a launch sequence ------------------------------------------------------ */
 int demfi_graph_begin(void* stream);
 int demfi_graph_end(void* stream, void** graph_exec_out);

@@ -1,10 +1,10 @@
-"""CPU interpreter of an Engine launch plan  --  TEST INFRASTRUCTURE (not shipped, not a fallback).
+"""CPU interpreter of a launch plan  --  TEST INFRASTRUCTURE (not shipped, not a fallback).
 
-Builds nothing itself: it takes an ``Engine`` constructed on CPU tensors (same descriptors, same packed
-weight blob the GPU would get) and *interprets* every ``demfi_conv`` descriptor and pointwise op with
-torch CPU ops, following the semantics documented in include/demfi_hip.h.  Purpose: check the host logic
-(channel maps, chunking, weight repack, output routing, buffer wiring of demfi_amd/engine.py) against the
-oracle without a GPU, so that a mismatch on the GPU box isolates the HIP kernels.
+Builds nothing itself: it takes an ``Engine`` whose context was bound to HOST memory (``device='cpu'``: same descriptors,
+same packed weight blob the GPU would get, built by the C++ planner in demfi_amd/csrc/ctx.cpp) or a ``Plan`` on CPU
+tensors, and *interprets* every ``demfi_conv`` descriptor and pointwise op with torch CPU ops, following the semantics
+documented in include/demfi_hip.h.  Purpose: check the host logic (channel maps, chunking, weight repack, output
+routing, buffer wiring) against the oracle without a GPU, so that a mismatch on the GPU box isolates the HIP kernels.
 """
 import ctypes as C
 
@@ -13,6 +13,7 @@ import torch
 import torch.nn.functional as F
 
 from demfi_amd import _lib as L
+from demfi_amd.engine import SEG_TRUNK, SEG_HEAD, SEG_ITER
 from oracle import demfi_oracle as O
 
 
@@ -20,8 +21,7 @@ class PlanSim:
     def __init__(self, eng):
         self.e = eng
         self.reg = []
-        extra = [getattr(eng, n) for n in ('x', 't_dev', 'weight_blob') if hasattr(eng, n)]
-        for t in list(eng._keep) + extra:
+        for t in eng.regions():
             self.reg.append((t.data_ptr(), t.numel() * t.element_size(), t))
 
     # ---- raw memory access through device-pointer arithmetic ----------------------------------------
@@ -133,57 +133,58 @@ class PlanSim:
                 out.copy_(v.to(out.dtype))
 
     # ---- whole segments ---------------------------------------------------------------------------------
+    def planes(self, ptr, n, H, W):
+        return self.strided(L.View(ptr, 1, W, H * W, 0, 1, 0), n, H, W)
+
     def run(self, ops):
         e = self.e
         H, W = e.H, e.W
+        f32 = e.f32
         for op in ops:
-            k = op[0]
-            if k == 'conv':
-                self.conv(e._descs[op[1]])
-            elif k == 'pack':
-                _, arr, dst, nch = op
-                for c in range(nch):
-                    if arr[c] is None:
-                        dst[0, :, :, c] = 0
+            k = op.kind
+            if k == 0:
+                self.conv(e.conv_desc(op.conv))
+            elif k == 1:                                                   # pack planar fp32 planes -> NHWC slice
+                dst = self.strided(op.o, op.nch, H, W)
+                for c in range(op.nch):
+                    if op.p[c] is None:
+                        dst[c] = 0
                     else:
-                        v = L.View(arr[c], 1, W, H * W, 0, 1, 0)
-                        dst[0, :, :, c] = self.strided(v, 1, H, W)[0].to(dst.dtype)
-            elif k == 's2d':
-                x = e.x                                                   # [3,4,H,W] -> frames-major 12 planes
+                        dst[c] = self.planes(op.p[c], 1, H, W)[0].to(dst.dtype)
+            elif k == 2:                                                   # s2d: x [3,4,H,W] -> [H/2,W/2,48]
+                x = self.planes(op.p[0], 12, H, W).view(3, 4, H, W)
                 cat = x.permute(1, 0, 2, 3).reshape(1, 12, H, W)
-                e.s2d[0].copy_(O.space_to_depth(cat, 2)[0].permute(1, 2, 0).to(e.dtype))
-            elif k == 'overlay':
-                e.overlay.copy_(torch.mean(e.x[:, 0:2], dim=1))
-            elif k == 'fgac':
-                b = op[1]
-                rk = e.rk[b].permute(2, 0, 1)[None].float()
-                fl = e.ffo[0:2] if b == 0 else e.ffo[2:4]
-                e.smp[b].copy_(O.fgac_sample(rk, fl[None])[0].permute(1, 2, 0).to(e.dtype))
-            elif k == 'gate':
-                b = op[1]
-                g = e.gate[b][..., None]
-                e.aF[b].copy_((g * e.enc[b].float() + (1 - g) * e.E[b].float()).to(e.dtype))
-            elif k == 'cfr':
-                t = e.t_dev.view(1, 1, 1, 1)
-                a, bb = O.cfr_flow_align(e.ffo[None, 0:2], e.ffo[None, 2:4], t)
-                e.ft[0:2].copy_(a[0])
-                e.ft[2:4].copy_(bb[0])
-            elif k == 'warp_fat':
-                _, buf, ba, bb, flows, lbuf, lch, obuf, ob, occ_i = op
-                t = e.t_dev.view(1, 1, 1, 1)
-                A = buf[ba].permute(2, 0, 1)[None].float()
-                B = buf[bb].permute(2, 0, 1)[None].float()
-                r = O.warp_blend(A, flows[None, 0:2], B, flows[None, 2:4], lbuf[None, lch:lch + 1], t)
-                obuf[ob or 0].copy_(r[0].permute(1, 2, 0).to(e.dtype))
-                if occ_i is not None:
-                    e.occ[occ_i].copy_(torch.sigmoid(lbuf[lch]))
-            elif k == 'warp_thin':
-                it = op[1]
-                dn = e.delta[it + 1]
-                t = e.t_dev.view(1, 1, 1, 1)
-                r = O.warp_blend(e.sharp1[None, 0:3], dn[None, 0:2], e.sharp1[None, 3:6], dn[None, 2:4], dn[None, 4:5], t)
-                e.stnew.copy_(r[0])
-                e.occ[it + 1].copy_(torch.sigmoid(dn[4]))
+                out = self.strided(L.View(op.p[1], 48, (W // 2) * 48, 1, 0, 1 if f32 else 0, 0), 48, H // 2, W // 2)
+                out.copy_(O.space_to_depth(cat, 2)[0].to(out.dtype))
+            elif k == 3:                                                   # overlay
+                x = self.planes(op.p[0], 12, H, W).view(3, 4, H, W)
+                self.planes(op.p[1], 3, H, W).copy_(torch.mean(x[:, 0:2], dim=1))
+            elif k == 4:                                                   # fgac gather
+                rk = self.strided(op.a, op.nch, H, W).float()[None]
+                fl = self.planes(op.p[0], 2, H, W)
+                out = self.strided(op.o, op.nch, H, W)
+                out.copy_(O.fgac_sample(rk, fl[None])[0].to(out.dtype))
+            elif k == 5:                                                   # gate blend
+                g = self.planes(op.p[0], 1, H, W)
+                s_, e_ = self.strided(op.a, op.nch, H, W).float(), self.strided(op.b, op.nch, H, W).float()
+                out = self.strided(op.o, op.nch, H, W)
+                out.copy_((g * s_ + (1 - g) * e_).to(out.dtype))
+            elif k == 6:                                                   # CFR
+                t = self.planes(op.t, 1, 1, 1).view(1, 1, 1, 1)
+                a, bb = O.cfr_flow_align(self.planes(op.p[0], 2, H, W)[None], self.planes(op.p[1], 2, H, W)[None], t)
+                out = self.planes(op.p[3], 4, H, W)
+                out[0:2].copy_(a[0])
+                out[2:4].copy_(bb[0])
+            elif k == 7:                                                   # warp + blend
+                t = self.planes(op.t, 1, 1, 1).view(1, 1, 1, 1)
+                A = self.strided(op.a, op.nch, H, W).float()[None]
+                B = self.strided(op.b, op.nch, H, W).float()[None]
+                lg = self.planes(op.p[2], 1, H, W)
+                r = O.warp_blend(A, self.planes(op.p[0], 2, H, W)[None], B, self.planes(op.p[1], 2, H, W)[None], lg[None], t)
+                out = self.strided(op.o, op.nch, H, W)
+                out.copy_(r[0].to(out.dtype))
+                if op.p[3] is not None:
+                    self.planes(op.p[3], 1, H, W).copy_(torch.sigmoid(lg))
             else:
                 raise AssertionError(k)
 
@@ -191,10 +192,10 @@ class PlanSim:
         e = self.e
         e.x.copy_(x[0])
         e.t_dev.fill_(float(t))
-        self.run(e.seg_trunk)
-        self.run(e.seg_t_head)
+        self.run(e.ops(SEG_TRUNK))
+        self.run(e.ops(SEG_HEAD))
         for it in range(n):
-            self.run(e.seg_iter[it])
+            self.run(e.ops(SEG_ITER, it))
 
 
 def _act(v, act):

@@ -111,7 +111,7 @@ def test_plan_matches_oracle_fp32(synthetic_sd):
     """The whole launch plan (engine.py) interpreted on CPU == oracle forward, fp32, N=2."""
     H, W, N = 32, 64, 2
     eng = Engine(synthetic_sd, H, W, torch.float32, 'cpu', max_updates=N)
-    assert len(eng._descs) == 74 + 30 + 25 * N
+    assert eng.n_convs == 74 + 30 + 25 * N
     x = synthetic_window(H, W, 4)
     PlanSim(eng).forward(x, 0.375, N)
     with torch.no_grad():
