@@ -91,6 +91,11 @@ _SIGS = {
     'demfi_pack_planes': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
     'demfi_u8_to_window': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     'demfi_frame_to_u8': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    'demfi_png_encode_bound': (C.c_int64, [C.c_int, C.c_int]),
+    'demfi_png_encode': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int64,
+                                   C.POINTER(C.c_int64)]),
+    'demfi_png_info': (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    'demfi_png_decode': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_int]),
     'demfi_conv_build': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                    C.c_int, C.c_int, C.POINTER(ConvSrc), C.c_int, C.POINTER(ConvDst), C.c_int, C.POINTER(Conv),
                                    C.c_void_p, C.POINTER(C.c_int64), C.c_void_p, C.POINTER(C.c_int32)]),

@@ -219,6 +219,23 @@ class WindowRunner:
         self._end(cur)
         return out, s01
 
+    def _u8_io(self, frames_u8, out_u8, s01_u8):
+        """(load, emit) pair of one uint8 window: 4 BGR uint8 [h,w,3] GPU frames in -> out_u8 [M-1,h,w,3], s01_u8 [2,h,w,3]."""
+        e = self.engine
+        self._check_u8_frames(frames_u8)
+        ptrs = (C.c_void_p * 4)(*[f.data_ptr() for f in frames_u8])
+
+        def load(eng, h):
+            L.check(self.lib.demfi_u8_to_window(ptrs, self.h, self.w, eng.x.data_ptr(), eng.H, eng.W, h), 'u8_to_window')
+
+        def emit(j, fin, sh):
+            L.check(self.lib.demfi_frame_to_u8(fin[2].data_ptr(), out_u8[j].data_ptr(), self.h, self.w, e.H, e.W, sh), 'to_u8')
+            if j == 0:
+                for i in range(2):
+                    L.check(self.lib.demfi_frame_to_u8(fin[i].data_ptr(), s01_u8[i].data_ptr(), self.h, self.w, e.H, e.W, sh),
+                            'to_u8')
+        return load, emit
+
     def run_window_u8(self, frames_u8):
         """uint8 in / uint8 out: frames_u8 = 4 BGR uint8 [h,w,3] GPU tensors in the order (B0,B1,B-1,B2).  Returns
         (St uint8 [M-1,h,w,3], S0S1 uint8 [2,h,w,3]).  Normalisation + reflect padding are fused into ONE kernel writing
@@ -227,22 +244,127 @@ class WindowRunner:
         if getattr(self, '_out_u8', None) is None:
             self._out_u8 = torch.zeros((self.mfi - 1, self.h, self.w, 3), dtype=torch.uint8, device=e.device)
             self._s01_u8 = torch.zeros((2, self.h, self.w, 3), dtype=torch.uint8, device=e.device)
-        self._check_u8_frames(frames_u8)
-        ptrs = (C.c_void_p * 4)(*[f.data_ptr() for f in frames_u8])
-
-        def load(eng, h):
-            L.check(self.lib.demfi_u8_to_window(ptrs, self.h, self.w, eng.x.data_ptr(), eng.H, eng.W, h), 'u8_to_window')
-
-        def emit(j, fin, sh):
-            L.check(self.lib.demfi_frame_to_u8(fin[2].data_ptr(), self._out_u8[j].data_ptr(), self.h, self.w, e.H, e.W, sh), 'to_u8')
-            if j == 0:
-                for i in range(2):
-                    L.check(self.lib.demfi_frame_to_u8(fin[i].data_ptr(), self._s01_u8[i].data_ptr(), self.h, self.w, e.H,
-                                                       e.W, sh), 'to_u8')
+        load, emit = self._u8_io(frames_u8, self._out_u8, self._s01_u8)
         cur = self._begin()
         self._window(load, emit)
         self._end(cur)
         return self._out_u8, self._s01_u8
+
+    def run_windows_u8(self, windows_u8, out=None, s01=None):
+        """Pipelined uint8 run of several windows (list of 4-tuples of BGR uint8 [h,w,3] GPU frames, ready on the current
+        stream): the scheduling of run_windows with the uint8 ingest / egress kernels of run_window_u8.
+        Returns (St uint8 [n,M-1,h,w,3], S0S1 uint8 [n,2,h,w,3])."""
+        n = len(windows_u8)
+        dev = self.engine.device
+        if out is None:
+            out = torch.empty((n, self.mfi - 1, self.h, self.w, 3), dtype=torch.uint8, device=dev)
+        if s01 is None:
+            s01 = torch.empty((n, 2, self.h, self.w, 3), dtype=torch.uint8, device=dev)
+        io = [self._u8_io(windows_u8[i], out[i], s01[i]) for i in range(n)]
+        cur = self._begin()
+        for load, emit in io:
+            self._window(load, emit)
+        self._end(cur)
+        return out, s01
+
+    # ---------------------------------------------------------------------------------------------------------
+    def run_clip_u8(self, host_frames, windows, sink=None, batch=4, reuse_frames=True):
+        """Host-to-host run of a list of windows: the counterpart of the test_custom loop (/root/reference/main.py:
+        1121-1178) between cv2.imread and cv2.imwrite.
+
+        host_frames: sequence of uint8 [h,w,3] CPU tensors (BGR, as cv2.imread returns them; pinned memory makes the
+        copies asynchronous); windows: list of (B0, B1, B-1, B2) index 4-tuples into it; sink(k, St, S0S1): called in
+        window order with uint8 CPU tensors St [M-1,h,w,3], S0S1 [2,h,w,3] (views of pinned staging buffers, valid until
+        the sink returns).  Windows are processed in batches of ``batch``: the H2D of a batch's frames (own stream), the
+        pipelined compute and the D2H of the previous batch's uint8 frames (own stream) overlap; a frame is uploaded
+        once when ``reuse_frames`` (consecutive windows share three frames), else once per window it appears in.
+        Returns the number of windows run."""
+        dev = self.engine.device
+        n = len(windows)
+        if n == 0:
+            return 0
+        M1 = self.mfi - 1
+        if getattr(self, '_clip', None) is None or self._clip['batch'] != batch:
+            nslot = 4 * batch + 4 if not reuse_frames else 2 * batch + 8
+            self._clip = {
+                'batch': batch, 'h2d': torch.cuda.Stream(dev), 'd2h': torch.cuda.Stream(dev),
+                'slots': torch.empty((max(nslot, 4 * batch * 2), self.h, self.w, 3), dtype=torch.uint8, device=dev),
+                'out': [torch.empty((batch, M1, self.h, self.w, 3), dtype=torch.uint8, device=dev) for _ in range(2)],
+                's01': [torch.empty((batch, 2, self.h, self.w, 3), dtype=torch.uint8, device=dev) for _ in range(2)],
+                'h_out': [torch.empty((batch, M1, self.h, self.w, 3), dtype=torch.uint8).pin_memory() for _ in range(2)],
+                'h_s01': [torch.empty((batch, 2, self.h, self.w, 3), dtype=torch.uint8).pin_memory() for _ in range(2)],
+            }
+        cl = self._clip
+        slots = cl['slots']
+        nslot = slots.shape[0]
+        cur = torch.cuda.current_stream(dev)
+        slot_of = {}                      # frame key -> slot
+        slot_busy = [None] * nslot        # event: compute of the batch that last read the slot
+        next_slot = 0
+        ev_done = [None, None]            # compute of the batch that last wrote device output buffer i
+        ev_d2h = [None, None]             # D2H of that batch
+        pending = None                    # (first window, count, buffer) whose D2H is in flight
+        nb = (n + batch - 1) // batch
+        for b in range(nb):
+            wins = windows[b * batch:(b + 1) * batch]
+            i = b & 1
+            # ---- H2D of the frames this batch needs (copy stream) -------------------------------------------------
+            dev_wins = []
+            with torch.cuda.stream(cl['h2d']):
+                for wi, win in enumerate(wins):
+                    fr = []
+                    for idx in win:
+                        key = idx if reuse_frames else (b, wi, idx)
+                        sl = slot_of.get(key)
+                        if sl is None:
+                            sl = next_slot
+                            next_slot = (next_slot + 1) % nslot
+                            for k_old, s_old in list(slot_of.items()):
+                                if s_old == sl:
+                                    del slot_of[k_old]
+                            if slot_busy[sl] is not None:
+                                cl['h2d'].wait_event(slot_busy[sl])
+                            f = host_frames[idx]
+                            if tuple(f.shape) != (self.h, self.w, 3) or f.dtype != torch.uint8:
+                                raise ValueError('frame %d: expected uint8 [%d,%d,3], got %s %s' % (idx, self.h, self.w, f.dtype, tuple(f.shape)))
+                            slots[sl].copy_(f, non_blocking=True)
+                            slot_of[key] = sl
+                        fr.append(slots[sl])
+                    dev_wins.append(fr)
+                ev_up = torch.cuda.Event()
+                ev_up.record(cl['h2d'])
+            # ---- compute (pipelined windows) ---------------------------------------------------------------------
+            cur.wait_event(ev_up)
+            if ev_d2h[i] is not None:
+                cur.wait_event(ev_d2h[i])                     # the D2H of batch b-2 has read this output buffer
+            self.run_windows_u8(dev_wins, out=cl['out'][i][:len(wins)], s01=cl['s01'][i][:len(wins)])
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            ev_done[i] = ev
+            for fr in dev_wins:
+                for t in fr:
+                    slot_busy[(t.data_ptr() - slots.data_ptr()) // t.numel()] = ev
+            # ---- hand the previous batch to the sink while this one computes ------------------------------------------
+            if pending is not None:
+                self._drain(pending, ev_d2h, sink)
+            # ---- D2H of this batch (copy stream), into pinned staging ------------------------------------------------
+            with torch.cuda.stream(cl['d2h']):
+                cl['d2h'].wait_event(ev)
+                cl['h_out'][i][:len(wins)].copy_(cl['out'][i][:len(wins)], non_blocking=True)
+                cl['h_s01'][i][:len(wins)].copy_(cl['s01'][i][:len(wins)], non_blocking=True)
+                e2 = torch.cuda.Event()
+                e2.record(cl['d2h'])
+                ev_d2h[i] = e2
+            pending = (b * batch, len(wins), i)
+        self._drain(pending, ev_d2h, sink)
+        return n
+
+    def _drain(self, pending, ev_d2h, sink):
+        k0, cnt, i = pending
+        ev_d2h[i].synchronize()
+        if sink is not None:
+            for j in range(cnt):
+                sink(k0 + j, self._clip['h_out'][i][j], self._clip['h_s01'][i][j])
 
     def __del__(self):
         try:
