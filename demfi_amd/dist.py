@@ -38,10 +38,32 @@ def shard_windows(n_windows, world, rank):
 
 
 def broadcast_weights(engine, world, src=0):
-    """One flat broadcast of the already-repacked weight/bias blob (7.4 M params: ~17 MB fp16 / 34 MB fp32)."""
+    """One flat broadcast of the already-repacked weight/bias blob of an engine (~15 MB fp16 / 30 MB fp32).  Only the
+    ENGINE's copy changes: a model whose parameters are not also synchronised would repack zeros the next time it builds
+    an engine -- use ``broadcast_state_dict`` for models (bench.py, ClipRunner launches)."""
     if world <= 1 or not active():
         return
     dist.broadcast(engine.weight_blob, src=src)
+
+
+def broadcast_state_dict(model, world, src=0, device=None):
+    """ONE flat broadcast (RCCL over xGMI on the GPU box, gloo in the CPU tests) of all 260 parameter tensors
+    (7 408 284 fp32 = 29.6 MB) from rank ``src``; every rank then holds the real state_dict, so any engine it builds later
+    (another frame size, more contexts) packs the right weights.  Bumps the model's weights version."""
+    if world <= 1 or not active():
+        return
+    params = [p for _, p in sorted(model.state_dict().items())]
+    dev = device or params[0].device
+    flat = torch.cat([p.detach().reshape(-1).to(dev, torch.float32) for p in params])
+    dist.broadcast(flat, src=src)
+    off = 0
+    with torch.no_grad():
+        for p in params:
+            n = p.numel()
+            p.copy_(flat[off:off + n].view_as(p).to(p.device, p.dtype))
+            off += n
+    if hasattr(model, 'invalidate_weights'):
+        model.invalidate_weights()
 
 
 def barrier():

@@ -224,6 +224,17 @@ int demfi_pack_planes(const float* const* planes, int nch, void* dst, int dtype,
 int demfi_u8_to_window(const uint8_t* const* frames, int h, int w, float* x, int H, int W, void* stream);
 int demfi_frame_to_u8(const float* frame, uint8_t* out, int h, int w, int H, int W, void* stream);
 
+/* ---- on-GPU evaluation ------------------------------------------------------------
+ * psnr (utils.py:652-660) and MATLAB-style 11x11 Gaussian ssim (utils.py:663-705) of one predicted frame against its
+ * target as test() computes them (main.py:762-770): pred is rounded after denorm255_np, the target is not (round_gt = 0)
+ * or is (round_gt = 1); fp64 arithmetic.  pred / gt: planar fp32 [3, ., .] in [-1,1] with explicit row / channel strides
+ * (elements), so a crop of a padded buffer is a view.  workspace: demfi_eval_workspace_bytes(h, w) bytes;
+ * out3 (device): {psnr dB (inf when identical), ssim, mse}.  Deterministic (fixed-order reductions). */
+int64_t demfi_eval_workspace_bytes(int h, int w);
+int demfi_eval_frame(const float* pred, int64_t pred_row_stride, int64_t pred_ch_stride, const float* gt,
+                     int64_t gt_row_stride, int64_t gt_ch_stride, int h, int w, int round_gt, double* workspace,
+                     double* out3, void* stream);
+
 /* ---- PNG codec of the clip I/O edge (host only, thread-safe) -------------------------
  * Counterpart of cv2.imread (utils.py:583-593) / cv2.imwrite (main.py:1165-1178) on zlib: uint8 [h,w,3] images in cv2's
  * B,G,R order, `stride` bytes per row.  decode: 8/16-bit gray / RGB / palette / +alpha, non-interlaced -> BGR8 (what

@@ -73,3 +73,76 @@ def test_single_process_is_noop():
     assert D.init(1, 0) is False
     assert D.max_over_ranks(3.5, 'cpu') == 3.5
     D.barrier()
+
+
+def _clip_worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    import sys
+    import torch as th
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from demfi_amd import DeMFInet, HyperParams, synthetic_state_dict, synthetic_window
+    from demfi_amd.clip import window_list
+    from demfi_amd.engine import Engine
+    from demfi_amd import dist as DD
+    from tests.plan_sim import PlanSim
+    th.set_num_threads(1)
+    assert DD.init(world, rank, 0, backend='gloo')
+    # only rank 0 holds the checkpoint; ONE flat broadcast gives every rank the real state_dict
+    model = DeMFInet(HyperParams(), dtype=th.float32)
+    if rank == 0:
+        model.load_state_dict(synthetic_state_dict(0))
+    v0 = model._weights_version
+    DD.broadcast_state_dict(model, world, device='cpu')
+    sd = {k: v.detach() for k, v in model.state_dict().items()}
+    nonzero = sum(int(v.abs().sum() > 0) for k, v in sd.items() if k.endswith('.weight'))
+    # an engine built AFTER the broadcast (what model.engine() does for a new frame size) packs real weights on rank 1 too
+    eng = Engine(sd, 32, 32, th.float32, 'cpu', max_updates=1)
+    blob_sum = int(eng.weight_blob.to(th.int64).sum())
+    # a tiny clip, sharded: 6 frames -> 3 windows; every rank interprets the plan of ITS windows on CPU
+    H = W = 32
+    frames = [synthetic_window(H, W, 40 + i)[0, :, 0] for i in range(6)]         # [3,H,W] each
+    wins = window_list(len(frames))
+    lo, hi = DD.shard_windows(len(wins), world, rank)
+    sim = PlanSim(eng)
+    sums = th.zeros(len(wins), dtype=th.float64)
+    for k in range(lo, hi):
+        x = th.stack([frames[i] for i in wins[k]], 1)[None]                      # [1,3,4,H,W] in (B0,B1,B-1,B2) order
+        sim.forward(x, 0.5, 1)
+        sums[k] = eng.finals[0, 2].double().sum()
+    tot = DD.sum_over_ranks(sums, 'cpu')                                         # every window filled by exactly one rank
+    cnt = DD.sum_over_ranks([float(hi - lo)], 'cpu')
+    q.put((rank, nonzero, blob_sum, model._weights_version - v0, tot.tolist(), cnt.tolist(), (lo, hi)))
+    DD.finalize()
+
+
+def test_two_process_gloo_state_dict_broadcast_and_sharded_clip():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_clip_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=600) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    r0, r1 = res
+    assert r0[1] == r1[1] == 130                           # all 130 weight tensors non-zero on BOTH ranks
+    assert r0[2] == r1[2] != 0                             # identical packed blobs from engines built after the broadcast
+    assert r0[3] == r1[3] == 1                             # the models know their weights changed
+    assert r0[4] == r1[4] and all(v != 0 for v in r0[4])   # 3 windows, each computed once, same totals everywhere
+    assert r0[5] == [3.0] and (r0[6], r1[6]) == ((0, 2), (2, 3))
+    # single-process reference of the same clip
+    import torch as th
+    from demfi_amd import synthetic_state_dict, synthetic_window
+    from demfi_amd.clip import window_list
+    from demfi_amd.engine import Engine
+    from tests.plan_sim import PlanSim
+    eng = Engine(synthetic_state_dict(0), 32, 32, th.float32, 'cpu', max_updates=1)
+    frames = [synthetic_window(32, 32, 40 + i)[0, :, 0] for i in range(6)]
+    sim = PlanSim(eng)
+    for k, w in enumerate(window_list(6)):
+        sim.forward(th.stack([frames[i] for i in w], 1)[None], 0.5, 1)
+        assert abs(float(eng.finals[0, 2].double().sum()) - r0[4][k]) < 2e-3       # MKLDNN sums differ with the thread count

@@ -1,0 +1,126 @@
+"""Clip edge on a real MI355X: host-to-host uint8 pipeline, folder run through the PNG codec, sharding, on-GPU PSNR/SSIM."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from demfi_amd import DeMFInet, HyperParams, synthetic_state_dict, synthetic_window   # noqa: E402
+from demfi_amd import clipio                                                          # noqa: E402
+from demfi_amd.clip import ClipRunner, output_names, window_list                      # noqa: E402
+from demfi_amd.metrics import FrameEvaluator, u8_frame_to_tensor                      # noqa: E402
+from oracle import demfi_oracle as O                                                  # noqa: E402
+
+DEV = 'cuda:0'
+
+
+@pytest.fixture(scope='module')
+def model16():
+    m = DeMFInet(HyperParams(), dtype=torch.float16)
+    m.load_state_dict(synthetic_state_dict(0))
+    return m.to(DEV).eval()
+
+
+def _clip(h, w, n, seed=0):
+    """n uint8 BGR frames of a moving pattern (host)."""
+    base = synthetic_window(h + 2 * n, w + 2 * n, seed)[0, :, 0]                        # [3,H,W] in [-1,1]
+    out = []
+    for i in range(n):
+        f = base[:, i:i + h, 2 * i:2 * i + w]
+        out.append(np.ascontiguousarray(((f.permute(1, 2, 0).numpy() + 1) * 127.5).clip(0, 255).astype(np.uint8)))
+    return out
+
+
+def test_run_clip_u8_equals_per_window_runs(model16):
+    from demfi_amd.runner import WindowRunner
+    h, w, N, M = 50, 70, 2, 4
+    frames = _clip(h, w, 9, 1)
+    wins = window_list(len(frames))
+    runner = WindowRunner(model16, h, w, n_tst=N, mfi=M)
+    ref = []
+    dev = [torch.from_numpy(f).to(DEV) for f in frames]
+    for wdw in wins:
+        st, s01 = runner.run_window_u8([dev[i] for i in wdw])
+        torch.cuda.synchronize()
+        ref.append((st.cpu().clone(), s01.cpu().clone()))
+    host = [torch.from_numpy(f).pin_memory() for f in frames]
+    for reuse in (True, False):
+        got = {}
+        n = runner.run_clip_u8(host, wins, lambda k, st, s01: got.__setitem__(k, (st.clone(), s01.clone())), batch=2, reuse_frames=reuse)
+        assert n == len(wins) and sorted(got) == list(range(len(wins)))
+        for k in range(len(wins)):
+            assert torch.equal(got[k][0], ref[k][0]) and torch.equal(got[k][1], ref[k][1]), (reuse, k)
+
+
+def test_folder_run_png_in_png_out_and_sharding(model16, tmp_path):
+    h, w, N, M = 40, 72, 1, 4
+    frames = _clip(h, w, 7, 2)
+    scene = tmp_path / 'scene1'
+    scene.mkdir()
+    names = []
+    for i, f in enumerate(frames):
+        names.append(str(scene / ('%05d.png' % i)))
+        clipio.write_frame(names[-1], f)
+    # single rank
+    cr = ClipRunner(model16, h, w, n_tst=N, mfi=M, batch=2)
+    out1 = str(tmp_path / 'out1')
+    nwin, nfr = cr.run_folder(str(scene), out1)
+    assert nwin == 4 and nfr == 4 * (M - 1 + 2)
+    exp_files = set()
+    for st_names, s0, s1 in output_names(names, M):
+        exp_files.update(st_names + [s0, s1])
+    assert set(os.listdir(out1)) == exp_files
+    # frames written == frames the runner returns for the same windows
+    got = {}
+    cr.run_frames(frames, lambda k, st, s01: got.__setitem__(k, (st.numpy().copy(), s01.numpy().copy())))
+    for k, (st_names, s0, s1) in enumerate(output_names(names, M)):
+        for j, nm in enumerate(st_names):
+            assert np.array_equal(clipio.read_frame(os.path.join(out1, nm)), got[k][0][j])
+    # two ranks (run one after the other on this GPU): disjoint windows, same files in the end
+    out2 = str(tmp_path / 'out2')
+    tot = 0
+    for rank in range(2):
+        crr = ClipRunner(model16, h, w, n_tst=N, mfi=M, batch=2, world=2, rank=rank)
+        nw, _ = crr.run_folder(str(scene), out2)
+        tot += nw
+    assert tot == 4 and set(os.listdir(out2)) == exp_files
+    for nm in exp_files:
+        if '_' in nm:                                                   # St frames: written exactly once
+            assert np.array_equal(clipio.read_frame(os.path.join(out2, nm)), clipio.read_frame(os.path.join(out1, nm)))
+
+
+def test_gpu_psnr_ssim_match_reference_fixture_and_oracle(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'metrics_96x128.npz'))
+    a, b = torch.from_numpy(g['a']).to(DEV), torch.from_numpy(g['b']).to(DEV)
+    ev = FrameEvaluator(96, 128, DEV)
+    # fixture: both images rounded (psnr / ssim of the reference code on np.around(denorm255_np(.)) images)
+    p, s = ev(b, a, round_gt=True)                                  # pred = b, target = a (symmetric for both metrics up to order)
+    assert abs(p - float(g['psnr'])) < 1e-9 and abs(s - float(g['ssim'])) < 1e-9
+    p2, s2 = ev(a, a, round_gt=True)
+    assert p2 == float('inf') and abs(s2 - 1.0) < 1e-12
+    # test()'s convention: prediction rounded, target not (main.py:762-770) -- against the oracle
+    po, so = O.eval_frame(g['b'], g['a'])
+    p3, s3 = ev(b, a)
+    assert abs(p3 - po) < 1e-9 and abs(s3 - so) < 1e-9
+    # a crop of a larger (padded) buffer is a view: strides are honoured
+    big = torch.zeros(3, 128, 160, device=DEV)
+    big[:, :96, :128] = b
+    p4, s4 = ev(big, a)
+    assert p4 == p3 and s4 == s3
+    # run-to-run bit-identical
+    assert ev(b, a) == (p3, s3)
+
+
+def test_gpu_eval_on_uint8_targets_full_size():
+    """720p: target from an 8-bit frame through the loader's arithmetic, prediction = target + noise; vs the oracle."""
+    h, w = 720, 1280
+    gen = torch.Generator().manual_seed(3)
+    gt_u8 = torch.randint(0, 256, (h, w, 3), generator=gen, dtype=torch.uint8)
+    gt = u8_frame_to_tensor(gt_u8.to(DEV))
+    assert torch.equal(gt.cpu(), O.frames_u8_to_tensor([gt_u8.numpy()])[:, 0])
+    pred = (gt + 0.03 * torch.randn(gt.shape, generator=gen).to(DEV)).contiguous()
+    p, s = FrameEvaluator(h, w, DEV)(pred, gt)
+    po, so = O.eval_frame(pred.cpu().numpy(), gt.cpu().numpy())
+    assert abs(p - po) < 1e-9 and abs(s - so) < 1e-9
