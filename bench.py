@@ -5,10 +5,12 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
         bench.py --gpus N --steps K --warmup W
 
-One "step" = one input window of a synthetic 720p clip: 4 blurry frames (resident in HBM) -> reflect-pad to
-736x1280 -> t-independent trunk once -> 7 time instants t = k/8, each with N_tst = 3 recursive boosts ->
-7 interpolated frames St (+ S0/S1).  Each rank owns its own windows (clip-parallel, no data-path collective;
-weights are broadcast once over RCCL); value = all ranks' St frames / max-over-ranks time.  Rank 0 prints ONE
+One "step" = one input window of a synthetic 720p clip: 4 blurry uint8 frames in pinned host memory -> H2D ->
+normalise + reflect-pad to 736x1280 -> t-independent trunk once -> 7 time instants t = k/8, each with N_tst = 3
+recursive boosts -> 7 interpolated frames St (+ S0/S1) -> crop + denorm + uint8 -> D2H (the metric
+includes H2D of the window and D2H of the outputs, excludes the PNG codec).  Each rank owns its own windows
+(clip-parallel, no data-path collective; the state_dict is broadcast once over RCCL); value = all ranks' St frames /
+max-over-ranks time.  Rank 0 prints ONE
 JSON line carrying the roofline of the dominant kernel and the CPU baseline (oracle, bounded sample).
 """
 import argparse
@@ -29,8 +31,8 @@ HBM_PEAK_GBS = 8000.0                                # MI355X_MICROARCH.md:35
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=3)
-    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=8)
+    ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--height', type=int, default=720)
     ap.add_argument('--width', type=int, default=1280)
     ap.add_argument('--n-tst', type=int, default=3)
@@ -38,6 +40,7 @@ def parse():
     ap.add_argument('--dtype', default='fp16', choices=['fp16', 'fp32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--batch', type=int, default=4, help='windows per copy/compute batch of the uint8 pipeline')
     ap.add_argument('--profile-ops', default='', help='write the per-launch timing table to this file')
     return ap.parse_args()
 
@@ -75,6 +78,34 @@ def cpu_baseline(n_tst, full_px, model=None, dev=None):
     return out, psnr
 
 
+def synthetic_clip_u8(h, w, n_frames, seed):
+    """n_frames uint8 BGR frames of a moving textured pattern with an 11-tap temporal box blur (SURVEY.md section 8d, config
+    2; the reference's inputs are 11-frame averages, README.md:71) -- host tensors in pinned memory."""
+    import numpy as np
+    from demfi_amd import synthetic_window
+    taps = 11
+    base = synthetic_window(h + 2 * (n_frames + taps), w + 4 * (n_frames + taps), seed)[0, :, 0]      # [3,H',W'] in [-1,1]
+    out = []
+    for i in range(n_frames):
+        acc = torch.zeros(3, h, w)
+        for k in range(taps):                                   # sub-frame motion: 1 px down, 2 px right per sharp frame
+            s = i * 2 + k // 4
+            acc += base[:, s:s + h, 2 * s:2 * s + w]
+        f = ((acc / taps).permute(1, 2, 0) + 1) * 127.5
+        out.append(f.clamp(0, 255).to(torch.uint8).contiguous().pin_memory())
+    return out
+
+
+def load_pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary (profiles/r02_pmc_traffic.json,
+    written by tools/pmc_traffic.py on the GPU box: separate --pmc passes, 2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction)."""
+    path = os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return json.load(f)
+
+
 def main():
     a = parse()
     rank = int(os.environ.get('RANK', 0))
@@ -82,7 +113,8 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', 1))
     if world != a.gpus:
         raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)' % (a.gpus, world))
-    from demfi_amd import DeMFInet, HyperParams, synthetic_state_dict, synthetic_window
+    from demfi_amd import DeMFInet, HyperParams, synthetic_state_dict
+    from demfi_amd.clip import window_list
     from demfi_amd.runner import WindowRunner
     from demfi_amd import dist as D
     # test hook: DEMFI_BENCH_BACKEND=gloo runs all ranks of a multi-process launch on the GPUs that exist (rank % count),
@@ -97,74 +129,92 @@ def main():
     if rank == 0:
         model.load_state_dict(synthetic_state_dict(0))       # random-init weights of the architecture (no checkpoint offline)
     model = model.to(dev).eval()
+    # ONE flat broadcast of the 7.4 M parameters (RCCL over xGMI): every rank then owns the real state_dict and packs its
+    # own engine, so later engine rebuilds (other frame sizes) are correct on every rank
+    D.broadcast_state_dict(model, world, device=dev if backend != 'gloo' else 'cpu')
     runner = WindowRunner(model, a.height, a.width, a.n_tst, a.mfi, use_graph=not a.no_graph)
-    D.broadcast_weights(runner.engine, world)                # one flat RCCL broadcast of the repacked weights
-    # synthetic clip: each rank gets its own windows (weak scaling), resident in HBM before the timed region
-    nwin = a.steps + a.warmup
-    windows = [synthetic_window(a.height, a.width, seed=1000 * rank + i).to(dev) for i in range(min(nwin, 4))]
-    # a step = one window (trunk once + 7 time instants x N_tst boosts); the K steps are handed to the scheduler together so
-    # that it can run the trunk of window w+1 under the last time instants of window w (WindowRunner.run_windows)
-    out_buf = torch.empty((a.steps, a.mfi - 1, 3, a.height, a.width), dtype=torch.float32, device=dev)
-    s01_buf = torch.empty((a.steps, 2, 3, a.height, a.width), dtype=torch.float32, device=dev)
+    # synthetic clip: each rank gets its own 11-frame clip = 8 distinct windows (weak scaling), uint8 frames in PINNED HOST
+    # memory: the timed region contains the H2D of every window's 4 frames, the forward, and the D2H of its uint8 outputs
+    frames = synthetic_clip_u8(a.height, a.width, 11, seed=1000 * rank + 1)
+    wins = window_list(len(frames))
+    pick = lambda first, n: [wins[(first + i) % len(wins)] for i in range(n)]
+    sunk = [0]
+
+    def sink(k, st, s01):                                     # the host consumer: touches every delivered window
+        sunk[0] += int(st.shape[0])
     if a.warmup:
-        runner.run_windows([windows[i % len(windows)] for i in range(a.warmup)])
+        runner.run_clip_u8(frames, pick(0, a.warmup), sink, batch=a.batch, reuse_frames=False)
     torch.cuda.synchronize()
+    sunk[0] = 0
     D.barrier()
     t0 = time.perf_counter()
-    runner.run_windows([windows[(a.warmup + i) % len(windows)] for i in range(a.steps)], out=out_buf, s01=s01_buf)
+    # a step = one window: H2D (4 uint8 frames, 11 MB) -> reflect pad + normalise -> trunk once -> 7 time instants x N_tst
+    # boosts -> crop + denorm + uint8 -> D2H (7 St + S0/S1, 25 MB); the K steps are handed to the scheduler together so that
+    # copies, the trunk of window w+1 and the time instants of window w overlap (WindowRunner.run_clip_u8)
+    runner.run_clip_u8(frames, pick(a.warmup, a.steps), sink, batch=a.batch, reuse_frames=False)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    dt = D.max_over_ranks(dt, dev)
+    dt = D.max_over_ranks(dt, dev if backend != 'gloo' else 'cpu')
     D.barrier()
-    frames = (a.mfi - 1) * a.steps * world
+    assert sunk[0] == (a.mfi - 1) * a.steps, 'frames delivered to the host: %d' % sunk[0]
+    frames_out = (a.mfi - 1) * a.steps * world
     eng = runner.engine
     if rank == 0:
         out = {
             # BASELINE.json's metric on its configuration; other --height/--mfi/--n-tst values label themselves
             'metric': 'interpolated frames/sec @%dp x%d MFI (N_tst=%d)' % (a.height, a.mfi, a.n_tst),
-            'value': round(frames / dt, 3), 'unit': 'frames/s',
+            'value': round(frames_out / dt, 3), 'unit': 'frames/s',
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(1e3 * dt / a.steps, 2),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f16' if a.dtype == 'fp16' else 'f32',
             'data': 'synthetic',
             'config': {'workload': 'DeMFI-Net_rb N_tst=%d, x%d MFI, %dx%d (padded %dx%d), %s, clip-parallel windows, '
-                                   'random-init weights' % (a.n_tst, a.mfi, a.height, a.width, eng.H, eng.W, a.dtype),
-                       'frames_per_step': a.mfi - 1, 'graph': not a.no_graph, 'parallelism': 'clip%d' % world},
+                                   'random-init weights; uint8 frames host->HBM->host inside the timed region (PNG codec '
+                                   'excluded), %d distinct windows' % (a.n_tst, a.mfi, a.height, a.width, eng.H, eng.W, a.dtype,
+                                                                         min(len(wins), a.steps)),
+                       'frames_per_step': a.mfi - 1, 'graph': not a.no_graph, 'parallelism': 'clip%d' % world,
+                       'h2d_bytes_per_step': 4 * a.height * a.width * 3, 'd2h_bytes_per_step': (a.mfi + 1) * a.height * a.width * 3},
         }
-        # ---- roofline of the dominant kernel, measured live with HIP events on the launch stream ----------
+        # ---- roofline of the dominant kernel, measured live with HIP events on the launch stream (mean of 5 launches) ----
         prof = eng.profile(a.n_tst)
         per_t = sum(p[3] for p in prof if p[0] != 'trunk')
         trunk = sum(p[3] for p in prof if p[0] == 'trunk')
         convs = [p for p in prof if p[1] == 'conv']
         dom = max(convs, key=lambda p: p[3])
-        grp = [p for p in convs if p[2].startswith('Decoder_res.')]          # D1 residual convs: 3x3 64->64, batch 3
+        grp = [p for p in convs if p[2].startswith('Decoder_res.')]          # D1 residual blocks: 3x3 64->64, batch 3
         g_ms = sum(p[3] for p in grp) / len(grp)
-        g_fl = 2.0 * grp[0][4]
+        g_fl = 2.0 * sum(p[4] for p in grp) / len(grp)
         tot_conv_ms = sum(p[3] for p in convs)
         tot_conv_fl = 2.0 * sum(p[4] for p in convs)
         peak = MFMA_PEAK_TF[a.dtype]
         ach = g_fl / (g_ms * 1e-3) / 1e12
-        out['roofline'] = {'kernel': '%s 3x3 64->64 batch 3 (D1 residual blocks, %d launches/frame)' %
-                                     ('conv3x3_c64_persist_kernel<2>' if a.dtype == 'fp16' else 'conv_kernel<float,2>', len(grp)), 'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak,
+        pmc = load_pmc_traffic() if a.dtype == 'fp16' and (eng.H, eng.W) == (736, 1280) else None
+        kname = runner.engine.dominant_kernel_name() if hasattr(runner.engine, 'dominant_kernel_name') else \
+            ('conv3x3_c64_persist_kernel<2>' if a.dtype == 'fp16' else 'conv_kernel<float,2>')
+        out['roofline'] = {'kernel': '%s: D1 residual blocks, 3x3 64->64, batch 3 (%d launches/frame)' % (kname, len(grp)),
+                           'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak,
                            'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
-                           # HBM bytes per launch from rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE, gfx950 correction),
-                           # profiles/r01e_pmc_conv_gru_warp.txt: 738.1 MB for the 5 launches without residual (algorithmic
-                           # 723.5 MB = in + out once) and 1122.0 MB for the 5 with residual (algorithmic 1085.2 MB): mean
-                           'traffic': 930.1e6 if a.dtype == 'fp16' and (eng.H, eng.W) == (736, 1280) else None,
-                           'algorithmic_bytes': 904.4e6 if a.dtype == 'fp16' and (eng.H, eng.W) == (736, 1280) else None,
-                           'avg_launch_ms': round(g_ms, 4), 'flop_per_launch': g_fl,
+                           # HBM bytes per launch from rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE, gfx950 correction), read from
+                           # the committed summary of the same code (profiles/r02_pmc_traffic.json)
+                           'traffic': pmc.get('dominant_traffic_bytes') if pmc else None,
+                           'algorithmic_bytes': pmc.get('dominant_algorithmic_bytes') if pmc else None,
+                           'traffic_source': pmc.get('source') if pmc else None,
+                           'avg_launch_ms': round(g_ms, 4), 'flop_per_launch': g_fl, 'timing': 'mean of 5 single launches (HIP events)',
                            'all_convs_TFLOPs': round(tot_conv_fl / (tot_conv_ms * 1e-3) / 1e12, 2),
                            'slowest_conv': '%s %.3f ms' % (dom[2], dom[3])}
         wb = [p for p in prof if p[1] == 'warp_fat']
         wb_ms = sum(p[3] for p in wb) / len(wb)
         esz = 2 if a.dtype == 'fp16' else 4
         wb_bytes = (3 * 64 * esz + 20) * eng.H * eng.W                       # 3*C*e + 20 B/px
-        out['roofline_hbm'] = {'kernel': 'warp_blend_fat C=64 (bwarp x2 + Eq.2 blend)', 'bound': 'hbm',
+        out['roofline_hbm'] = {'kernel': 'warp_blend_fat C=64 (bwarp x2 + Eq.2 blend), in-network flows', 'bound': 'hbm',
                                'achieved': round(wb_bytes / (wb_ms * 1e-3) / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                               'frac': round(wb_bytes / (wb_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), 'traffic': None,
+                               'frac': round(wb_bytes / (wb_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                               'traffic': pmc.get('warp_traffic_bytes') if pmc else None,
                                'avg_launch_ms': round(wb_ms, 4), 'bytes_per_launch': wb_bytes}
+        cfr = [p for p in prof if p[1] == 'cfr']
         out['breakdown_ms'] = {'trunk_once_per_window': round(trunk, 2), 'per_t': round(per_t, 2),
                                'launches_per_t': len([p for p in prof if p[0] != 'trunk']),
-                               'conv_share_of_per_t': round(sum(p[3] for p in convs if p[0] != 'trunk') / per_t, 3)}
+                               'conv_share_of_per_t': round(sum(p[3] for p in convs if p[0] != 'trunk') / per_t, 3),
+                               'cfr_flow_align': round(cfr[0][3], 4) if cfr else None}
         if a.profile_ops:
             with open(a.profile_ops, 'w') as f:
                 for p in prof:

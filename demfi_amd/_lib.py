@@ -90,6 +90,7 @@ _SIGS = {
                                    C.c_int, C.c_void_p]),
     'demfi_pack_planes': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
     'demfi_u8_to_window': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    'demfi_u8_to_planar': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     'demfi_frame_to_u8': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'demfi_eval_workspace_bytes': (C.c_int64, [C.c_int, C.c_int]),
     'demfi_eval_frame': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int,

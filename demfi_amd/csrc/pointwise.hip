@@ -596,6 +596,19 @@ __global__ void u8_to_window_kernel(U8Frames fr, float* __restrict__ x, int h, i
     }
 }
 
+// One uint8 frame -> planar fp32 [3,h,w] with the loader's arithmetic (targets of the on-GPU evaluation).
+__global__ void u8_to_planar_kernel(const unsigned char* __restrict__ f, float* __restrict__ out, int hw)
+{
+    const int i = blockIdx.x * NT + threadIdx.x;
+    if (i >= hw) return;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float v = (float)f[(int64_t)i * 3 + c] / 255.0f;
+        v = v - 0.5f;
+        out[(int64_t)c * hw + i] = v * 2.0f;
+    }
+}
+
 // Output side: denorm255_np (utils.py:718-721) on the float64 copy of the fp32 frame, then .astype(np.uint8)
 // truncation (main.py:1165-1178), cropped to h x w, HWC.
 __global__ void frame_to_u8_kernel(const float* __restrict__ fr, unsigned char* __restrict__ out, int h, int w, int H, int W)
@@ -787,6 +800,14 @@ extern "C" int demfi_u8_to_window(const uint8_t* const* frames, int h, int w, fl
         fr.f[i] = frames[i];
     }
     hipLaunchKernelGGL(u8_to_window_kernel, dim3(blocks_for((int64_t)4 * H * W)), dim3(NT), 0, (hipStream_t)stream, fr, x, h, w, H, W);
+    DEMFI_HIP_CHECK(hipGetLastError());
+    return DEMFI_OK;
+}
+
+extern "C" int demfi_u8_to_planar(const uint8_t* frame, int h, int w, float* out, void* stream)
+{
+    if (!frame || !out || h <= 0 || w <= 0) return demfi_set_error(DEMFI_ERR_ARG, "demfi_u8_to_planar: bad args");
+    hipLaunchKernelGGL(u8_to_planar_kernel, dim3(blocks_for((int64_t)h * w)), dim3(NT), 0, (hipStream_t)stream, frame, out, h * w);
     DEMFI_HIP_CHECK(hipGetLastError());
     return DEMFI_OK;
 }

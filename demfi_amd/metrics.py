@@ -38,5 +38,12 @@ class FrameEvaluator:
 
 
 def u8_frame_to_tensor(frame_u8):
-    """uint8 [h,w,3] BGR GPU tensor -> fp32 [3,h,w] in [-1,1] with the loader's arithmetic (utils.py:232-236)."""
-    return ((frame_u8.permute(2, 0, 1).to(torch.float32) / 255.0 - 0.5) * 2).contiguous()
+    """uint8 [h,w,3] BGR GPU tensor -> fp32 [3,h,w] in [-1,1] with the loader's arithmetic (utils.py:232-236), computed by
+    the library (IEEE division: torch's GPU ``/`` multiplies by a reciprocal and differs in the last bit)."""
+    if not (frame_u8.is_cuda and frame_u8.dtype == torch.uint8 and frame_u8.dim() == 3 and frame_u8.shape[2] == 3 and frame_u8.is_contiguous()):
+        raise ValueError('u8_frame_to_tensor: contiguous uint8 [h,w,3] GPU tensor expected')
+    h, w = frame_u8.shape[:2]
+    out = torch.empty((3, h, w), dtype=torch.float32, device=frame_u8.device)
+    L.check(L.load().demfi_u8_to_planar(frame_u8.data_ptr(), h, w, out.data_ptr(), torch.cuda.current_stream(frame_u8.device).cuda_stream),
+            'u8_to_planar')
+    return out

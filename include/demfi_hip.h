@@ -222,6 +222,8 @@ int demfi_pack_planes(const float* const* planes, int nch, void* dst, int dtype,
  * demfi_frame_to_u8: frame planar fp32 [3,H,W] -> out uint8 [h,w,3]: crop + denorm255_np (utils.py:718-721) + uint8
  * truncation (main.py:1165-1178), bit-identical to the reference's float64 arithmetic. */
 int demfi_u8_to_window(const uint8_t* const* frames, int h, int w, float* x, int H, int W, void* stream);
+/* one BGR uint8 [h,w,3] frame -> planar fp32 [3,h,w] with the same arithmetic (ground-truth frames of the evaluation) */
+int demfi_u8_to_planar(const uint8_t* frame, int h, int w, float* out, void* stream);
 int demfi_frame_to_u8(const float* frame, uint8_t* out, int h, int w, int H, int W, void* stream);
 
 /* ---- on-GPU evaluation ------------------------------------------------------------

@@ -21,12 +21,19 @@ DEV = 'cuda:0'
 
 def conv_case(pl, name, cin, cout, kh, kw, batch=1, res=False, h=H, w=W, act=L.ACT_RELU):
     x = pl._fat(h, w, cin, batch)
-    x.copy_(torch.randn(x.shape, device=DEV) * 0.5)
+    if os.environ.get('PROBE_DATA') == 'zero':           # power-light operands: separates clock / power effects from stalls
+        x.zero_()
+    elif os.environ.get('PROBE_DATA') == 'relu':         # half zeros, like post-ReLU activations
+        x.copy_(torch.relu(torch.randn(x.shape, device=DEV) * 0.5))
+    else:
+        x.copy_(torch.randn(x.shape, device=DEV) * 0.5)
     out = pl._fat(h, w, cout, batch)
     r = pl._fat(h, w, cout, batch) if res else None
     if res:
         r.copy_(torch.randn(r.shape, device=DEV) * 0.5)
     wt = torch.randn(cout, cin, kh, kw) * (1.0 / (cin * kh * kw) ** 0.5)
+    if os.environ.get('PROBE_WEIGHTS') == 'zero':
+        wt.zero_()
     seg = []
     pl.conv(seg, name, [pl.fsrc(x, 0)], [_Dst(pl.fview(out), range(cout), act, res=pl.fview(r) if res else None)], h, w,
             batch=batch, weight=wt, bias=torch.zeros(cout))
