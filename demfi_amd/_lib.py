@@ -86,6 +86,9 @@ _SIGS = {
                                    C.POINTER(View), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     'demfi_fgac_gather': (C.c_int, [C.POINTER(View), C.c_void_p, C.POINTER(View), C.c_int, C.c_int, C.c_int,
                                     C.c_void_p, C.c_void_p]),
+    'demfi_fgac_window': (C.c_int, [C.POINTER(View), C.POINTER(View), C.c_void_p, C.POINTER(View), C.c_int, C.c_int, C.c_int,
+                                    C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    'demfi_avg_pool_fat': (C.c_int, [C.POINTER(View), C.POINTER(View), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'demfi_gate_blend': (C.c_int, [C.c_void_p, C.POINTER(View), C.POINTER(View), C.POINTER(View), C.c_int, C.c_int,
                                    C.c_int, C.c_void_p]),
     'demfi_pack_planes': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p]),

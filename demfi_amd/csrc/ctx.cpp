@@ -379,6 +379,10 @@ void alloc_trunk(Layout& L, BufSet& s)
     L.fat(s, "enc_t", H, W, 64, 2);
     L.fat(s, "enc_b", H, W, 64, 2);
     L.fat(s, "rk", H, W, 64, 2);
+    if (L.c->hp.fgac_rr > 0) {
+        L.fat(s, "skk", H, W, 64, 2);               // conv_source_k(source): live only in the generalised FGAC
+        if (L.c->hp.fgac_sr > 0) { L.fat(s, "rkp", H, W, 64, 2); L.fat(s, "skp", H, W, 64, 2); }
+    }
     L.fat(s, "smp", H, W, 64, 2);
     L.fat(s, "E", H, W, 64, 2);
     L.fat(s, "wg", H, W, 64, 2);
@@ -661,7 +665,26 @@ struct Builder {
             const std::string fg = p + (c->hp.shared_fgac ? "shared_FGAC" : (b == 0 ? "FGAC_F1toF0" : "FGAC_F0toF1"));
             const int ref = 1 - b, src = b;
             conv(tr, fg + ".conv_ref_k", {fsrc(*enc, 0, 0, -1, ref)}, {D(fview(B["rk"], 0, b), range(0, 64))}, H, W);
-            {
+            if (c->hp.fgac_rr > 0) {
+                // generalised FGAC (DeMFInet.py:401-445): conv_source_k is live, optional PxP average pooling of both key
+                // maps, then the window kernel (correlation, softmax, weighted sum)
+                conv(tr, fg + ".conv_source_k", {fsrc(*enc, 0, 0, -1, src)}, {D(fview(B["skk"], 0, b), range(0, 64))}, H, W);
+                const char *rkn = "rk", *skn = "skk";
+                if (c->hp.fgac_sr > 0) {
+                    for (int q = 0; q < 2; ++q) {
+                        demfi_op o = blank();
+                        o.nch = 64; o.conv = c->hp.fgac_sr;
+                        o.a = fview(B[q ? "skk" : "rk"], 0, b); o.o = fview(B[q ? "skp" : "rkp"], 0, b);
+                        simple(tr, DEMFI_OP_AVG_POOL, "avg_pool", o);
+                    }
+                    rkn = "rkp"; skn = "skp";
+                }
+                demfi_op o = blank();
+                o.nch = 64; o.conv = c->hp.fgac_rr; o._pad = c->hp._pad;
+                o.a = fview(B[rkn], 0, b); o.b = fview(B[skn], 0, b); o.o = fview(B["smp"], 0, b);
+                o.p[0] = ptr(B["ffo"]) + (b == 0 ? 0 : 2) * hw4;
+                simple(tr, DEMFI_OP_FGAC_WINDOW, "fgac_window", o);
+            } else {
                 demfi_op o = blank();
                 o.nch = 64;
                 o.a = fview(B["rk"], 0, b); o.o = fview(B["smp"], 0, b);
@@ -917,9 +940,14 @@ extern "C" int demfi_ctx_create(int H, int W, int max_updates, int dtype, const 
         return demfi_set_error(DEMFI_ERR_ARG, "the HIP path is built for nf=64, scale_factor=2 (the released configuration)");
     if (h.num_resb_facfb < 0 || h.num_resb_dec < 0 || h.num_resb_facfb > 32 || h.num_resb_dec > 32)
         return demfi_set_error(DEMFI_ERR_ARG, "demfi_ctx_create: residual block counts");
-    if (h.fgac_rr != 0 || h.fgac_sr != 0)
-        return demfi_set_error(DEMFI_ERR_ARG, "demfi_ctx_create: the plan runs the released point-wise FGAC (rr = sr = 0, DeMFInet.py:401-402); "
-                                              "the generalised window kernel is exposed as demfi_fgac_window");
+    // fgac_rr / fgac_sr: the radii hard-coded to 0 at DeMFInet.py:401-402; > 0 selects the generalised window FGAC
+    // (demfi_fgac_window, fp16 path only; h._pad = index map: 0 reference code, 1 pixel-centred window)
+    if (h.fgac_rr < 0 || h.fgac_rr > 2 || h.fgac_sr < 0 || h.fgac_sr > 4 || (h._pad != 0 && h._pad != 1))
+        return demfi_set_error(DEMFI_ERR_ARG, "demfi_ctx_create: fgac_rr in 0..2, fgac_sr in 0..4, map in {0,1}");
+    if (h.fgac_rr == 0 && h.fgac_sr != 0)
+        return demfi_set_error(DEMFI_ERR_ARG, "demfi_ctx_create: fgac_sr > 0 needs fgac_rr > 0 (the pooled point-wise form is not built)");
+    if (h.fgac_rr > 0 && dtype != DEMFI_F16)
+        return demfi_set_error(DEMFI_ERR_ARG, "demfi_ctx_create: the generalised FGAC kernel is built for the fp16 path");
     demfi_ctx* c = new demfi_ctx();
     c->H = H; c->W = W; c->N = max_updates; c->dtype = dtype; c->n_trunk = n_trunk; c->n_ctx = n_ctx; c->hp = h;
     layer_table(c);
@@ -1098,6 +1126,10 @@ extern "C" int demfi_run_op(demfi_ctx* c, const demfi_op* op, void* stream)
         return demfi_overlay_mean((const float*)op->p[0], (float*)op->p[1], H, W, stream);
     case DEMFI_OP_FGAC:
         return demfi_fgac_gather(&op->a, (const float*)op->p[0], &op->o, op->nch, H, W, nullptr, stream);
+    case DEMFI_OP_FGAC_WINDOW:
+        return demfi_fgac_window(&op->a, &op->b, (const float*)op->p[0], &op->o, op->nch, H, W, op->conv, op->_pad, nullptr, stream);
+    case DEMFI_OP_AVG_POOL:
+        return demfi_avg_pool_fat(&op->a, &op->o, op->nch, H, W, op->conv, stream);
     case DEMFI_OP_GATE:
         return demfi_gate_blend((const float*)op->p[0], &op->a, &op->b, &op->o, op->nch, H, W, stream);
     case DEMFI_OP_CFR:

@@ -182,7 +182,7 @@ class Plan:
 
 
 SEG_TRUNK, SEG_HEAD, SEG_ITER = 0, 1, 2
-KIND_NAME = {0: 'conv', 1: 'pack', 2: 's2d', 3: 'overlay', 4: 'fgac', 5: 'gate', 6: 'cfr', 7: 'warp', 8: 'fgac_window'}
+KIND_NAME = {0: 'conv', 1: 'pack', 2: 's2d', 3: 'overlay', 4: 'fgac', 5: 'gate', 6: 'cfr', 7: 'warp', 8: 'fgac_window', 9: 'avg_pool'}
 
 
 class Engine:
@@ -207,7 +207,8 @@ class Engine:
         if self.hp.nf != 64 or self.hp.scale_factor != 2:
             raise NotImplementedError('the HIP path is built for nf=64, scale_factor=2 (the released configuration)')
         chp = L.HParams(self.hp.nf, self.hp.scale_factor, self.hp.num_ResB_FACFB, self.hp.num_ResB_Dec,
-                        1 if self.hp.shared_FGAC_flag else 0, 0, 0, 0)
+                        1 if self.hp.shared_FGAC_flag else 0, getattr(self.hp, 'fgac_rr', 0), getattr(self.hp, 'fgac_sr', 0),
+                        getattr(self.hp, 'fgac_map', 0))
         self._ctx = C.c_void_p()
         self._n_trunk, self._n_ctx = max(1, n_trunk), max(1, n_ctx)
         L.check(self.lib.demfi_ctx_create(H, W, max_updates, self.dt, C.byref(chp), self._n_trunk, self._n_ctx,

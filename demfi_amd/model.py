@@ -39,7 +39,8 @@ class DeMFInet(nn.Module):
         args = args or HyperParams()
         self.args = args
         self.hp = HyperParams(getattr(args, 'gpu', 0), args.nf, args.scale_factor, args.num_ResB_FACFB,
-                              args.num_ResB_Dec, args.shared_FGAC_flag, getattr(args, 'visualization_flag', False))
+                              args.num_ResB_Dec, args.shared_FGAC_flag, getattr(args, 'visualization_flag', False),
+                              getattr(args, 'fgac_rr', 0), getattr(args, 'fgac_sr', 0), getattr(args, 'fgac_map', 0))
         self.device = torch.device('cuda:' + str(self.hp.gpu) if torch.cuda.is_available() else 'cpu')
         self.nf = self.hp.nf
         self.scale_factor = self.hp.scale_factor

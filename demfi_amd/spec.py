@@ -15,7 +15,7 @@ class HyperParams:
     """The constructor arguments the reference reads from ``args`` (DeMFInet.py:17-21, 32, 42, 326, 328)."""
 
     def __init__(self, gpu=0, nf=64, scale_factor=2, num_ResB_FACFB=5, num_ResB_Dec=5,
-                 shared_FGAC_flag=True, visualization_flag=False):
+                 shared_FGAC_flag=True, visualization_flag=False, fgac_rr=0, fgac_sr=0, fgac_map=0):
         self.gpu = gpu
         self.nf = nf
         self.scale_factor = scale_factor
@@ -23,6 +23,9 @@ class HyperParams:
         self.num_ResB_Dec = num_ResB_Dec
         self.shared_FGAC_flag = shared_FGAC_flag
         self.visualization_flag = visualization_flag
+        # radii of the generalised FGAC (function-local constants 0 at DeMFInet.py:401-402) and its index map
+        # (0: as the reference code computes it, 1: pixel-centred window) -- extensions, defaults = the released model
+        self.fgac_rr, self.fgac_sr, self.fgac_map = fgac_rr, fgac_sr, fgac_map
 
 
 def layer_table(hp=None):

@@ -204,6 +204,18 @@ int demfi_warp_blend(const demfi_view* A, const float* fa, const demfi_view* B, 
 int demfi_fgac_gather(const demfi_view* src, const float* flow, const demfi_view* out, int C, int H,
                       int W, int32_t* dbg_maps, void* stream);
 
+/* Generalised FGAC (radii rr > 0, DeMFInet.py:401-445): correlation of the (2rr+1)^2 bilinear samples of ref_k with
+ * source_k over the C = 64 channels, softmax over the window, attention-weighted sum (Eq. 3).  fp16 NHWC views.
+ * mode 0: the index map the reference code computes when its hard-coded radii are overridden (pinned by fixtures from a
+ * patched in-memory copy of the reference); mode 1: window centred on flow[y,x] (the paper's description), (2rr+2)^2
+ * texel window staged per pixel in LDS; both: wavefront-shuffle channel reduction + softmax.  attn_out (optional):
+ * fp32 [(2rr+1)^2, H, W] softmax weights.  sr > 0 (DeMFInet.py:417, 434): apply demfi_avg_pool_fat to ref_k / source_k
+ * first.  rr in {1, 2}. */
+int demfi_fgac_window(const demfi_view* ref_k, const demfi_view* source_k, const float* flow, const demfi_view* out,
+                      int C, int H, int W, int rr, int mode, float* attn_out, void* stream);
+/* F.avg_pool2d(x, 2sr+1, stride 1, padding sr) (count_include_pad), fp16 NHWC. */
+int demfi_avg_pool_fat(const demfi_view* src, const demfi_view* out, int C, int H, int W, int sr, void* stream);
+
 /* Eq.(4) gate blend (DeMFInet.py:452): out = w*source + (1-w)*e; w planar fp32 [H,W]. */
 int demfi_gate_blend(const float* w, const demfi_view* source, const demfi_view* e, const demfi_view* out,
                      int C, int H, int W, void* stream);
@@ -290,21 +302,21 @@ typedef struct demfi_hparams {           /* DeMFInet.py:17-21, 32, 42, 326, 328;
     int32_t num_resb_dec;                /* 5                                                            */
     int32_t shared_fgac;                 /* 1                                                            */
     int32_t fgac_rr, fgac_sr;            /* 0, 0: the radii hard-coded at DeMFInet.py:401-402 (generalised FGAC when > 0) */
-    int32_t _pad;
+    int32_t _pad;                        /* generalised FGAC index map: 0 = as the reference code computes it, 1 = pixel-centred */
 } demfi_hparams;
 
 enum demfi_op_kind {
     DEMFI_OP_CONV = 0, DEMFI_OP_PACK = 1, DEMFI_OP_S2D = 2, DEMFI_OP_OVERLAY = 3, DEMFI_OP_FGAC = 4, DEMFI_OP_GATE = 5,
-    DEMFI_OP_CFR = 6, DEMFI_OP_WARP = 7, DEMFI_OP_FGAC_WINDOW = 8
+    DEMFI_OP_CFR = 6, DEMFI_OP_WARP = 7, DEMFI_OP_FGAC_WINDOW = 8, DEMFI_OP_AVG_POOL = 9
 };
 enum demfi_segment { DEMFI_SEG_TRUNK = 0, DEMFI_SEG_T_HEAD = 1, DEMFI_SEG_ITER = 2 };
 
 /* One launch of the plan (introspection for tests / per-launch profiling; pointers are already bound). */
 typedef struct demfi_op {
     int32_t kind;           /* demfi_op_kind                                                             */
-    int32_t conv;           /* CONV: descriptor index (demfi_ctx_conv_desc)                              */
+    int32_t conv;           /* CONV: descriptor index (demfi_ctx_conv_desc); FGAC_WINDOW: rr; AVG_POOL: sr */
     int32_t nch;            /* PACK: channels (multiple of 8); WARP / FGAC / GATE: C                     */
-    int32_t _pad;
+    int32_t _pad;           /* FGAC_WINDOW: index map (0 reference code, 1 pixel-centred)                */
     int64_t macs;           /* CONV: algorithmic multiply-accumulates of the launch                      */
     demfi_view a, b, o;     /* WARP: A, B, out; FGAC: src, -, out; GATE: source, e, out; PACK: o = dst     */
     const void* p[32];      /* PACK: plane pointers; WARP: fa, fb, logit, occ_out; FGAC: flow; GATE: w;

@@ -263,8 +263,9 @@ def fgac(sd, name, ref, source, flow):
     return w * source + (1 - w) * e, w
 
 
-def fac_fb(sd, F0, F1, flow_10, flow_01, n_res=5, shared=True):
-    """FAC_FB.forward (DeMFInet.py:335-358): shared encoder on both frames, then FGAC both ways."""
+def fac_fb(sd, F0, F1, flow_10, flow_01, n_res=5, shared=True, fgac_radii=(0, 0, 0)):
+    """FAC_FB.forward (DeMFInet.py:335-358): shared encoder on both frames, then FGAC both ways.  fgac_radii = (rr, sr,
+    mode): the generalised FGAC (fgac_general) when rr > 0."""
     p = 'FAC_FB_Module.'
     enc = F.relu(conv(sd, p + 'conv_first', torch.cat([F0, F1], 0)))
     for i in range(n_res):
@@ -272,8 +273,12 @@ def fac_fb(sd, F0, F1, flow_10, flow_01, n_res=5, shared=True):
     e0, e1 = enc[0:1], enc[1:2]
     n0 = p + ('shared_FGAC' if shared else 'FGAC_F1toF0')
     n1 = p + ('shared_FGAC' if shared else 'FGAC_F0toF1')
-    a0, w0 = fgac(sd, n0, e1, e0, flow_01)
-    a1, w1 = fgac(sd, n1, e0, e1, flow_10)
+    if fgac_radii[0] > 0:
+        a0, w0 = fgac_general(sd, n0, e1, e0, flow_01, *fgac_radii)[:2]
+        a1, w1 = fgac_general(sd, n1, e0, e1, flow_10, *fgac_radii)[:2]
+    else:
+        a0, w0 = fgac(sd, n0, e1, e0, flow_01)
+        a1, w1 = fgac(sd, n1, e0, e1, flow_10)
     return a0, a1, enc, (w0, w1)
 
 
@@ -334,7 +339,7 @@ def booster(sd, F_rec, ref_list, delta_list):
 # --------------------------------------------------------------------------------------------
 # full forward
 # --------------------------------------------------------------------------------------------
-def forward(sd, x, t_value, num_update=None, nf=64, shared_fgac=True, return_stages=False):
+def forward(sd, x, t_value, num_update=None, nf=64, shared_fgac=True, return_stages=False, fgac_radii=(0, 0, 0)):
     """DeMFInet.forward, inference branch (DeMFInet.py:46-179).
 
     x [B,3,4,H,W] fp32 (frame order B0,B1,B-1,B2: 52-55), t_value [B,1].  Batch 1 only (the harness
@@ -347,7 +352,7 @@ def forward(sd, x, t_value, num_update=None, nf=64, shared_fgac=True, return_sta
     t = t_value.reshape(-1, 1, 1, 1)
     flow_t0, flow_t1 = cfr_flow_align(flow_01, flow_10, t)
     Ft = warp_blend(F0, flow_t0, F1, flow_t1, occ_logit, t)
-    aF0, aF1, enc, gates = fac_fb(sd, F0, F1, flow_10, flow_01, shared=shared_fgac)
+    aF0, aF1, enc, gates = fac_fb(sd, F0, F1, flow_10, flow_01, shared=shared_fgac, fgac_radii=fgac_radii)
     agg = torch.cat([aF0, aF1, Ft, flow_t0, flow_t1, flow_01, flow_10, occ_logit], 1)
     agg = unet(sd, agg) + torch.cat([flow_t0, flow_t1, occ_logit, aF0, aF1], 1)
     rflow_t0, rflow_t1, occ_logit1 = agg[:, 0:2], agg[:, 2:4], agg[:, 4:5]
@@ -485,3 +490,56 @@ def eval_frame(pred, gt, round_gt=False):
     if round_gt:
         b = np.around(b)
     return psnr255(b, a), ssim_matlab(b, a)
+
+
+# --------------------------------------------------------------------------------------------
+# generalised FGAC (radii rr, sr > 0) -- DeMFInet.py:401-445.  The released code hard-codes rr = sr = 0;
+# mode 0 restates what the reference code computes when the two constants are overridden (pinned by
+# tests/golden/fgac_window_*.npz, generated from a patched in-memory copy of the reference function), mode 1 is the window
+# centred on the pixel's own flow value (the paper's description; oracle-only parity).
+# --------------------------------------------------------------------------------------------
+def fgac_window(ref_k, source_k, flow, rr, sr=0, mode=0):
+    """ref_k, source_k: torch [1,C,H,W]; flow [1,2,H,W] (absolute coordinates, F7).  Returns (FAC_sr [1,C,H,W],
+    softmax weights [R*R,H,W]) with R = 2 rr + 1."""
+    R = 2 * rr + 1
+    if sr:
+        ref_k = F.avg_pool2d(ref_k, (2 * sr + 1, 2 * sr + 1), (1, 1), padding=sr)            # 417
+        source_k = F.avg_pool2d(source_k, (2 * sr + 1, 2 * sr + 1), (1, 1), padding=sr)      # 434
+    a = ref_k[0].numpy().astype(f32)
+    C, H, W = a.shape
+    fl = flow[0].numpy().astype(f32)
+    ys, xs = np.meshgrid(np.arange(H), np.arange(W), indexing='ij')
+    G = np.zeros((R * R, C, H, W), f32)
+    for ki in range(R):
+        for kj in range(R):
+            if mode == 1:
+                px = (fl[0] + f32(kj - rr)).astype(f32)
+                py = (fl[1] + f32(ki - rr)).astype(f32)
+                valid = np.ones((H, W), bool)
+            else:
+                r = ys * R - rr + ki                          # unfold(kernel R, stride R, padding rr) over [R*H, R*W] (423-427)
+                c = xs * R - rr + kj
+                valid = (r >= 0) & (r < R * H) & (c >= 0) & (c < R * W)
+                rc, cc = np.clip(r, 0, R * H - 1), np.clip(c, 0, R * W - 1)
+                i, h = rc // H, rc % H                        # view(C,H,R,W,R).permute -> [C, R*H, R*W] (419-422)
+                j, w = cc // W, cc % W
+                fy, fx = (h * R + i) % H, (w * R + j) % W     # centroid grid = flow.repeat(1,R,R,1) (411): TILED
+                px = (fl[0][fy, fx] + (i - rr).astype(f32)).astype(f32)      # delta channel 0 = dy[i] (405-408)
+                py = (fl[1][fy, fx] + (j - rr).astype(f32)).astype(f32)
+            m = sample_maps(px, py, H, W)
+            G[ki * R + kj] = _gather_bilinear(a, m) * valid[None].astype(f32)
+    Gt = torch.from_numpy(G)                                   # [E,C,H,W]
+    corr = (Gt * source_k[0][None]).sum(1)                     # 438
+    att = torch.softmax(corr, 0)                               # 441
+    fac = (Gt * att[:, None]).sum(0)                           # 443
+    return fac[None], att
+
+
+def fgac_general(sd, name, ref, source, flow, rr, sr=0, mode=0):
+    """FGAC.forward (386-452) with radii (rr, sr): conv_source_k is live here (it is dead only for rr = 0)."""
+    rk = conv(sd, name + '.conv_ref_k', ref)
+    sk = conv(sd, name + '.conv_source_k', source)
+    fac, att = fgac_window(rk, sk, flow, rr, sr, mode)
+    E = conv(sd, name + '.fusion', fac)
+    w = torch.sigmoid(conv(sd, name + '.w_gen_2', torch.relu(conv(sd, name + '.w_gen', torch.cat([source, E], 1)))))
+    return w * source + (1 - w) * E, w, fac, att

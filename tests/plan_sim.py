@@ -164,6 +164,16 @@ class PlanSim:
                 fl = self.planes(op.p[0], 2, H, W)
                 out = self.strided(op.o, op.nch, H, W)
                 out.copy_(O.fgac_sample(rk, fl[None])[0].to(out.dtype))
+            elif k == 8:                                                   # generalised FGAC window (rr = op.conv, map = op._pad)
+                rk = self.strided(op.a, op.nch, H, W).float()[None]
+                sk = self.strided(op.b, op.nch, H, W).float()[None]
+                fl = self.planes(op.p[0], 2, H, W)
+                out = self.strided(op.o, op.nch, H, W)
+                out.copy_(O.fgac_window(rk, sk, fl[None], op.conv, 0, op._pad)[0][0].to(out.dtype))
+            elif k == 9:                                                   # avg_pool (sr = op.conv)
+                a = self.strided(op.a, op.nch, H, W).float()[None]
+                out = self.strided(op.o, op.nch, H, W)
+                out.copy_(F.avg_pool2d(a, 2 * op.conv + 1, 1, op.conv)[0].to(out.dtype))
             elif k == 5:                                                   # gate blend
                 g = self.planes(op.p[0], 1, H, W)
                 s_, e_ = self.strided(op.a, op.nch, H, W).float(), self.strided(op.b, op.nch, H, W).float()

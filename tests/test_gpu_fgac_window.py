@@ -1,0 +1,109 @@
+"""Generalised FGAC kernel (rr in {1,2}; LDS window staging + wavefront-shuffle softmax) on a real MI355X: against the
+fixtures of the PATCHED reference (mode 0) and the oracle (both modes)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from demfi_amd import _lib as L, synthetic_state_dict     # noqa: E402
+from oracle import demfi_oracle as O                      # noqa: E402
+
+DEV = 'cuda:0'
+
+
+def _nhwc(t):
+    h, w, c = t.shape
+    return L.View(t.data_ptr(), c, w * c, 1, 0, 0, 0)
+
+
+def _run(rk, sk, fl, rr, mode, sr=0):
+    """rk, sk: fp16 NHWC GPU tensors; returns (fac [C,H,W] fp32 cpu, attn [E,H,W] cpu)."""
+    lib = L.load()
+    H, W, Cc = rk.shape
+    st = torch.cuda.current_stream().cuda_stream
+    if sr:
+        rk2, sk2 = torch.empty_like(rk), torch.empty_like(sk)
+        for a, b in ((rk, rk2), (sk, sk2)):
+            va, vb = _nhwc(a), _nhwc(b)
+            L.check(lib.demfi_avg_pool_fat(C.byref(va), C.byref(vb), Cc, H, W, sr, st))
+        rk, sk = rk2, sk2
+    out = torch.zeros_like(rk)
+    R = 2 * rr + 1
+    attn = torch.zeros(R * R, H, W, device=DEV)
+    vr, vs, vo = _nhwc(rk), _nhwc(sk), _nhwc(out)
+    L.check(lib.demfi_fgac_window(C.byref(vr), C.byref(vs), fl.data_ptr(), C.byref(vo), Cc, H, W, rr, mode, attn.data_ptr(), st))
+    torch.cuda.synchronize()
+    return out.permute(2, 0, 1).float().cpu(), attn.cpu()
+
+
+@pytest.mark.parametrize('rr,sr', [(1, 0), (2, 0), (1, 1)])
+def test_window_kernel_vs_patched_reference_and_oracle(golden_dir, rr, sr):
+    g = np.load(os.path.join(golden_dir, 'fgac_window_16x24.npz'))
+    sd = synthetic_state_dict(0)
+    ref, src = torch.from_numpy(g['ref'])[None], torch.from_numpy(g['src'])[None]
+    with torch.no_grad():
+        rk = O.conv(sd, 'FAC_FB_Module.shared_FGAC.conv_ref_k', ref)
+        sk = O.conv(sd, 'FAC_FB_Module.shared_FGAC.conv_source_k', src)
+    rk16 = rk[0].permute(1, 2, 0).contiguous().half().to(DEV)
+    sk16 = sk[0].permute(1, 2, 0).contiguous().half().to(DEV)
+    for name in ('inrange', 'mixed'):
+        fl = torch.from_numpy(g['flow_' + name]).to(DEV)
+        for mode in (0, 1):
+            fac, att = _run(rk16, sk16, fl, rr, mode, sr)
+            # oracle on the SAME fp16-rounded inputs (pooling in fp32 then rounded like the kernel's fp16 store)
+            rkq, skq = rk16.float().cpu().permute(2, 0, 1)[None], sk16.float().cpu().permute(2, 0, 1)[None]
+            if sr:
+                import torch.nn.functional as F
+                rkq = F.avg_pool2d(rkq, 2 * sr + 1, 1, sr).half().float()
+                skq = F.avg_pool2d(skq, 2 * sr + 1, 1, sr).half().float()
+            efac, eatt = O.fgac_window(rkq, skq, fl.cpu()[None], rr, 0, mode)
+            assert (att - eatt).abs().max() < 2e-3, (name, mode)
+            assert abs(float(att.sum(0).mean()) - 1.0) < 1e-5
+            assert (fac - efac[0]).abs().max() < 4e-3, (name, mode)
+            if mode == 0:                                   # and against what the patched reference produced in fp32
+                gfac = g['fac_rr%d_sr%d_%s' % (rr, sr, name)]
+                assert np.abs(fac.numpy() - gfac).max() < 2e-2 and np.median(np.abs(fac.numpy() - gfac)) < 1e-3
+
+
+def test_window_kernel_larger_frame_deterministic_and_rejects_bad_args():
+    torch.manual_seed(0)
+    H, W = 40, 72
+    rk = torch.tanh(torch.randn(H, W, 64, device=DEV)).half()
+    sk = torch.tanh(torch.randn(H, W, 64, device=DEV)).half()
+    fl = (torch.rand(2, H, W, device=DEV) * torch.tensor([W + 6.0, H + 6.0], device=DEV).view(2, 1, 1) - 3).contiguous()
+    for mode in (0, 1):
+        a, at = _run(rk, sk, fl, 1, mode)
+        b, bt = _run(rk, sk, fl, 1, mode)
+        assert torch.equal(a, b) and torch.equal(at, bt)
+        e, ea = O.fgac_window(rk.float().cpu().permute(2, 0, 1)[None], sk.float().cpu().permute(2, 0, 1)[None], fl.cpu()[None], 1, 0, mode)
+        assert (a - e[0]).abs().max() < 4e-3 and (at - ea).abs().max() < 2e-3
+    lib = L.load()
+    v = _nhwc(rk)
+    assert lib.demfi_fgac_window(C.byref(v), C.byref(v), fl.data_ptr(), C.byref(v), 64, H, W, 0, 0, None, 0) == -1
+    assert lib.demfi_fgac_window(C.byref(v), C.byref(v), fl.data_ptr(), C.byref(v), 64, H, W, 3, 0, None, 0) == -1
+
+
+@pytest.mark.parametrize('rr,sr,fmap', [(1, 0, 0), (2, 0, 1), (1, 1, 1)])
+def test_model_with_generalised_fgac_end_to_end(rr, sr, fmap):
+    """The module surface with hp.fgac_rr / fgac_sr set: the whole forward (trunk with conv_source_k + window FGAC) on the
+    GPU against the oracle's generalised forward; and it differs from the released rr = 0 model."""
+    from demfi_amd import DeMFInet, HyperParams, synthetic_window
+    sd = synthetic_state_dict(0)
+    hp = HyperParams(fgac_rr=rr, fgac_sr=sr, fgac_map=fmap)
+    m = DeMFInet(hp, dtype=torch.float16)
+    m.load_state_dict(sd)
+    m = m.to(DEV).eval()
+    x = synthetic_window(64, 96, 9)
+    t = torch.tensor([[0.375]])
+    out = m(x.to(DEV), t.to(DEV), 2)
+    with torch.no_grad():
+        ref = O.forward(sd, x, t, 2, fgac_radii=(rr, sr, fmap))
+        base = O.forward(sd, x, t, 2)
+    got = out[1][1][2][0].float().cpu().numpy()
+    ps = O.psnr(got, ref[1][1][2][0].numpy())
+    assert np.isfinite(got).all() and ps > 36.0, ps
+    assert ps > O.psnr(got, base[1][1][2][0].numpy()) + 2.0

@@ -136,3 +136,25 @@ def test_plan_non_shared_fgac():
     with torch.no_grad():
         out = O.forward(sd, x, torch.tensor([[0.5]]), 1, shared_fgac=False)
     assert (eng.finals[0, 2] - out[1][0][2][0]).abs().max() < 1e-4
+
+
+@pytest.mark.parametrize('rr,sr,fmap', [(1, 0, 0), (1, 1, 1)])
+def test_plan_generalised_fgac(rr, sr, fmap):
+    """hp.fgac_rr / fgac_sr > 0: the plan gains conv_source_k, the optional pooling and the window op (fp16 path only);
+    interpreted on CPU it follows the oracle's generalised FGAC (itself pinned to the patched reference)."""
+    hp = HyperParams(fgac_rr=rr, fgac_sr=sr, fgac_map=fmap)
+    sd = synthetic_state_dict(0)
+    H, W = 32, 32
+    with pytest.raises(L.DemfiError):
+        Engine(sd, H, W, torch.float32, 'cpu', max_updates=1, hp=hp)            # window kernel is fp16-only
+    eng = Engine(sd, H, W, torch.float16, 'cpu', max_updates=1, hp=hp)
+    kinds = [op.kind for op in eng.ops(0)]
+    assert kinds.count(8) == 2 and kinds.count(4) == 0 and kinds.count(9) == (4 if sr else 0)
+    x = synthetic_window(H, W, 6)
+    PlanSim(eng).forward(x, 0.5, 1)
+    with torch.no_grad():
+        ref = O.forward(sd, x, torch.tensor([[0.5]]), 1, fgac_radii=(rr, sr, fmap))
+        base = O.forward(sd, x, torch.tensor([[0.5]]), 1)
+    got = eng.finals[0, 2].float().numpy()
+    assert O.psnr(got, ref[1][0][2][0].numpy()) > 38.0                           # fp16 storage vs fp32 oracle
+    assert O.psnr(got, ref[1][0][2][0].numpy()) > O.psnr(got, base[1][0][2][0].numpy()) + 3.0   # and it is NOT the rr = 0 result

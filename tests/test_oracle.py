@@ -145,3 +145,30 @@ def test_psnr_ssim_fixture(golden_dir):
     assert O.psnr255(ia, ia) == float('inf') and abs(O.ssim_matlab(ia, ia) - 1.0) < 1e-12
     p, s = O.eval_frame(g['a'], g['b'], round_gt=True)
     assert abs(p - float(g['psnr'])) < 1e-9 and abs(s - float(g['ssim'])) < 1e-9
+
+
+def test_generalised_fgac_matches_patched_reference(golden_dir, synthetic_sd):
+    """FGAC with radii rr, sr > 0 (DeMFInet.py:401-445): the reference never executes it (its radii are function-local
+    constants 0), so the pin is a PATCHED in-memory copy of the reference function (tools/make_goldens.py::patched_fgac) --
+    parity pinned to a patched reference, said so here and in DESIGN.md."""
+    g = _load(golden_dir, 'fgac_window_16x24')
+    ref, src = torch.from_numpy(g['ref'])[None], torch.from_numpy(g['src'])[None]
+    for rr, sr in ((1, 0), (2, 0), (1, 1)):
+        for name in ('inrange', 'mixed'):
+            fl = torch.from_numpy(g['flow_' + name])[None]
+            with torch.no_grad():
+                out, w, fac, att = O.fgac_general(synthetic_sd, 'FAC_FB_Module.shared_FGAC', ref, src, fl, rr, sr, 0)
+            tag = 'rr%d_sr%d_%s' % (rr, sr, name)
+            assert np.abs(fac[0].numpy() - g['fac_' + tag]).max() < 5e-6, tag
+            assert np.abs(out[0].numpy() - g['out_' + tag]).max() < 5e-6, tag
+            assert np.abs(w[0].numpy() - g['gate_' + tag]).max() < 5e-6, tag
+            assert abs(float(att.sum(0).mean()) - 1.0) < 1e-6
+    # rr = 0 collapses to the point-wise form whatever the mode (softmax over one element)
+    fl = torch.from_numpy(g['flow_mixed'])[None]
+    with torch.no_grad():
+        rk = O.conv(synthetic_sd, 'FAC_FB_Module.shared_FGAC.conv_ref_k', ref)
+        sk = O.conv(synthetic_sd, 'FAC_FB_Module.shared_FGAC.conv_source_k', src)
+    for mode in (0, 1):
+        fac0, att0 = O.fgac_window(rk, sk, fl, 0, 0, mode)
+        assert torch.equal(att0, torch.ones_like(att0))
+        assert (fac0 - O.fgac_sample_explicit(rk, fl)[0]).abs().max() < 1e-6

@@ -243,7 +243,58 @@ def round2():
     print('metrics                psnr %.6f dB  ssim %.8f' % (U.psnr(ia, ib), U.ssim(ia, ib)))
 
 
+def patched_fgac(net, rr, sr):
+    """The reference's FGAC.forward with its two hard-coded radii (DeMFInet.py:401-402) overridden IN MEMORY: the source
+    text of the method is fetched with inspect, the two constant assignments are rewritten, and the result is bound to the
+    model's own FGAC module (its weights).  Nothing is written to disk; the generalised code path (403-445) is the
+    reference's own."""
+    import inspect
+    import textwrap
+    src = textwrap.dedent(inspect.getsource(R.FGAC.forward))
+    assert src.count('rr = 0') == 1 and src.count('sr = 0') == 1
+    src = src.replace('rr = 0', 'rr = %d' % rr).replace('sr = 0', 'sr = %d' % sr)
+    ns = {}
+    exec(compile(src, 'FGAC_forward_patched', 'exec'), R.__dict__, ns)
+    fg = net.FAC_FB_Module.shared_FGAC
+    return lambda ref, source, flow: ns['forward'](fg, ref, source, flow)
+
+
+def fgac_window_fixtures():
+    """Generalised FGAC (rr, sr > 0): outputs of the PATCHED reference (see patched_fgac) -> tests/golden/fgac_window_16x24.npz."""
+    sd = synthetic_state_dict(0)
+    net = R.DeMFInet(ARGS).eval()
+    net.load_state_dict(sd)
+    H, W = 16, 24
+    g = torch.Generator().manual_seed(31)
+    ref = torch.tanh(torch.randn(1, 64, H, W, generator=g))
+    src = torch.tanh(torch.randn(1, 64, H, W, generator=g))
+    flows = {'inrange': torch.rand(1, 2, H, W, generator=g) * torch.tensor([W - 1.0, H - 1.0]).view(1, 2, 1, 1),
+             'mixed': torch.randn(1, 2, H, W, generator=g) * 9}
+    rec = dict(ref=ref[0].numpy(), src=src[0].numpy())
+    fg = net.FAC_FB_Module.shared_FGAC
+    for (rr, sr) in ((1, 0), (2, 0), (1, 1)):
+        fwd = patched_fgac(net, rr, sr)
+        for name, fl in flows.items():
+            grabbed = {}
+            hook = fg.fusion.register_forward_pre_hook(lambda mod, inp: grabbed.__setitem__('fac', inp[0].detach().clone()))
+            with torch.no_grad():
+                out, w, _ = fwd(ref, src, fl)
+                mo, mw, mfac, matt = O.fgac_general(sd, 'FAC_FB_Module.shared_FGAC', ref, src, fl, rr, sr, 0)
+            hook.remove()
+            tag = 'rr%d_sr%d_%s' % (rr, sr, name)
+            rec['flow_' + name] = fl[0].numpy()
+            rec['fac_' + tag] = grabbed['fac'][0].numpy()
+            rec['out_' + tag] = out[0].numpy()
+            rec['gate_' + tag] = w[0].numpy()
+            print('fgac_window %-22s oracle-vs-patched-reference: FAC %.3e  out %.3e' %
+                  (tag, float((grabbed['fac'] - mfac).abs().max()), float((out - mo).abs().max())))
+    np.savez_compressed(os.path.join(OUT, 'fgac_window_16x24.npz'), **rec)
+
+
 if __name__ == '__main__':
+    if '--fgac-window' in sys.argv:
+        fgac_window_fixtures()
+        sys.exit(0)
     if '--round2' in sys.argv:
         round2()
     else:
