@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('DEMFI_HIP_LIB') or os.path.join(_HERE, 'csrc', 'libdemfi_hip.so')   # override: ablation builds
 
 F16, F32 = 0, 1
-ABI_VERSION = 2
+ABI_VERSION = 3
 ACT_NONE, ACT_RELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3
 MODE_STORE, MODE_MUL, MODE_GRU = 0, 1, 2
 MAX_PIECES, MAX_CHUNKS, MAX_SEGS, MAX_OCTS = 48, 40, 8, 32
@@ -44,7 +44,11 @@ class Conv(C.Structure):
                 ('chunks', Chunk * MAX_CHUNKS), ('pieces', Piece * MAX_PIECES), ('segs', Seg * MAX_SEGS),
                 ('oct_seg', C.c_int32 * MAX_OCTS), ('oct_n', C.c_int32 * MAX_OCTS), ('oct_ch', C.c_int32 * MAX_OCTS),
                 ('sub_seg', C.c_int32 * (MAX_OCTS // 4)),
-                ('lw_magic', C.c_uint32), ('_pad2', C.c_uint32)]
+                ('lw_magic', C.c_uint32), ('u8_iter', C.c_int32), ('u8_sink', C.c_void_p)]
+
+
+class U8Sink(C.Structure):
+    _fields_ = [('frame', C.c_void_p * MAX_SEGS), ('h', C.c_int32), ('w', C.c_int32), ('iter', C.c_int32), ('_pad', C.c_int32)]
 
 
 class ConvSrc(C.Structure):
@@ -94,6 +98,8 @@ _SIGS = {
     'demfi_pack_planes': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
     'demfi_u8_to_window': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     'demfi_u8_to_planar': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    'demfi_u8_ingest': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                  C.c_void_p]),
     'demfi_frame_to_u8': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'demfi_eval_workspace_bytes': (C.c_int64, [C.c_int, C.c_int]),
     'demfi_eval_frame': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int,
@@ -116,6 +122,8 @@ _SIGS = {
     'demfi_ctx_weight_region': (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     'demfi_ctx_buffer': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int32),
                                    C.POINTER(C.c_int32)]),
+    'demfi_ingest_u8': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    'demfi_forward_trunk_body': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     'demfi_forward_trunk': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     'demfi_forward_t': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'demfi_ctx_num_ops': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),

@@ -1095,6 +1095,19 @@ __global__ __launch_bounds__(P_NT, 1) void conv3x3_narrow_persist_kernel(const d
             t_rsb[g] = sg.res.sb;
         }
     }
+    // optional uint8 sink (demfi_u8_sink, read at run time so that one captured graph serves every destination): octet g
+    // = one 3-channel frame segment whose channels all sit in the hi == 0 lane's quad
+    unsigned char* s_dst[4] = {nullptr, nullptr, nullptr, nullptr};
+    int s_h = 0, s_w = 0;
+    if constexpr (THIN) {
+        const demfi_u8_sink* sk = d->u8_sink;
+        if (sk != nullptr && sk->iter == d->u8_iter) {
+            s_h = sk->h; s_w = sk->w;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                if (t_on[g] == 3 && d->oct_ch[g] == 0) s_dst[g] = sk->frame[d->oct_seg[g]];
+        }
+    }
     int slot = 0;
     for (int k = 0; k < n_tiles; ++k) {
         int bimg, oy0, ox0;
@@ -1177,6 +1190,18 @@ __global__ __launch_bounds__(P_NT, 1) void conv3x3_narrow_persist_kernel(const d
                     for (int j = 0; j < 4; ++j) v[j] = (acc[0][p][g * 4 + j] + bq[j]) + tr[g][p][j];   // + 0 without a residual
                     apply_act_n<4>(v, t_act[g]);
                     const int oy = oy0 + wave * 2 + p, oxx = ox0 + lx;
+                    if (s_dst[g] != nullptr) {                  // wave-uniform: crop + denorm255 + uint8 truncation instead of the fp32 store
+                        if (hi == 0 && oy < s_h && oxx < s_w) {
+                            unsigned char* bp = s_dst[g] + ((int64_t)oy * s_w + oxx) * 3;
+#pragma unroll
+                            for (int j = 0; j < 3; ++j) {
+                                double q = ((double)v[j] + 1.0) / 2.0;          // denorm255_np on the float64 copy (utils.py:718-721)
+                                q = q < 0.0 ? 0.0 : (q > 1.0 ? 1.0 : q);
+                                *gp<unsigned char>(bp + j) = (unsigned char)(q * 255.0);   // .astype(np.uint8), main.py:1165-1178
+                            }
+                        }
+                        continue;
+                    }
                     if (oy < H && oxx < W) {
                         float* dp = t_dst[g] + bimg * t_dsb[g] + (int64_t)oy * W + oxx;
 #pragma unroll

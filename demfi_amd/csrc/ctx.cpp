@@ -396,6 +396,7 @@ void alloc_t(Layout& L, BufSet& s)
     const int H = L.c->H, W = L.c->W, N = L.c->N;
     const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4, H8 = H / 8, W8 = W / 8;
     L.thin(s, "t", 1, 1, 1);
+    L.raw(s, "sink", 256);                          // demfi_u8_sink record (zero = disabled: iter 0 with NULL frames writes nothing)
     L.raw(s, "cfr_acc", demfi_cfr_workspace_bytes(H, W));
     L.thin(s, "ft", 4, H, W);                       // flow_t0, flow_t1
     L.fat(s, "Ft", H, W, 64);
@@ -468,6 +469,8 @@ struct Builder {
     bool f32;
     bool dry;                  // sizing pass of demfi_ctx_create: no weights, nothing is written
     int status = DEMFI_OK;
+    const demfi_u8_sink* sink_for_next = nullptr;   // uint8 sink record of the NEXT conv() call (Dec_last2_2)
+    int sink_iter = 0;
 
     char* ptr(const Tensor& t) const { return c->base + t.off; }
     // input piece from a fat buffer [B,h,w,C]: channels [c0, c0+nch) feed original cin [cin0, cin0+nch); b < 0 keeps the
@@ -574,6 +577,9 @@ struct Builder {
         bc.d.wpack = c->base + c->w_region + w_off;
         bc.d.bias = (const float*)(c->base + c->w_region + b_off);
         bc.d.zero_page = c->base + c->zero_off;
+        bc.d.u8_sink = sink_for_next;                // set by the caller for the frame-producing layer only
+        bc.d.u8_iter = sink_iter;
+        sink_for_next = nullptr;
         c->descs.push_back(bc.d);
         demfi_op op;
         memset(&op, 0, sizeof(op));
@@ -861,6 +867,8 @@ struct Builder {
                  {D(fview(B["g_a"]), range(0, 64), R)}, H, W);
             const Tensor* g = resblocks(sg, "Decoder_res_2", c->hp.num_resb_dec, B["g_a"], B["g_t"], B["g_b"], H, W, 1);
             conv(sg, "Dec_last1_2", {fsrc(*g, 0)}, {D(fview(B["g_t"]), range(0, 64), R)}, H, W);
+            sink_for_next = (const demfi_u8_sink*)ptr(B["sink"]);
+            sink_iter = it;
             conv(sg, "Dec_last2_2", {fsrc(B["g_t"], 0)},
                  {D(tview(B["finals"], 9 * it + 0), range(0, 3), DEMFI_ACT_NONE, DEMFI_MODE_STORE, tview(B["sharp1"], 0)),
                   D(tview(B["finals"], 9 * it + 3), range(3, 6), DEMFI_ACT_NONE, DEMFI_MODE_STORE, tview(B["sharp1"], 3)),
@@ -1053,6 +1061,27 @@ extern "C" int demfi_ctx_buffer(const demfi_ctx* c, int trunk, int q, const char
     *offset = it->second.off;
     if (kind) *kind = it->second.kind;
     if (dims) for (int i = 0; i < 4; ++i) dims[i] = it->second.d[i];
+    return DEMFI_OK;
+}
+
+extern "C" int demfi_ingest_u8(demfi_ctx* c, int trunk, const uint8_t* const* frames, int h, int w, void* stream)
+{
+    if (!c || !c->bound || c->on_host || trunk < 0 || trunk >= c->n_trunk)
+        return demfi_set_error(DEMFI_ERR_ARG, "demfi_ingest_u8: context not bound to device memory / bad trunk index");
+    BufSet& B = c->tr_bufs[trunk];
+    return demfi_u8_ingest(frames, h, w, (float*)(c->base + B["x"].off), c->base + B["s2d"].off, (float*)(c->base + B["overlay"].off),
+                           c->dtype, c->H, c->W, stream);
+}
+
+extern "C" int demfi_forward_trunk_body(demfi_ctx* c, int trunk, void* stream)
+{
+    if (!c || !c->bound || c->on_host || trunk < 0 || trunk >= c->n_trunk)
+        return demfi_set_error(DEMFI_ERR_ARG, "demfi_forward_trunk_body: context not bound to device memory / bad trunk index");
+    const OpList& ops = c->tr_ops[trunk];                        // ops 0, 1 = s2d, overlay: done by demfi_ingest_u8
+    for (size_t i = 2; i < ops.size(); ++i) {
+        const int st = demfi_run_op(c, &ops[i], stream);
+        if (st < 0) return st;
+    }
     return DEMFI_OK;
 }
 

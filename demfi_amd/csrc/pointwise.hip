@@ -596,6 +596,48 @@ __global__ void u8_to_window_kernel(U8Frames fr, float* __restrict__ x, int h, i
     }
 }
 
+// u8_to_window fused with the first loads of the network: one thread per half-resolution pixel reads the 2x2 block of the 4
+// frames once and writes x (fp32 planes), the space-to-depth record of FF_RDB (48 channels: (frame*3 + c)*4 + ry*2 + rx,
+// DeMFInet.py:311-316) and the overlay mean of B0, B1 (DeMFInet.py:178).
+template <typename T>
+__global__ void u8_ingest_kernel(U8Frames fr, float* __restrict__ x, T* __restrict__ s2d, float* __restrict__ ov, int h, int w,
+                                 int H, int W)
+{
+    const int H2 = H >> 1, W2 = W >> 1;
+    const int i = blockIdx.x * NT + threadIdx.x;
+    if (i >= H2 * W2) return;
+    const int x2 = i % W2, y2 = i / W2;
+    T rec[48];
+    float b01[2][3][4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int Y = 2 * y2 + (q >> 1), X = 2 * x2 + (q & 1);
+            const int sx = X < w ? X : 2 * (w - 1) - X;
+            const int sy = Y < h ? Y : 2 * (h - 1) - Y;
+            const unsigned char* p = fr.f[f] + ((int64_t)sy * w + sx) * 3;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float v = (float)p[c] / 255.0f;
+                v = v - 0.5f;
+                v = v * 2.0f;
+                x[((int64_t)(c * 4 + f) * H + Y) * W + X] = v;
+                rec[(f * 3 + c) * 4 + q] = (T)v;
+                if (f < 2) b01[f][c][q] = v;
+            }
+        }
+    }
+    T* o = s2d + (int64_t)i * 48;
+#pragma unroll
+    for (int k = 0; k < 48 * (int)sizeof(T) / 16; ++k) st_global16((char*)o + k * 16, ((const uint4*)rec)[k]);
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            ov[((int64_t)c * H + 2 * y2 + (q >> 1)) * W + 2 * x2 + (q & 1)] = (b01[0][c][q] + b01[1][c][q]) / 2.0f;
+}
+
 // One uint8 frame -> planar fp32 [3,h,w] with the loader's arithmetic (targets of the on-GPU evaluation).
 __global__ void u8_to_planar_kernel(const unsigned char* __restrict__ f, float* __restrict__ out, int hw)
 {
@@ -800,6 +842,27 @@ extern "C" int demfi_u8_to_window(const uint8_t* const* frames, int h, int w, fl
         fr.f[i] = frames[i];
     }
     hipLaunchKernelGGL(u8_to_window_kernel, dim3(blocks_for((int64_t)4 * H * W)), dim3(NT), 0, (hipStream_t)stream, fr, x, h, w, H, W);
+    DEMFI_HIP_CHECK(hipGetLastError());
+    return DEMFI_OK;
+}
+
+extern "C" int demfi_u8_ingest(const uint8_t* const* frames, int h, int w, float* x, void* s2d, float* overlay, int dtype, int H,
+                               int W, void* stream)
+{
+    if (!frames || !x || !s2d || !overlay || h < 2 || w < 2 || H < h || W < w || H - h >= h || W - w >= w || (H & 1) || (W & 1))
+        return demfi_set_error(DEMFI_ERR_ARG, "demfi_u8_ingest: bad sizes %dx%d -> %dx%d", h, w, H, W);
+    U8Frames fr;
+    for (int i = 0; i < 4; ++i) {
+        if (!frames[i]) return demfi_set_error(DEMFI_ERR_ARG, "demfi_u8_ingest: frame %d is NULL", i);
+        fr.f[i] = frames[i];
+    }
+    const int64_t n = (int64_t)(H / 2) * (W / 2);
+    if (dtype == DEMFI_F16)
+        hipLaunchKernelGGL(u8_ingest_kernel<half_t>, dim3(blocks_for(n)), dim3(NT), 0, (hipStream_t)stream, fr, x, (half_t*)s2d, overlay, h, w, H, W);
+    else if (dtype == DEMFI_F32)
+        hipLaunchKernelGGL(u8_ingest_kernel<float>, dim3(blocks_for(n)), dim3(NT), 0, (hipStream_t)stream, fr, x, (float*)s2d, overlay, h, w, H, W);
+    else
+        return demfi_set_error(DEMFI_ERR_ARG, "demfi_u8_ingest: dtype");
     DEMFI_HIP_CHECK(hipGetLastError());
     return DEMFI_OK;
 }

@@ -272,7 +272,8 @@ class Engine:
         H, W, N = self.H, self.W, self.N
         return {'t_dev': self.buffer('t', k, c).view(1), 'sharp1': self.buffer('sharp1', k, c),
                 'finals': self.buffer('finals', k, c).view(N, 3, 3, H, W), 'delta': self.buffer('delta', k, c).view(N + 1, 5, H, W),
-                'occ': self.buffer('occ', k, c), 'ft': self.buffer('ft', k, c), 'cfr_acc': self.buffer('cfr_acc', k, c)}
+                'occ': self.buffer('occ', k, c), 'ft': self.buffer('ft', k, c), 'cfr_acc': self.buffer('cfr_acc', k, c),
+                'sink': self.buffer('sink', k, c)}
 
     @property
     def n_ctx(self):
@@ -299,6 +300,19 @@ class Engine:
     # ---- execution --------------------------------------------------------------------------------------------
     def run_trunk(self, stream):
         L.check(self.lib.demfi_forward_trunk(self._ctx, self.trunk, None, stream), 'forward_trunk')
+
+    def ingest_u8(self, frame_ptrs, h, w, stream):
+        """4 BGR uint8 [h,w,3] device frames (ctypes array of 4 pointers) -> x, s2d, overlay of the bound trunk context."""
+        L.check(self.lib.demfi_ingest_u8(self._ctx, self.trunk, frame_ptrs, h, w, stream), 'ingest_u8')
+
+    def run_trunk_body(self, stream):
+        """The trunk without its s2d / overlay prologue (what follows ingest_u8)."""
+        L.check(self.lib.demfi_forward_trunk_body(self._ctx, self.trunk, stream), 'forward_trunk_body')
+
+    @property
+    def supports_u8_sink(self):
+        """The uint8 egress is an epilogue of the fp16 thin-output kernel."""
+        return not self.f32
 
     def run_t(self, stream, n_updates):
         if not 1 <= n_updates <= self.N:

@@ -112,6 +112,7 @@ class DeMFInet(nn.Module):
         for b in range(B):
             eng.x.copy_(x[b].to(torch.float32), non_blocking=True)
             eng.t_dev.copy_(t_value[b].reshape(-1)[:1].to(torch.float32), non_blocking=True)
+            eng.sink.zero_()                        # the uint8 sink of a WindowRunner sharing this engine must not fire
             eng.run_trunk(stream)
             eng.run_t(stream, n)
             outs.append(self._collect(eng, n, clone_outputs or B > 1))
@@ -135,6 +136,7 @@ class DeMFInet(nn.Module):
         eng.x.copy_(x[0].to(torch.float32), non_blocking=True)
         eng.run_trunk(stream)
         res = []
+        eng.sink.zero_()
         for tv in t_values:
             eng.t_dev.fill_(float(tv))
             eng.run_t(stream, n)

@@ -84,10 +84,11 @@ class WindowRunner:
                 e.use_ctx(c)
                 e.run_t(h, self.n_tst)
         self.stream.synchronize()
-        self._g_trunk, self._g_t = [], []
+        self._g_trunk, self._g_t, self._g_body = [], [], []
         for k in range(self.n_trunk):
             e.use_ctx(0, trunk=k)
             self._g_trunk.append(self._capture(e.run_trunk, self.stream))
+            self._g_body.append(self._capture(e.run_trunk_body, self.stream))     # trunk after the fused uint8 ingest
             gs = []
             for c in range(self.n_ctx):
                 e.use_ctx(c)
@@ -97,9 +98,11 @@ class WindowRunner:
             s.synchronize()
         e.use_ctx(0, trunk=0)
 
-    def _window(self, load, emit):
+    def _window(self, load, emit, body_only=False, pre=None):
         """One window: load(engine, stream_handle) fills the bound trunk context's input on the trunk stream;
-        emit(j, finals, stream_handle) copies the outputs of time instant j out of a per-t context on that context's stream."""
+        emit(j, finals, stream_handle) copies the outputs of time instant j out of a per-t context on that context's stream.
+        body_only: load() already did the trunk's prologue (fused uint8 ingest).  pre(j, ctx): runs on the per-t stream before
+        the per-t segment of time instant j (sets the uint8 sink record)."""
         e = self.engine
         k = self._next_trunk
         self._next_trunk = (k + 1) % self.n_trunk
@@ -111,7 +114,9 @@ class WindowRunner:
             h = self.stream.cuda_stream
             load(e, h)
             if self.use_graph:
-                L.check(self.lib.demfi_graph_launch(self._g_trunk[k], h), 'graph_launch')
+                L.check(self.lib.demfi_graph_launch((self._g_body if body_only else self._g_trunk)[k], h), 'graph_launch')
+            elif body_only:
+                e.run_trunk_body(h)
             else:
                 e.run_trunk(h)
             ev_trunk = torch.cuda.Event()
@@ -127,6 +132,10 @@ class WindowRunner:
                 used.add(c)
             with torch.cuda.stream(st):
                 ctx['t_dev'].copy_(self.t_all[j:j + 1], non_blocking=True)
+                if pre is not None:
+                    pre(j, ctx)
+                else:
+                    ctx['sink'].zero_()              # float path: a sink left by an earlier uint8 run must not fire
                 if self.use_graph:
                     L.check(self.lib.demfi_graph_launch(self._g_t[k][c], st.cuda_stream), 'graph_launch')
                 else:
@@ -141,7 +150,8 @@ class WindowRunner:
         self._t_done[k] = evs
 
     def _destroy_graphs(self):
-        gs = list(self._g_trunk or [])
+        gs = list(self._g_trunk or []) + list(getattr(self, '_g_body', None) or [])
+        self._g_body = None
         for row in (self._g_t or []):
             gs += list(row)
         for g in gs:
@@ -219,14 +229,49 @@ class WindowRunner:
         self._end(cur)
         return out, s01
 
-    def _u8_io(self, frames_u8, out_u8, s01_u8):
-        """(load, emit) pair of one uint8 window: 4 BGR uint8 [h,w,3] GPU frames in -> out_u8 [M-1,h,w,3], s01_u8 [2,h,w,3]."""
+    def _sink_table(self, out, s01):
+        """Device table of demfi_u8_sink records, one per (window, time instant) of the output buffers out [n,M-1,h,w,3] /
+        s01 [n,2,h,w,3]: segment 0 / 1 / 2 of the last layer = S0 / S1 / St (S0, S1 are kept from the first time instant
+        only, main.py:1165-1172).  Cached per output buffer."""
+        key = (out.data_ptr(), s01.data_ptr(), out.shape[0])
+        tab = self._sink_tabs.get(key) if hasattr(self, '_sink_tabs') else None
+        if tab is None:
+            import numpy as np
+            n, m1 = out.shape[0], self.mfi - 1
+            a = np.zeros((n, m1, 32), np.int64)                  # 256-byte records (the context's "sink" buffer)
+            fsz = self.h * self.w * 3
+            for i in range(n):
+                for j in range(m1):
+                    a[i, j, 2] = out.data_ptr() + (i * m1 + j) * fsz                 # frame[2] = St
+                    if j == 0:
+                        a[i, j, 0] = s01.data_ptr() + (i * 2 + 0) * fsz              # frame[0] = S0
+                        a[i, j, 1] = s01.data_ptr() + (i * 2 + 1) * fsz              # frame[1] = S1
+                    a[i, j, 8] = self.h | (self.w << 32)                              # int32 h, w
+                    a[i, j, 9] = self.n_tst - 1                                        # int32 iter, pad
+            tab = torch.from_numpy(a).to(self.engine.device)
+            if not hasattr(self, '_sink_tabs'):
+                self._sink_tabs = {}
+            if len(self._sink_tabs) > 8:
+                self._sink_tabs.clear()
+            self._sink_tabs[key] = tab
+        return tab
+
+    def _u8_io(self, frames_u8, out_u8, s01_u8, sink_rows=None):
+        """(load, emit, pre) of one uint8 window: 4 BGR uint8 [h,w,3] GPU frames in -> out_u8 [M-1,h,w,3], s01_u8 [2,h,w,3].
+        Ingest: ONE kernel (normalise + reflect pad + pixel reshuffle + overlay) straight into the trunk context.  Egress:
+        with ``sink_rows`` (rows of _sink_table) the last layer's epilogue writes the uint8 frames itself; otherwise one
+        crop + denorm + truncate kernel per frame (fp32 path)."""
         e = self.engine
         self._check_u8_frames(frames_u8)
         ptrs = (C.c_void_p * 4)(*[f.data_ptr() for f in frames_u8])
 
         def load(eng, h):
-            L.check(self.lib.demfi_u8_to_window(ptrs, self.h, self.w, eng.x.data_ptr(), eng.H, eng.W, h), 'u8_to_window')
+            eng.ingest_u8(ptrs, self.h, self.w, h)
+
+        if sink_rows is not None:
+            def pre(j, ctx):
+                ctx['sink'][:32].copy_(sink_rows[j], non_blocking=True)
+            return load, (lambda j, fin, sh: None), pre
 
         def emit(j, fin, sh):
             L.check(self.lib.demfi_frame_to_u8(fin[2].data_ptr(), out_u8[j].data_ptr(), self.h, self.w, e.H, e.W, sh), 'to_u8')
@@ -234,7 +279,7 @@ class WindowRunner:
                 for i in range(2):
                     L.check(self.lib.demfi_frame_to_u8(fin[i].data_ptr(), s01_u8[i].data_ptr(), self.h, self.w, e.H, e.W, sh),
                             'to_u8')
-        return load, emit
+        return load, emit, None
 
     def run_window_u8(self, frames_u8):
         """uint8 in / uint8 out: frames_u8 = 4 BGR uint8 [h,w,3] GPU tensors in the order (B0,B1,B-1,B2).  Returns
@@ -244,9 +289,10 @@ class WindowRunner:
         if getattr(self, '_out_u8', None) is None:
             self._out_u8 = torch.zeros((self.mfi - 1, self.h, self.w, 3), dtype=torch.uint8, device=e.device)
             self._s01_u8 = torch.zeros((2, self.h, self.w, 3), dtype=torch.uint8, device=e.device)
-        load, emit = self._u8_io(frames_u8, self._out_u8, self._s01_u8)
+        rows = self._sink_table(self._out_u8[None], self._s01_u8[None])[0] if e.supports_u8_sink else None
+        load, emit, pre = self._u8_io(frames_u8, self._out_u8, self._s01_u8, rows)
         cur = self._begin()
-        self._window(load, emit)
+        self._window(load, emit, body_only=True, pre=pre)
         self._end(cur)
         return self._out_u8, self._s01_u8
 
@@ -260,10 +306,11 @@ class WindowRunner:
             out = torch.empty((n, self.mfi - 1, self.h, self.w, 3), dtype=torch.uint8, device=dev)
         if s01 is None:
             s01 = torch.empty((n, 2, self.h, self.w, 3), dtype=torch.uint8, device=dev)
-        io = [self._u8_io(windows_u8[i], out[i], s01[i]) for i in range(n)]
+        tab = self._sink_table(out, s01) if self.engine.supports_u8_sink else None
+        io = [self._u8_io(windows_u8[i], out[i], s01[i], None if tab is None else tab[i]) for i in range(n)]
         cur = self._begin()
-        for load, emit in io:
-            self._window(load, emit)
+        for load, emit, pre in io:
+            self._window(load, emit, body_only=True, pre=pre)
         self._end(cur)
         return out, s01
 

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DEMFI_ABI_VERSION 2
+#define DEMFI_ABI_VERSION 3
 
 enum demfi_dtype { DEMFI_F16 = 0, DEMFI_F32 = 1 };
 
@@ -132,8 +132,23 @@ typedef struct demfi_conv {
     int32_t sub_seg[DEMFI_MAX_OCTS / 4];
     /* magic = ceil(2^32 / LW), LW = (32-1)*stride + kw: exact px / LW for px < 2^16 (filled by host) */
     uint32_t lw_magic;
-    uint32_t _pad2;
+    int32_t  u8_iter;           /* recursion index this descriptor belongs to (compared with demfi_u8_sink.iter) */
+    /* optional uint8 sink (planar fp32 3-channel segments on the thin epilogue only, i.e. the frame-producing last layer
+     * Dec_last2_2): device pointer to a demfi_u8_sink record read AT RUN TIME, so a captured hipGraph serves every
+     * destination.  NULL = none. */
+    const struct demfi_u8_sink* u8_sink;
 } demfi_conv;
+
+/* uint8 egress fused into the last store: when `iter` equals the descriptor's u8_iter, segment
+ * s of the convolution additionally writes crop + denorm255_np + uint8 truncation (utils.py:718-721, main.py:1165-1178:
+ * float64 arithmetic) of its 3 channels to frame[s] as [h, w, 3] bytes (NULL = that frame is not wanted) and skips the
+ * fp32 store of that segment. */
+typedef struct demfi_u8_sink {
+    uint8_t* frame[DEMFI_MAX_SEGS];
+    int32_t  h, w;              /* crop (top-left h x w of the padded H x W) */
+    int32_t  iter;              /* recursion index whose output is the final one (num_update - 1); -1 disables */
+    int32_t  _pad;
+} demfi_u8_sink;
 
 /* ---- library / device ------------------------------------------------------------------------- */
 int         demfi_abi_version(void);
@@ -234,6 +249,11 @@ int demfi_pack_planes(const float* const* planes, int nch, void* dst, int dtype,
  * demfi_frame_to_u8: frame planar fp32 [3,H,W] -> out uint8 [h,w,3]: crop + denorm255_np (utils.py:718-721) + uint8
  * truncation (main.py:1165-1178), bit-identical to the reference's float64 arithmetic. */
 int demfi_u8_to_window(const uint8_t* const* frames, int h, int w, float* x, int H, int W, void* stream);
+/* The same fused with the first layers' loads: one pass over the 4 uint8 frames writes x (fp32 [3,4,H,W], still needed by
+ * the Mixer / D2 inputs), the space-to-depth tensor of FF_RDB (NHWC [H/2,W/2,48], path dtype; pixel_reshuffle,
+ * DeMFInet.py:234-235) and the overlay (mean of B0, B1; DeMFInet.py:178). */
+int demfi_u8_ingest(const uint8_t* const* frames, int h, int w, float* x, void* s2d, float* overlay, int dtype, int H, int W,
+                    void* stream);
 /* one BGR uint8 [h,w,3] frame -> planar fp32 [3,h,w] with the same arithmetic (ground-truth frames of the evaluation) */
 int demfi_u8_to_planar(const uint8_t* frame, int h, int w, float* out, void* stream);
 int demfi_frame_to_u8(const float* frame, uint8_t* out, int h, int w, int H, int W, void* stream);
@@ -309,7 +329,7 @@ enum demfi_op_kind {
     DEMFI_OP_CONV = 0, DEMFI_OP_PACK = 1, DEMFI_OP_S2D = 2, DEMFI_OP_OVERLAY = 3, DEMFI_OP_FGAC = 4, DEMFI_OP_GATE = 5,
     DEMFI_OP_CFR = 6, DEMFI_OP_WARP = 7, DEMFI_OP_FGAC_WINDOW = 8, DEMFI_OP_AVG_POOL = 9
 };
-enum demfi_segment { DEMFI_SEG_TRUNK = 0, DEMFI_SEG_T_HEAD = 1, DEMFI_SEG_ITER = 2 };
+enum demfi_segment { DEMFI_SEG_TRUNK = 0, DEMFI_SEG_T_HEAD = 1, DEMFI_SEG_ITER = 2 };   /* TRUNK: ops 0, 1 = s2d, overlay (the prologue demfi_ingest_u8 replaces) */
 
 /* One launch of the plan (introspection for tests / per-launch profiling; pointers are already bound). */
 typedef struct demfi_op {
@@ -345,6 +365,12 @@ int     demfi_ctx_weight_region(const demfi_ctx* ctx, int64_t* offset, int64_t* 
  * "delta" ([N+1][5]: flow_t0, flow_t1, occ logit), "occ" ([N+1]) ... every buffer of the plan is addressable. */
 int     demfi_ctx_buffer(const demfi_ctx* ctx, int trunk, int c, const char* name, int64_t* offset, int32_t* kind,
                          int32_t dims[4]);
+/* uint8 boundary of a context.  demfi_ingest_u8: 4 BGR uint8 [h,w,3] device frames (B0,B1,
+ * B-1,B2; HOST array of 4 device pointers) -> the context's x / s2d / overlay buffers (normalise + reflect pad + pixel
+ * reshuffle in one kernel); follow it with demfi_forward_trunk_body.  The per-t context's buffer "sink" is a
+ * demfi_u8_sink record: fill it (device memory) before demfi_forward_t and the last layer writes uint8 frames directly. */
+int     demfi_ingest_u8(demfi_ctx* ctx, int trunk, const uint8_t* const* frames, int h, int w, void* stream);
+int     demfi_forward_trunk_body(demfi_ctx* ctx, int trunk, void* stream);
 /* t-independent segment (FF_RDB + FAC-FB, DeMFInet.py:59, 74) of trunk context `trunk`; x: device fp32 [3,4,H,W]
  * copied into the context's input buffer first, or NULL when the caller already filled buffer "x". */
 int     demfi_forward_trunk(demfi_ctx* ctx, int trunk, const float* x, void* stream);

@@ -38,8 +38,7 @@ def _write_inputs(tmp, golden_dir, name):
 
 @pytest.mark.parametrize('name', ['e2e_64x96_t0500_n3', 'e2e_32x64_t0375_n5'])
 def test_forward_from_plain_c(tmp_path, golden_dir, name):
-    if not os.path.exists(BIN):
-        subprocess.check_call(['bash', os.path.join(ROOT, 'tests', 'c', 'build.sh')])
+    subprocess.check_call(['bash', os.path.join(ROOT, 'tests', 'c', 'build.sh')])      # < 1 s; never run a stale binary
     w, c = _write_inputs(str(tmp_path), golden_dir, name)
     r = subprocess.run([BIN, w, c], capture_output=True, text=True, timeout=300)
     print(r.stdout, r.stderr)

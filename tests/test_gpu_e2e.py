@@ -221,6 +221,18 @@ def test_uint8_io_bit_exact_and_runner_u8(model16):
     L.check(lib.demfi_frame_to_u8(fr.data_ptr(), out.data_ptr(), h, w, H, W, st))
     torch.cuda.synchronize()
     assert np.array_equal(out.cpu().numpy(), O.frame_to_u8(fr.cpu().numpy()[:, :h, :w]))
+    # fused ingest: x + space-to-depth + overlay in one pass == the three separate kernels
+    for dtype, dt in ((torch.float16, L.F16), (torch.float32, L.F32)):
+        x2 = torch.zeros(3, 4, H, W, device=DEV)
+        s2d2 = torch.zeros(H // 2, W // 2, 48, device=DEV, dtype=dtype)
+        ov2 = torch.zeros(3, H, W, device=DEV)
+        L.check(lib.demfi_u8_ingest(ptrs, h, w, x2.data_ptr(), s2d2.data_ptr(), ov2.data_ptr(), dt, H, W, st))
+        s2d1 = torch.zeros_like(s2d2)
+        ov1 = torch.zeros_like(ov2)
+        L.check(lib.demfi_space_to_depth(x.data_ptr(), s2d1.data_ptr(), dt, H, W, st))
+        L.check(lib.demfi_overlay_mean(x.data_ptr(), ov1.data_ptr(), H, W, st))
+        torch.cuda.synchronize()
+        assert torch.equal(x2, x) and torch.equal(s2d2, s2d1) and torch.equal(ov2, ov1)
     # the uint8 runner == float runner on the same window, then quantised
     N, M = 2, 4
     runner = WindowRunner(model16, h, w, n_tst=N, mfi=M)
@@ -231,6 +243,22 @@ def test_uint8_io_bit_exact_and_runner_u8(model16):
     for k in range(M - 1):
         assert np.array_equal(stu[k].cpu().numpy(), O.frame_to_u8(stf[k].cpu().numpy()))
     assert np.array_equal(s01u[1].cpu().numpy(), O.frame_to_u8(s01f[1].cpu().numpy()))
+    assert np.array_equal(s01u[0].cpu().numpy(), O.frame_to_u8(s01f[0].cpu().numpy()))
+    # the uint8 sink of the last layer must not leak into a later float run on the same engine (and vice versa)
+    stf2, _ = runner.run_window(ref[None].to(DEV))
+    torch.cuda.synchronize()
+    assert torch.equal(stf2, stf)
+    out_m = model16(torch.nn.functional.pad(ref.reshape(1, 12, h, w), [0, W - w, 0, H - h], mode='reflect').reshape(1, 3, 4, H, W).to(DEV),
+                    torch.tensor([[float(t_schedule(M)[1])]], device=DEV), N)
+    assert torch.equal(out_m[1][N - 1][2][0, :, :h, :w], stf[1])
+    # fp32 engine: no sink epilogue, the separate egress kernel is used -- same bytes as the oracle
+    m32 = _model(torch.float32)
+    r32 = WindowRunner(m32, h, w, n_tst=1, mfi=2)
+    f32, _ = r32.run_window(ref[None].to(DEV))
+    f32 = f32.clone()
+    u32, _ = r32.run_window_u8(dev)
+    torch.cuda.synchronize()
+    assert np.array_equal(u32[0].cpu().numpy(), O.frame_to_u8(f32[0].cpu().numpy()))
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.float16])
