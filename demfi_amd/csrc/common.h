@@ -30,6 +30,8 @@ typedef unsigned int u4_t __attribute__((ext_vector_type(4)));
 // 16-byte global load / store (HIP's uint4 is a class and cannot be accessed through an address-space pointer)
 __device__ __forceinline__ uint4 ld_global16(const void* p) { return __builtin_bit_cast(uint4, *gcp<u4_t>(p)); }
 __device__ __forceinline__ void st_global16(void* p, const uint4& v) { *gp<u4_t>(p) = __builtin_bit_cast(u4_t, v); }
+// streaming store (nt): for outputs nobody on this XCD re-reads soon -- keeps the L2 for the gathered inputs
+__device__ __forceinline__ void st_global16_nt(void* p, const uint4& v) { __builtin_nontemporal_store(__builtin_bit_cast(u4_t, v), gp<u4_t>(p)); }
 
 // ---- element access through demfi_view (device) --------------------------------------------------
 __device__ __forceinline__ float view_load(const demfi_view& v, int64_t off)

@@ -389,6 +389,7 @@ void alloc_trunk(Layout& L, BufSet& s)
     L.thin(s, "gate", 2, H, W);
     L.fat(s, "aF", H, W, 64, 2);
     L.thin(s, "overlay", 3, H, W);
+    if (L.c->dtype == DEMFI_F16) L.fat(s, "u1a", H2, W2, 64);     // t-independent part of Refine_Module.enc1 (see build_trunk)
 }
 
 void alloc_t(Layout& L, BufSet& s)
@@ -435,6 +436,7 @@ void alloc_t(Layout& L, BufSet& s)
     L.fat(s, "g_a", H, W, 64);
     L.fat(s, "g_t", H, W, 64);
     L.fat(s, "g_b", H, W, 64);
+    if (L.c->dtype == DEMFI_F16) { L.fat(s, "g_p", H, W, 64); L.fat(s, "g_p2", H, W, 64); }   // partial sums of Dec_first_2
     L.thin(s, "finals", 9 * N, H, W);               // [N][3 frames][3 colours]
 }
 
@@ -590,6 +592,33 @@ struct Builder {
         seg.push_back(op);
     }
 
+    // Sub-convolution over the original input channels `sel` (in that order) of layer `name`: a convolution is linear in its
+    // input channels, so conv(cat[A, B]) = conv_A(A) + conv_B(B); the fp16 plan uses it to hoist the part of a layer whose
+    // inputs do not change (per window / per recursion) and to bring the rest onto the persistent kernels.
+    struct SubW { std::vector<float> w, b; Layer shape; };
+    SubW sub_weight(const std::string& name, const std::vector<int32_t>& sel, bool with_bias)
+    {
+        SubW o;
+        auto it = c->table.find(name);
+        if (it == c->table.end()) { status = demfi_set_error(DEMFI_ERR_ARG, "unknown layer '%s'", name.c_str()); return o; }
+        const Layer& l = it->second;
+        o.shape = {l.cout, (int)sel.size(), l.kh, l.kw};
+        if (dry) return o;
+        auto iw = c->weights.find(name + ".weight"), ib = c->weights.find(name + ".bias");
+        if (iw == c->weights.end() || ib == c->weights.end()) {
+            status = demfi_set_error(DEMFI_ERR_ARG, "demfi_ctx_bind: weight '%s' was not loaded", name.c_str());
+            return o;
+        }
+        const int taps = l.kh * l.kw;
+        o.w.resize((size_t)l.cout * sel.size() * taps);
+        for (int co = 0; co < l.cout; ++co)
+            for (size_t k = 0; k < sel.size(); ++k)
+                memcpy(&o.w[((size_t)co * sel.size() + k) * taps], &iw->second.data[((size_t)co * l.cin + sel[k]) * taps], taps * sizeof(float));
+        o.b.assign(l.cout, 0.0f);
+        if (with_bias) o.b = ib->second.data;
+        return o;
+    }
+
     void simple(OpList& seg, int kind, const char* name, demfi_op op)
     {
         op.kind = kind;
@@ -708,6 +737,13 @@ struct Builder {
                 simple(tr, DEMFI_OP_GATE, "gate", o);
             }
         }
+        if (c->dtype == DEMFI_F16) {
+            // Refine_Module.enc1 = conv4x4s2(cat[aF0, aF1 | Ft, flows ...]) (DeMFInet.py:77, 588): the aF0 | aF1 half (128 of
+            // 201 input channels, 64 % of the layer) does not depend on t -> computed once per window, added as a residual
+            SubW wa = sub_weight("Refine_Module.enc1", range(0, 128), true);
+            conv(tr, "Refine_Module.enc1#aF", {fsrc(B["aF"], 0, 0, -1, 0), fsrc(B["aF"], 64, 0, -1, 1)},
+                 {D(fview(B["u1a"]), range(0, 64))}, H2, W2, 2, 1, &wa.w, &wa.b, &wa.shape);
+        }
     }
 
     void warp(OpList& seg, const char* name, int C, demfi_view A, demfi_view Bv, demfi_view O, const void* fa, const void* fb,
@@ -753,6 +789,14 @@ struct Builder {
         {
             std::vector<int32_t> m = range(192, 201);
             m.insert(m.end(), 7, -1);
+            if (c->dtype == DEMFI_F16) {
+                // the t-dependent 73 channels only; + the hoisted aF part (trunk) as residual, then ReLU
+                std::vector<int32_t> sel = range(128, 201), m2 = range(64, 73);
+                m2.insert(m2.end(), 7, -1);
+                SubW wb = sub_weight(p + "enc1", sel, false);
+                conv(th, p + "enc1#t", {fsrc(B["Ft"], 0), fsrc_map(B["misc16"], m2)},
+                     {D(fview(B["u1"]), range(0, 64), R, DEMFI_MODE_STORE, fview(TB["u1a"]))}, H2, W2, 2, 1, &wb.w, &wb.b, &wb.shape);
+            } else
             conv(th, p + "enc1", {fsrc(aF, 0, 0, -1, 0), fsrc(aF, 64, 0, -1, 1), fsrc(B["Ft"], 128), fsrc_map(B["misc16"], m)},
                  {D(fview(B["u1"]), range(0, 64), R)}, H2, W2, 2);
         }
@@ -808,6 +852,23 @@ struct Builder {
             agg3s_cin.insert(agg3s_cin.end(), 5, -1);
         }
         conv(th, p + "Mixer.conv_ref2", {fsrc(B["re1"], 0)}, {D(fview(B["ref_enc"]), range(0, 32), R)}, H, W);
+        // Dec_first_2 = relu(conv3x3(Agg3)) with Agg3 = cat[F_rec (64, changes per recursion) | 27 recursion-invariant planes |
+        // 8 planes of the current recursion] (DeMFInet.py:151-157).  fp16 plan: the invariant part + bias once per t (g_p), per
+        // recursion the 8-plane part on the narrow kernel (+ g_p -> g_p2) and the F_rec part on the persistent 64 -> 64 kernel
+        // (+ g_p2, ReLU) instead of one 112-channel launch of the general kernel.
+        std::vector<int32_t> a3_sel;                     // original input channels held by agg3s, in buffer order
+        for (int32_t ch : agg3s_cin) if (ch >= 0) a3_sel.push_back(ch);
+        const std::vector<int32_t> a3d_sel = {6, 7, 8, 82, 83, 84, 85, 86};
+        SubW w_inv, w_dyn, w_rec;
+        if (c->dtype == DEMFI_F16) {
+            w_inv = sub_weight("Dec_first_2", a3_sel, true);
+            w_dyn = sub_weight("Dec_first_2", a3d_sel, false);
+            w_rec = sub_weight("Dec_first_2", range(9, 73), false);
+            std::vector<int32_t> m = range(0, (int)a3_sel.size());
+            m.insert(m.end(), 32 - (int)a3_sel.size(), -1);
+            conv(th, "Dec_first_2#inv", {fsrc_map(B["agg3s"], m)}, {D(fview(B["g_p"]), range(0, 64))}, H, W, 1, 1, &w_inv.w, &w_inv.b,
+                 &w_inv.shape);
+        }
         // ============================ recursive boosting, one list per iteration ====================================
         // SepConvGRU (838-857): z | r share their input -> one 128-cout conv
         std::vector<float> zrw[2], zrb[2];
@@ -863,6 +924,13 @@ struct Builder {
                 pl.push_back(plane(B["occ"], it + 1));
                 pack(sg, pl, B["agg3d"]);
             }
+            if (c->dtype == DEMFI_F16) {
+                conv(sg, "Dec_first_2#dyn", {fsrc_map(B["agg3d"], range(0, 8))},
+                     {D(fview(B["g_p2"]), range(0, 64), DEMFI_ACT_NONE, DEMFI_MODE_STORE, fview(B["g_p"]))}, H, W, 1, 1, &w_dyn.w, &w_dyn.b,
+                     &w_dyn.shape);
+                conv(sg, "Dec_first_2#rec", {fsrc(hout, 0)}, {D(fview(B["g_a"]), range(0, 64), R, DEMFI_MODE_STORE, fview(B["g_p2"]))}, H, W,
+                     1, 1, &w_rec.w, &w_rec.b, &w_rec.shape);
+            } else
             conv(sg, "Dec_first_2", {fsrc(hout, 9), fsrc_map(B["agg3s"], agg3s_cin), fsrc_map(B["agg3d"], {6, 7, 8, 82, 83, 84, 85, 86})},
                  {D(fview(B["g_a"]), range(0, 64), R)}, H, W);
             const Tensor* g = resblocks(sg, "Decoder_res_2", c->hp.num_resb_dec, B["g_a"], B["g_t"], B["g_b"], H, W, 1);

@@ -3,6 +3,7 @@
 // Built with -ffp-contract=off: the coordinate arithmetic must round exactly like the reference's
 // step-by-step fp32 tensor ops so that the integer index / validity maps are bit-identical.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -350,14 +351,14 @@ struct WarpRec {                    // 20 dwords per pixel
     float ka, kb, inv_den, den;     // (1-t)*o0, t*(1-o0), 1/den, den
 };
 
-template <typename T>
-__global__ __launch_bounds__(NT) void warp_blend_fat_kernel(demfi_view A, const float* __restrict__ fa, demfi_view B,
+template <typename T, int ROWS = 4, bool NTS = false>      // ROWS: rows of the tile = waves of the workgroup; NTS: streaming output stores
+__global__ __launch_bounds__(ROWS * 64) void warp_blend_fat_kernel(demfi_view A, const float* __restrict__ fa, demfi_view B,
                                       const float* __restrict__ fb, const float* __restrict__ logit,
                                       const float* __restrict__ tptr, demfi_view O, int lpp_shift, int H, int W,
                                       float* __restrict__ occ_out, int* __restrict__ dbg)
 {
     constexpr int N = Vec16<T>::N;
-    __shared__ WarpRec recs[NT];                                  // 64 records per wave
+    __shared__ WarpRec recs[ROWS * 64];                           // 64 records per wave
     const int hw = H * W;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -366,12 +367,12 @@ __global__ __launch_bounds__(NT) void warp_blend_fat_kernel(demfi_view A, const 
     // CU's L1 or the XCD's own L2 instead of being fetched once per XCD (linear 64-pixel spans: rows y and y+1 of one
     // image column sat on different XCDs).
     const int tiles_x = (W + 63) >> 6;
-    const int ntile = tiles_x * ((H + 3) >> 2);
+    const int ntile = tiles_x * ((H + ROWS - 1) / ROWS);
     const int per = (ntile + 7) >> 3;
     const int tile = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
     if (tile >= ntile) return;
     const int ty = tile / tiles_x;
-    const int y = ty * 4 + wave;
+    const int y = ty * ROWS + wave;
     const int x0 = (tile - ty * tiles_x) << 6;
     if (y >= H) return;                                            // whole wave past the image (no workgroup barrier below)
     const int pix0 = y * W + x0;                                   // first pixel of this wave
@@ -457,7 +458,22 @@ __global__ __launch_bounds__(NT) void warp_blend_fat_kernel(demfi_view A, const 
             if constexpr (sizeof(T) == 2) o[j] = __builtin_fmaf(r.ka, wa[j], r.kb * wb[j]) * r.inv_den;      // Eq.(2), fp16 result
             else o[j] = (r.ka * wa[j] + r.kb * wb[j]) / r.den;                                              // Eq.(2), exact fp32 steps
         }
-        store16<T>((char*)O.ptr + ((int64_t)y * O.sy + (int64_t)x * O.sx) * sizeof(T) + part * 16, o);
+        char* op = (char*)O.ptr + ((int64_t)y * O.sy + (int64_t)x * O.sx) * sizeof(T) + part * 16;
+        if constexpr (NTS) {
+            if constexpr (sizeof(T) == 2) {
+                h8_t hv;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) hv[j] = (half_t)o[j];
+                st_global16_nt(op, __builtin_bit_cast(uint4, hv));
+            } else {
+                f4_t fv;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) fv[j] = o[j];
+                st_global16_nt(op, __builtin_bit_cast(uint4, fv));
+            }
+        } else {
+            store16<T>(op, o);
+        }
     };
     uint4 ra0[4], rb0[4], ra1[4], rb1[4];
     WarpRec r0, r1;
@@ -757,14 +773,21 @@ extern "C" int demfi_warp_blend(const demfi_view* A, const float* fa, const demf
         if (((int64_t)(H - 1) * A->sy + (int64_t)(W - 1) * A->sx + C) * elt >= ((int64_t)1 << 31) ||
             ((int64_t)(H - 1) * B->sy + (int64_t)(W - 1) * B->sx + C) * elt >= ((int64_t)1 << 31))
             return demfi_set_error(DEMFI_ERR_ARG, "demfi_warp_blend: image spans >= 2^31 bytes (32-bit corner offsets)");
-        // 4-row x 64-pixel tiles, 8 XCD bands of ceil(ntile / 8) tiles each
-        const unsigned nblk = 8u * (unsigned)((((W + 63) / 64) * ((H + 3) / 4) + 7) / 8);
-        if (f32)
-            hipLaunchKernelGGL(warp_blend_fat_kernel<float>, dim3(nblk), dim3(NT), 0, st, *A, fa, *B, fb, logit, t,
-                               *out, sh, H, W, occ_out, dbg_maps);
-        else
-            hipLaunchKernelGGL(warp_blend_fat_kernel<half_t>, dim3(nblk), dim3(NT), 0, st, *A, fa, *B, fb, logit,
-                               t, *out, sh, H, W, occ_out, dbg_maps);
+        // ROWS-row x 64-pixel tiles, 8 XCD bands of ceil(ntile / 8) tiles each
+        static const int var = getenv("DEMFI_WARP_VAR") ? atoi(getenv("DEMFI_WARP_VAR")) : 0;   // probe switch (tools/conv_probe.py warp)
+        const int rows = (var & 2) ? 8 : 4;
+        const unsigned nblk = 8u * (unsigned)((((W + 63) / 64) * ((H + rows - 1) / rows) + 7) / 8);
+#define DEMFI_WARP_LAUNCH(TT, R, N)                                                                                   \
+        hipLaunchKernelGGL((warp_blend_fat_kernel<TT, R, N>), dim3(nblk), dim3(R * 64), 0, st, *A, fa, *B, fb, logit, t, *out, sh, H, W, \
+                           occ_out, dbg_maps)
+        if (f32) {
+            if (var == 0) DEMFI_WARP_LAUNCH(float, 4, false); else if (var == 1) DEMFI_WARP_LAUNCH(float, 4, true);
+            else if (var == 2) DEMFI_WARP_LAUNCH(float, 8, false); else DEMFI_WARP_LAUNCH(float, 8, true);
+        } else {
+            if (var == 0) DEMFI_WARP_LAUNCH(half_t, 4, false); else if (var == 1) DEMFI_WARP_LAUNCH(half_t, 4, true);
+            else if (var == 2) DEMFI_WARP_LAUNCH(half_t, 8, false); else DEMFI_WARP_LAUNCH(half_t, 8, true);
+        }
+#undef DEMFI_WARP_LAUNCH
     } else {
         hipLaunchKernelGGL(warp_blend_thin_kernel, dim3(blocks_for(hw)), dim3(NT), 0, st, *A, fa, *B, fb, logit, t, *out, C,
                            H, W, occ_out, dbg_maps);

@@ -158,3 +158,21 @@ def test_plan_generalised_fgac(rr, sr, fmap):
     got = eng.finals[0, 2].float().numpy()
     assert O.psnr(got, ref[1][0][2][0].numpy()) > 38.0                           # fp16 storage vs fp32 oracle
     assert O.psnr(got, ref[1][0][2][0].numpy()) > O.psnr(got, base[1][0][2][0].numpy()) + 3.0   # and it is NOT the rr = 0 result
+
+
+def test_fp16_plan_with_hoisted_partial_convs(synthetic_sd):
+    """The fp16 plan splits two layers by linearity (enc1: t-independent aF half hoisted into the trunk; Dec_first_2:
+    recursion-invariant planes hoisted, the rest on the persistent kernels).  Interpreted on CPU it must still be the
+    network: compare with the fp32 oracle (fp16 storage only costs ~50 dB) and count the extra launches."""
+    H, W, N = 32, 64, 2
+    eng = Engine(synthetic_sd, H, W, torch.float16, 'cpu', max_updates=N)
+    names = [op.name.decode() for op in eng.ops(0)] + [op.name.decode() for op in eng.ops(1)] + [op.name.decode() for op in eng.ops(2, 0)]
+    assert 'Refine_Module.enc1#aF' in names and 'Refine_Module.enc1#t' in names and 'Refine_Module.enc1' not in names
+    assert {'Dec_first_2#inv', 'Dec_first_2#dyn', 'Dec_first_2#rec'} <= set(names) and 'Dec_first_2' not in names
+    x = synthetic_window(H, W, 4)
+    PlanSim(eng).forward(x, 0.375, N)
+    with torch.no_grad():
+        ref = O.forward(synthetic_sd, x, torch.tensor([[0.375]]), N)
+    for i in range(3):
+        assert O.psnr(eng.finals[N - 1, i].float().numpy(), ref[1][N - 1][i][0].numpy()) > 42.0
+    assert (eng.delta[N, 0:4].float() - ref[2][N][0]).abs().median() < 2e-2
