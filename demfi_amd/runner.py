@@ -24,7 +24,7 @@ class WindowRunner:
         self.h, self.w = height, width
         H = (height + 31) // 32 * 32
         W = (width + 31) // 32 * 32
-        self.n_ctx = int(os.environ.get('DEMFI_NCTX', 3)) if (use_graph and mfi > 2) else 1
+        self.n_ctx = min(int(os.environ.get('DEMFI_NCTX', 5)), max(1, mfi - 1)) if (use_graph and mfi > 2) else 1
         self.n_trunk = int(os.environ.get('DEMFI_NTRUNK', 2)) if use_graph else 1
         self.model = model
         self._HW = (H, W)

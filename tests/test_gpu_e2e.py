@@ -154,13 +154,13 @@ def test_window_runner_graph_replay_matches_module(model16):
 
 def test_window_runner_pipelined_windows_match_module(model16):
     """run_windows (trunk of window w+1 under the last time instants of window w, several time instants in flight on
-    separate streams, two trunk contexts x three per-t contexts) returns bit-identical frames to one forward per (window, t)."""
+    separate streams, two trunk contexts x five per-t contexts) returns bit-identical frames to one forward per (window, t)."""
     from demfi_amd.harness import t_schedule
     from demfi_amd.runner import WindowRunner
     h, w, N, M = 40, 72, 2, 8
     xs = [synthetic_window(h, w, 30 + i).to(DEV) for i in range(5)]
     runner = WindowRunner(model16, h, w, n_tst=N, mfi=M, use_graph=True)
-    assert runner.n_trunk == 2 and runner.n_ctx == 3
+    assert runner.n_trunk == 2 and runner.n_ctx == 5
     for rep in range(2):
         st, s01 = runner.run_windows(xs)
         torch.cuda.synchronize()

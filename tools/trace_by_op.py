@@ -1,0 +1,59 @@
+"""Map a rocprofv3 kernel trace of a SEQUENTIAL bench run (DEMFI_NCTX=1 DEMFI_NTRUNK=1: one stream, plan order) back to
+the ops of the launch plan and average the true kernel durations per op.
+
+    python tools/trace_by_op.py <kernel_trace.csv> <ops.txt written by bench.py --profile-ops> [out.md]
+
+The trace holds, per window, the trunk ops followed by 7 per-t passes; a per-t pass is recognised as the longest
+period of the kernel-name sequence.  Output: per op (plan order) the kernel name, calls and mean / min duration --
+the in-sequence ground truth the per-launch HIP-event numbers of bench.py are compared with."""
+import csv
+import sys
+from collections import defaultdict
+
+
+def main():
+    trace, ops_path = sys.argv[1], sys.argv[2]
+    out = open(sys.argv[3], 'w') if len(sys.argv) > 3 else sys.stdout
+    rows = []
+    for r in csv.DictReader(open(trace)):
+        rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']) - int(r['Start_Timestamp']), r['Kernel_Name']))
+    rows.sort()
+    ops = [l.split() for l in open(ops_path) if l.strip()]
+    n_trunk = sum(1 for o in ops if o[0] == 'trunk')
+    n_t = len(ops) - n_trunk
+    names = [r[2] for r in rows]
+    # kernels per plan op: cfr = 2 kernels (far + tile), every other op 1
+    per = [2 if o[1] == 'cfr' else 1 for o in ops]
+    k_trunk, k_t = sum(per[:n_trunk]), sum(per[n_trunk:])
+    # find windows: a window = k_trunk + 7 * k_t kernels (+ ingest / egress kernels of the runner, which carry other names)
+    plan_kernels = [n for n in names if 'u8_' not in n and 'frame_to_u8' not in n and 'reflect_pad' not in n and 'Memcpy' not in n
+                    and 'fill' not in n.lower() and 'copy' not in n.lower() and 'elementwise' not in n.lower()]
+    idx = [i for i, n in enumerate(names) if n in set(plan_kernels)]
+    win = k_trunk + 7 * k_t
+    nwin = len(idx) // win
+    acc = defaultdict(list)
+    for wi in range(nwin):
+        base = wi * win
+        pos = 0
+        for oi, o in enumerate(ops[:n_trunk]):
+            d = sum(rows[idx[base + pos + j]][1] for j in range(per[oi]))
+            acc[oi].append((d, rows[idx[base + pos]][2]))
+            pos += per[oi]
+        for t in range(7):
+            for oi in range(n_trunk, len(ops)):
+                d = sum(rows[idx[base + pos + j]][1] for j in range(per[oi]))
+                acc[oi].append((d, rows[idx[base + pos]][2]))
+                pos += per[oi]
+    out.write('| segment | op | name | kernel | calls | mean us | min us | bench events us |\n|---|---|---|---|---|---|---|---|\n')
+    for oi, o in enumerate(ops):
+        ds = [d for d, _ in acc[oi]]
+        if not ds:
+            continue
+        kn = acc[oi][0][1]
+        kn = kn.split('(anonymous namespace)::')[-1].split('(')[0][:44]
+        out.write('| %s | %s | %s | %s | %d | %.1f | %.1f | %.1f |\n' % (o[0], o[1], o[2], kn, len(ds), sum(ds) / len(ds) / 1e3, min(ds) / 1e3,
+                                                                  float(o[3]) * 1e3))
+
+
+if __name__ == '__main__':
+    main()

@@ -6,6 +6,6 @@ m = DeMFInet(HyperParams(), dtype=torch.float16); m.load_state_dict(synthetic_st
 x = synthetic_window(736, 1280, 1).to('cuda:0')
 m(x, torch.tensor([[0.5]], device='cuda:0'), 3)
 eng = m.engine(736, 1280, 3)
-prof = eng.profile(3, reps=20)
+prof = eng.profile(3, reps=10, isolated=bool(int(os.environ.get('ISOLATED', '0'))))
 for p in prof:
     if p[1] in ('warp_fat',): print(os.environ.get('DEMFI_WARP_VAR','0'), p[1], '%.4f ms' % p[3], '%.1f GB/s' % (404*736*1280/p[3]/1e6))
