@@ -174,9 +174,8 @@ def main():
                        'frames_per_step': a.mfi - 1, 'graph': not a.no_graph, 'parallelism': 'clip%d' % world,
                        'h2d_bytes_per_step': 4 * a.height * a.width * 3, 'd2h_bytes_per_step': (a.mfi + 1) * a.height * a.width * 3},
         }
-        # ---- roofline of the dominant kernel, measured live with HIP events on the launch stream, IN SEQUENCE (every kernel sees
-        # the cache state the pipeline leaves it; mean over 5 passes) ----
-        prof = eng.profile(a.n_tst)
+        # ---- roofline of the dominant kernel, measured live with HIP events on the launch stream (mean of 5 launches per op) ----
+        prof = eng.profile(a.n_tst, isolated=True)
         per_t = sum(p[3] for p in prof if p[0] != 'trunk')
         trunk = sum(p[3] for p in prof if p[0] == 'trunk')
         convs = [p for p in prof if p[1] == 'conv']
@@ -199,7 +198,7 @@ def main():
                            'traffic': pmc.get('dominant_traffic_bytes') if pmc else None,
                            'algorithmic_bytes': pmc.get('dominant_algorithmic_bytes') if pmc else None,
                            'traffic_source': pmc.get('source') if pmc else None,
-                           'avg_launch_ms': round(g_ms, 4), 'flop_per_launch': g_fl, 'timing': 'mean over 5 in-sequence passes (HIP events between consecutive launches of the whole forward)',
+                           'avg_launch_ms': round(g_ms, 4), 'flop_per_launch': g_fl, 'timing': 'mean of 5 launches per op, HIP events on the launch stream around each launch (agrees with the rocprofv3 in-sequence kernel durations in profiles/r02_seq_trace_by_op.md; events BETWEEN consecutive launches of a whole pass read 5-8 us higher: launch gaps)',
                            'all_convs_TFLOPs': round(tot_conv_fl / (tot_conv_ms * 1e-3) / 1e12, 2),
                            'slowest_conv': '%s %.3f ms' % (dom[2], dom[3])}
         wb = [p for p in prof if p[1] == 'warp_fat']
