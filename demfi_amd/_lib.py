@@ -105,7 +105,7 @@ _SIGS = {
     'demfi_eval_frame': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int,
                                    C.c_void_p, C.c_void_p, C.c_void_p]),
     'demfi_png_encode_bound': (C.c_int64, [C.c_int, C.c_int]),
-    'demfi_png_encode': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int64,
+    'demfi_png_encode': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64,
                                    C.POINTER(C.c_int64)]),
     'demfi_png_info': (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     'demfi_png_decode': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_int]),

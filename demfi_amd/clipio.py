@@ -26,8 +26,9 @@ def png_decode(data):
     return out
 
 
-def png_encode(img, level=1, filter=-1):
-    """uint8 [h,w,3] BGR -> PNG bytes (8-bit RGB, lossless: decodes to the pixels ``cv2.imwrite`` would store)."""
+def png_encode(img, level=1, filter=1, strategy=-1):
+    """uint8 [h,w,3] BGR -> PNG bytes (8-bit RGB, lossless: decodes to the pixels ``cv2.imwrite`` would store).  Defaults =
+    OpenCV's writer: zlib level 1, Sub filter, Z_RLE; filter=-1 / level 6 trade time for size."""
     lib = L.load()
     img = np.ascontiguousarray(img)
     if img.dtype != np.uint8 or img.ndim != 3 or img.shape[2] != 3:
@@ -36,7 +37,7 @@ def png_encode(img, level=1, filter=-1):
     cap = lib.demfi_png_encode_bound(h, w)
     out = np.empty(cap, np.uint8)
     n = C.c_int64(0)
-    L.check(lib.demfi_png_encode(img.ctypes.data, h, w, w * 3, level, filter, out.ctypes.data, cap, C.byref(n)), 'png_encode')
+    L.check(lib.demfi_png_encode(img.ctypes.data, h, w, w * 3, level, filter, strategy, out.ctypes.data, cap, C.byref(n)), 'png_encode')
     return out[:n.value].tobytes()
 
 

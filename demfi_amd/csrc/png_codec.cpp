@@ -61,15 +61,17 @@ extern "C" int64_t demfi_png_encode_bound(int h, int w)
 {
     if (h <= 0 || w <= 0) return 0;
     const uLong raw = (uLong)h * ((uLong)w * 3 + 1);
-    return (int64_t)compressBound(raw) + 128;
+    return (int64_t)compressBound(raw) + 4096;
 }
 
-// bgr: uint8 [h,w,3] with row stride `stride` bytes.  level: zlib 0..9 (cv2's default is 1 with Z_RLE-ish speed settings; 1-3
-// keeps a core under ~25 ms per 720p frame).  filter: -1 = adaptive (min-sum heuristic over the 5 filters), 0..4 = fixed.
-extern "C" int demfi_png_encode(const uint8_t* bgr, int h, int w, int64_t stride, int level, int filter, uint8_t* out,
+// bgr: uint8 [h,w,3] with row stride `stride` bytes.  level: zlib 0..9; filter: -1 = adaptive (min-sum heuristic over the 5
+// filters, libpng's default), 0..4 = fixed (1 = Sub is what OpenCV's writer sets); strategy: -1 = Z_RLE for level <= 3 (OpenCV's
+// default), else a zlib strategy constant.  level 1 / Sub / RLE: ~15 ms per 720p frame and core.
+extern "C" int demfi_png_encode(const uint8_t* bgr, int h, int w, int64_t stride, int level, int filter, int strategy, uint8_t* out,
                                 int64_t out_cap, int64_t* out_bytes)
 {
-    if (!bgr || !out || !out_bytes || h <= 0 || w <= 0 || stride < (int64_t)w * 3 || level < 0 || level > 9 || filter < -1 || filter > 4)
+    if (!bgr || !out || !out_bytes || h <= 0 || w <= 0 || stride < (int64_t)w * 3 || level < 0 || level > 9 || filter < -1 || filter > 4 ||
+        strategy > 4)
         return demfi_set_error(DEMFI_ERR_ARG, "demfi_png_encode: bad arguments");
     const int n = w * 3, bpp = 3;
     std::vector<uint8_t> raw((size_t)h * (n + 1));
@@ -79,7 +81,18 @@ extern "C" int demfi_png_encode(const uint8_t* bgr, int h, int w, int64_t stride
         for (int x = 0; x < w; ++x) { cur[3 * x] = src[3 * x + 2]; cur[3 * x + 1] = src[3 * x + 1]; cur[3 * x + 2] = src[3 * x]; }   // BGR -> RGB
         const uint8_t* pv = y ? prev.data() : nullptr;
         uint8_t* dst = &raw[(size_t)y * (n + 1)];
-        if (filter >= 0) {
+        if (filter == 1) {                                       // Sub: OpenCV's default; branch-free, vectorisable
+            dst[0] = 1;
+            const uint8_t* r = cur.data();
+            uint8_t* q = dst + 1;
+            q[0] = r[0]; q[1] = r[1]; q[2] = r[2];
+            for (int i = 3; i < n; ++i) q[i] = (uint8_t)(r[i] - r[i - 3]);
+        } else if (filter == 2 && pv) {
+            dst[0] = 2;
+            const uint8_t* r = cur.data();
+            uint8_t* q = dst + 1;
+            for (int i = 0; i < n; ++i) q[i] = (uint8_t)(r[i] - pv[i]);
+        } else if (filter >= 0) {
             dst[0] = (uint8_t)filter;
             filter_row(filter, cur.data(), pv, n, bpp, dst + 1);
         } else {
@@ -94,10 +107,20 @@ extern "C" int demfi_png_encode(const uint8_t* bgr, int h, int w, int64_t stride
         }
         prev.swap(cur);
     }
-    uLongf zn = compressBound((uLong)raw.size());
+    // deflate: Z_RLE at a low level is what OpenCV's PNG writer uses by default (fast: the filtered rows are run-friendly);
+    // strategy < 0 = Z_RLE for level <= 3, Z_DEFAULT_STRATEGY above
+    const int strat = strategy >= 0 ? strategy : (level <= 3 ? Z_RLE : Z_DEFAULT_STRATEGY);
+    z_stream zs;
+    memset(&zs, 0, sizeof(zs));
+    if (deflateInit2(&zs, level, Z_DEFLATED, 15, 8, strat) != Z_OK) return demfi_set_error(DEMFI_ERR_ARG, "demfi_png_encode: deflateInit2 failed");
+    uLongf zn = deflateBound(&zs, (uLong)raw.size());
     std::vector<uint8_t> z(zn);
-    if (compress2(z.data(), &zn, raw.data(), (uLong)raw.size(), level) != Z_OK)
-        return demfi_set_error(DEMFI_ERR_ARG, "demfi_png_encode: zlib compress2 failed");
+    zs.next_in = raw.data(); zs.avail_in = (uInt)raw.size();
+    zs.next_out = z.data(); zs.avail_out = (uInt)zn;
+    const int zr = deflate(&zs, Z_FINISH);
+    zn = zs.total_out;
+    deflateEnd(&zs);
+    if (zr != Z_STREAM_END) return demfi_set_error(DEMFI_ERR_ARG, "demfi_png_encode: deflate failed (%d)", zr);
     std::vector<uint8_t> o(PNG_SIG, PNG_SIG + 8);
     uint8_t ihdr[13];
     put32(ihdr, (uint32_t)w);

@@ -272,9 +272,10 @@ int demfi_eval_frame(const float* pred, int64_t pred_row_stride, int64_t pred_ch
 /* ---- PNG codec of the clip I/O edge (host only, thread-safe) -------------------------
  * Counterpart of cv2.imread (utils.py:583-593) / cv2.imwrite (main.py:1165-1178) on zlib: uint8 [h,w,3] images in cv2's
  * B,G,R order, `stride` bytes per row.  decode: 8/16-bit gray / RGB / palette / +alpha, non-interlaced -> BGR8 (what
- * cv2.imread(path) returns); encode: 8-bit RGB, zlib `level` 0..9, filter -1 = adaptive (libpng's heuristic) or 0..4. */
+ * cv2.imread(path) returns); encode: 8-bit RGB, zlib `level` 0..9, filter -1 = adaptive (libpng's heuristic) or 0..4 (1 = Sub, OpenCV's default),
+ * strategy -1 = Z_RLE at level <= 3 (OpenCV's default) or a zlib strategy constant. */
 int64_t demfi_png_encode_bound(int h, int w);
-int demfi_png_encode(const uint8_t* bgr, int h, int w, int64_t stride, int level, int filter, uint8_t* out,
+int demfi_png_encode(const uint8_t* bgr, int h, int w, int64_t stride, int level, int filter, int strategy, uint8_t* out,
                      int64_t out_cap, int64_t* out_bytes);
 int demfi_png_info(const uint8_t* data, int64_t n, int* h, int* w);
 int demfi_png_decode(const uint8_t* data, int64_t n, uint8_t* bgr, int64_t stride, int h_expect, int w_expect);
