@@ -921,30 +921,33 @@ int launch_persist(const demfi_conv* h, const demfi_conv* dev, hipStream_t st)
 //     these layers is only ~1 us of work, much less than the HBM latency;
 //   * MFMA loop pipelined per k-step (fragments two steps ahead); register epilogue as above.
 // ======================================================================================================
-template <int REC> struct NarrowCfg {
+template <int REC, int KS = 3> struct NarrowCfg {                // KS: filter size (3, or 7 for Mixer.conv_delta1)
+    static constexpr int LW = TW + KS - 1, LH = TH + KS - 1, NP = LW * LH, PAD = KS / 2, NTAPS = KS * KS;
     static constexpr int NKS = REC / 32;                        // k-steps per tap
     static constexpr int SL = REC / 16;                         // 16-byte slots per record
     static constexpr int PPI = 1024 / REC;                      // records per DMA instruction
-    static constexpr int NI = (P_NP + PPI - 1) / PPI;           // DMA instructions per tile: 43 / 22 / 11
+    static constexpr int NI = (NP + PPI - 1) / PPI;             // DMA instructions per tile: 43 / 22 / 11 (3x3), 17 (7x7, REC 32)
     static constexpr int TILE_BYTES = NI * 1024;
     static constexpr int NBUF = REC == 128 ? 2 : (REC == 64 ? 3 : 4);
     static_assert((NBUF - 1) * NI <= 63, "tiles in flight must be countable in vmcnt");
+    static_assert(KS == 3 || (KS == 7 && REC == 32), "7x7: one 16-channel k-step per tap (49 KiB of resident weights)");
     static __device__ __forceinline__ int swz(int col) { return REC == 128 ? (col >> 1) & 7 : (REC == 64 ? (col >> 2) & 3 : (col >> 4) & 1); }
-    static constexpr size_t lds_bytes(int nco) { return (size_t)9 * NKS * nco * 1024 + (size_t)NBUF * TILE_BYTES + 1024; }
+    static constexpr size_t lds_bytes(int nco) { return (size_t)NTAPS * NKS * nco * 1024 + (size_t)NBUF * TILE_BYTES + 1024; }
 };
 
 struct NarrowFrag { uint4 a[2], b0, b1; };
 
 // EPI: 0 = one NHWC fp16 destination, 1 = the same + residual, 2 = THIN: planar fp32 destinations / residuals routed per
 // octet (Dec_last2, Dec_last2_2, flow_occ.conv2, w_gen_2: <= 32 packed couts, NCO == 1)
-template <int NCO, int REC, int EPI>
+template <int NCO, int REC, int EPI, int KS = 3>
 __global__ __launch_bounds__(P_NT, 1) void conv3x3_narrow_persist_kernel(const demfi_conv* __restrict__ d)
 {
     constexpr bool RES = EPI == 1, THIN = EPI == 2;
     static_assert(!THIN || NCO == 1, "thin epilogue: one 32-cout subtile");
-    using Cfg = NarrowCfg<REC>;
+    using Cfg = NarrowCfg<REC, KS>;
+    constexpr int P_LW = Cfg::LW, P_NP = Cfg::NP, PAD = Cfg::PAD;      // shadow the 3x3 constants of the 64-channel kernel
     constexpr int NKS = Cfg::NKS, SL = Cfg::SL, NI = Cfg::NI, NBUF = Cfg::NBUF, TILE_BYTES = Cfg::TILE_BYTES;
-    constexpr int NSTEP = 9 * NKS;
+    constexpr int NSTEP = Cfg::NTAPS * NKS;
     constexpr int WBYTES = NSTEP * NCO * 1024;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -1018,14 +1021,14 @@ __global__ __launch_bounds__(P_NT, 1) void conv3x3_narrow_persist_kernel(const d
         auto issue_tile = [&](int k) {
             int bimg, oy0, ox0;
             tile_coords(t_first + k * t_step, bimg, oy0, ox0);
-            const char* base0 = src[0] + (int64_t)bimg * psb[0] + (int64_t)(oy0 - 1) * psy[0] + (int64_t)(ox0 - 1) * psx[0];
-            const char* base1 = src[1] + (int64_t)bimg * psb[1] + (int64_t)(oy0 - 1) * psy[1] + (int64_t)(ox0 - 1) * psx[1];
+            const char* base0 = src[0] + (int64_t)bimg * psb[0] + (int64_t)(oy0 - PAD) * psy[0] + (int64_t)(ox0 - PAD) * psx[0];
+            const char* base1 = src[1] + (int64_t)bimg * psb[1] + (int64_t)(oy0 - PAD) * psy[1] + (int64_t)(ox0 - PAD) * psx[1];
             char* dst = tbuf + (k % NBUF) * TILE_BYTES;
-            const bool interior = oy0 >= 1 && oy0 + TH + 1 <= H && ox0 >= 1 && ox0 + TW + 1 <= W;
+            const bool interior = oy0 >= PAD && oy0 + TH + PAD <= H && ox0 >= PAD && ox0 + TW + PAD <= W;
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
                 const int sel = meta[i] >> 16;
-                const int iy = oy0 - 1 + (meta[i] & 255), ix = ox0 - 1 + ((meta[i] >> 8) & 255);
+                const int iy = oy0 - PAD + (meta[i] & 255), ix = ox0 - PAD + ((meta[i] >> 8) & 255);
                 const bool ok = sel != 2 && (interior || (iy >= 0 && iy < H && ix >= 0 && ix < W));
                 const char* g = ok ? (sel == 1 ? base1 : base0) + off[i] : zeros;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
@@ -1063,9 +1066,9 @@ __global__ __launch_bounds__(P_NT, 1) void conv3x3_narrow_persist_kernel(const d
     float* const bias_lds = (float*)(tbuf + NBUF * TILE_BYTES);
     if (tid < NCO * 32) bias_lds[tid] = d->bias[tid];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    int boff[3 * NKS];                                          // [kx*NKS + ks]: record (lx + kx) + swizzled 16-byte slot
+    int boff[KS * NKS];                                         // [kx*NKS + ks]: record (lx + kx) + swizzled 16-byte slot
 #pragma unroll
-    for (int g = 0; g < 3 * NKS; ++g) {
+    for (int g = 0; g < KS * NKS; ++g) {
         const int col = lx + g / NKS;
         boff[g] = col * REC + ((((g % NKS) * 2 + hi) ^ Cfg::swz(col)) << 4);
     }
@@ -1151,7 +1154,7 @@ __global__ __launch_bounds__(P_NT, 1) void conv3x3_narrow_persist_kernel(const d
         {
             auto load_step = [&](NarrowFrag& f, int g) {        // g = tap*NKS + ks
                 const int tap = g / NKS, ks = g % NKS;
-                const int ky = tap / 3, kx = tap % 3;
+                const int ky = tap / KS, kx = tap % KS;
 #pragma unroll
                 for (int s = 0; s < NCO; ++s) f.a[s] = *(const uint4*)(wl + (g * NCO + s) * 1024);
                 const char* p0 = tb + boff[kx * NKS + ks];
@@ -1256,18 +1259,18 @@ __global__ __launch_bounds__(P_NT, 1) void conv3x3_narrow_persist_kernel(const d
     }
 }
 
-template <int NCO, int REC>
+template <int NCO, int REC, int KS = 3>
 int launch_narrow(const demfi_conv* h, const demfi_conv* dev, hipStream_t st, bool thin)
 {
-    const size_t lds = NarrowCfg<REC>::lds_bytes(NCO);
+    const size_t lds = NarrowCfg<REC, KS>::lds_bytes(NCO);
     static bool attr_done = false;
     if (!attr_done) {
-        DEMFI_HIP_CHECK(hipFuncSetAttribute((const void*)conv3x3_narrow_persist_kernel<NCO, REC, 1>,
+        DEMFI_HIP_CHECK(hipFuncSetAttribute((const void*)conv3x3_narrow_persist_kernel<NCO, REC, 1, KS>,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        DEMFI_HIP_CHECK(hipFuncSetAttribute((const void*)conv3x3_narrow_persist_kernel<NCO, REC, 0>,
+        DEMFI_HIP_CHECK(hipFuncSetAttribute((const void*)conv3x3_narrow_persist_kernel<NCO, REC, 0, KS>,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         if constexpr (NCO == 1)
-            DEMFI_HIP_CHECK(hipFuncSetAttribute((const void*)conv3x3_narrow_persist_kernel<1, REC, 2>,
+            DEMFI_HIP_CHECK(hipFuncSetAttribute((const void*)conv3x3_narrow_persist_kernel<1, REC, 2, KS>,
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done = true;
     }
@@ -1275,13 +1278,13 @@ int launch_narrow(const demfi_conv* h, const demfi_conv* dev, hipStream_t st, bo
     const int grid = total >= 256 ? 256 : total;
     if (thin) {
         if constexpr (NCO == 1)
-            hipLaunchKernelGGL((conv3x3_narrow_persist_kernel<1, REC, 2>), dim3(grid), dim3(P_NT), lds, st, dev);
+            hipLaunchKernelGGL((conv3x3_narrow_persist_kernel<1, REC, 2, KS>), dim3(grid), dim3(P_NT), lds, st, dev);
         else
             return demfi_set_error(DEMFI_ERR_ARG, "demfi_conv2d: thin epilogue needs nco == 1");
     } else if (h->segs[h->sub_seg[0]].res.ptr != nullptr)
-        hipLaunchKernelGGL((conv3x3_narrow_persist_kernel<NCO, REC, 1>), dim3(grid), dim3(P_NT), lds, st, dev);
+        hipLaunchKernelGGL((conv3x3_narrow_persist_kernel<NCO, REC, 1, KS>), dim3(grid), dim3(P_NT), lds, st, dev);
     else
-        hipLaunchKernelGGL((conv3x3_narrow_persist_kernel<NCO, REC, 0>), dim3(grid), dim3(P_NT), lds, st, dev);
+        hipLaunchKernelGGL((conv3x3_narrow_persist_kernel<NCO, REC, 0, KS>), dim3(grid), dim3(P_NT), lds, st, dev);
     DEMFI_HIP_CHECK(hipGetLastError());
     return DEMFI_OK;
 }
@@ -1720,10 +1723,12 @@ static bool thin_out_eligible(const demfi_conv* h)
 // narrow layers: one chunk of 32 / 64 / 128 bytes built from <= 2 NHWC fp16 pieces + zero padding
 static bool narrow_eligible(const demfi_conv* h)
 {
-    if (h->dtype != DEMFI_F16 || h->stride != 1 || h->kh != 3 || h->kw != 3 || h->pad_y != 1 || h->pad_x != 1) return false;
+    if (h->dtype != DEMFI_F16 || h->stride != 1 || h->kh != h->kw || (h->kh != 3 && h->kh != 7) || h->pad_y != h->kh / 2 || h->pad_x != h->kw / 2)
+        return false;
     if (h->n_chunks != 1) return false;
     const demfi_chunk& ch = h->chunks[0];
     if (ch.nks != 1 && ch.nks != 2 && ch.nks != 4) return false;
+    if (h->kh == 7 && (ch.nks != 1 || h->nco != 1)) return false;      // 7x7: 16 input channels, 32 outputs (Mixer.conv_delta1)
     int nreal = 0;
     for (int k = 0; k < ch.n_pieces; ++k) {
         const demfi_piece& p = h->pieces[ch.first_piece + k];
@@ -1890,6 +1895,9 @@ extern "C" int demfi_conv2d(const demfi_conv* h, const demfi_conv* dev, void* st
 #endif
         {
             const bool thin = !persist_out_eligible(h);
+            if (h->kh == 7) {
+                if (!thin) return launch_narrow<1, 32, 7>(h, dev, st, false);
+            } else
             switch (h->chunks[0].nks * 2 + h->nco) {
             case 1 * 2 + 1: return launch_narrow<1, 32>(h, dev, st, thin);
             case 1 * 2 + 2: return launch_narrow<2, 32>(h, dev, st, thin);

@@ -221,6 +221,29 @@ def test_narrow_persistent_conv(case, H, W, batch):
     assert err < 4e-3 * max(1.0, ref.abs().max().item()), (case, err)
 
 
+@pytest.mark.parametrize('H,W', [(8, 32), (37, 75), (64, 96), (19, 130)])
+def test_narrow_persistent_conv_7x7(H, W):
+    """Mixer.conv_delta1 (7x7, 5 -> 32, DeMFInet.py:800-812): the 7x7 instantiation of the narrow persistent kernel (49 taps of
+    resident weights, one 16-channel k-step per tap, 14x38-pixel tiles) instead of the general kernel's 49 per-tap barriers."""
+    torch.manual_seed(5)
+    pl = Plan(H, W, torch.float16, DEV)
+    b = pl._fat(H, W, 8)
+    b.copy_(torch.randn(b.shape, device=DEV))
+    out = pl._fat(H, W, 32)
+    wt = torch.randn(32, 5, 7, 7) * (1.0 / (5 * 49) ** 0.5)
+    bs = torch.randn(32) * 0.1
+    pl.conv([], 'delta1', [pl.fsrc_map(b, [0, 1, 2, 3, 4, -1, -1, -1])], [_Dst(pl.fview(out), range(32), L.ACT_RELU)], H, W, weight=wt, bias=bs)
+    pl._upload()
+    for rep in range(2):
+        out.zero_()
+        pl.launch_conv(0, _stream())
+    torch.cuda.synchronize()
+    nchw = lambda t: t.permute(0, 3, 1, 2).double().cpu()
+    ref = torch.relu(torch.nn.functional.conv2d(nchw(b[..., :5]), wt.half().double(), bs.double(), padding=3))
+    err = (nchw(out) - ref).abs().max().item()
+    assert err < 4e-3 * max(1.0, ref.abs().max().item()), err
+
+
 THIN_CASES = [
     # cin, list of (n couts, residual?) per destination tensor, act, batch
     (64, [(3, True), (3, True), (3, True)], L.ACT_NONE, 1),      # Dec_last2_2: three frames, each + its own residual
