@@ -456,8 +456,12 @@ template <int NCO> struct FragSet { uint4 a[2][NCO]; uint4 b[2][2]; };
 // a few instructions at a time, between the MFMAs of the other.  Measured 0.30 ms vs 0.28 ms for the plain version (both with raw barriers; residual loads issued through inline asm with one manual vmcnt wait per half-phase)
 // (3x3 64->64, 736x1280, batch 3): halving the A-fragment reuse (3 ds_reads per 2 MFMAs) costs more than the hidden
 // epilogue gains.
+#ifndef DEMFI_P_NDMA
+#define DEMFI_P_NDMA 2
+#endif
+constexpr int P_NDMA = DEMFI_P_NDMA;                            // waves issuing the tile DMA (instruction i -> wave i % P_NDMA)
 template <int NCO, int VAR, bool PIPE = false, bool RES = true>   // RES: the segment has a residual input (compile time: keeps the loads free of phis).  VAR: 0 = product; 1 no epilogue, 2 no MFMA phase, 3 no tile DMA, 4 epilogue only (ablation builds)
-__global__ __launch_bounds__(P_NT, 1) void conv3x3_c64_persist_kernel(const demfi_conv* __restrict__ d)
+__global__ __launch_bounds__(NT + 64 * P_NDMA, 1) void conv3x3_c64_persist_kernel(const demfi_conv* __restrict__ d)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NTAPS = 9, NKS = 4;
@@ -498,8 +502,9 @@ __global__ __launch_bounds__(P_NT, 1) void conv3x3_c64_persist_kernel(const demf
         ox0 = (rem - ty * tiles_x) * TW;
     };
 
-    if (wave == 4) {
-        // ================= DMA wave: owns every global->LDS transfer, so only ITS vmcnt tracks them ==============
+    if (wave >= 4) {
+        // ================= DMA waves: own every global->LDS transfer, so only THEIR vmcnt tracks them ============
+        const int dw = wave - 4;
         const demfi_piece& pc = d->pieces[0];
         const char* const src = (const char*)pc.v.ptr;
         const int64_t sx = pc.v.sx * 2, sy = pc.v.sy * 2, sb = pc.v.sb * 2;
@@ -526,6 +531,7 @@ __global__ __launch_bounds__(P_NT, 1) void conv3x3_c64_persist_kernel(const demf
             if (interior) {
 #pragma unroll
                 for (int i = 0; i < P_NI; ++i) {
+                    if ((i % P_NDMA) != dw) continue;            // wave-uniform
                     const char* g = (i == P_NI - 1 && lyx[i] == 0xffff) ? zeros : base + off[i];
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                                      (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
@@ -533,6 +539,7 @@ __global__ __launch_bounds__(P_NT, 1) void conv3x3_c64_persist_kernel(const demf
             } else {
 #pragma unroll
                 for (int i = 0; i < P_NI; ++i) {
+                    if ((i % P_NDMA) != dw) continue;
                     const int iy = oy0 - 1 + (lyx[i] & 255), ix = ox0 - 1 + (lyx[i] >> 8);
                     const char* g = (lyx[i] != 0xffff && iy >= 0 && iy < H && ix >= 0 && ix < W) ? base + off[i] : zeros;
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
@@ -541,7 +548,7 @@ __global__ __launch_bounds__(P_NT, 1) void conv3x3_c64_persist_kernel(const demf
             }
         };
         const uint4* wsrc = (const uint4*)d->wpack;
-        for (int i = 0; i < NTAPS * NKS * NCO; ++i)
+        for (int i = dw; i < NTAPS * NKS * NCO; i += P_NDMA)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + i * 64 + lane),
                                              (__attribute__((address_space(3))) void*)(wlds + i * 1024), 16, 0, 0);
         issue_tile(t_first, 0);
@@ -900,9 +907,9 @@ int launch_persist(const demfi_conv* h, const demfi_conv* dev, hipStream_t st)
     const int total = ((h->W + TW - 1) / TW) * ((h->H + TH - 1) / TH) * h->batch;
     const int grid = total >= 256 ? 256 : total;
     if (h->segs[h->sub_seg[0]].res.ptr != nullptr)
-        hipLaunchKernelGGL((conv3x3_c64_persist_kernel<NCO, VAR, PIPE, true>), dim3(grid), dim3(P_NT), lds, st, dev);
+        hipLaunchKernelGGL((conv3x3_c64_persist_kernel<NCO, VAR, PIPE, true>), dim3(grid), dim3(NT + 64 * P_NDMA), lds, st, dev);
     else
-        hipLaunchKernelGGL((conv3x3_c64_persist_kernel<NCO, VAR, PIPE, false>), dim3(grid), dim3(P_NT), lds, st, dev);
+        hipLaunchKernelGGL((conv3x3_c64_persist_kernel<NCO, VAR, PIPE, false>), dim3(grid), dim3(NT + 64 * P_NDMA), lds, st, dev);
     DEMFI_HIP_CHECK(hipGetLastError());
     return DEMFI_OK;
 }
@@ -931,6 +938,8 @@ template <int REC, int KS = 3> struct NarrowCfg {                // KS: filter s
     static constexpr int NBUF = REC == 128 ? 2 : (REC == 64 ? 3 : 4);
     static_assert((NBUF - 1) * NI <= 63, "tiles in flight must be countable in vmcnt");
     static_assert(KS == 3 || (KS == 7 && REC == 32), "7x7: one 16-channel k-step per tap (49 KiB of resident weights)");
+    // waves issuing the tile DMA (see the kernel): one wave needs NI x ~80 cycles to issue a tile
+    static constexpr int NDMA = REC == 128 ? 4 : (REC == 64 ? 2 : (KS == 7 ? 2 : 1));
     static __device__ __forceinline__ int swz(int col) { return REC == 128 ? (col >> 1) & 7 : (REC == 64 ? (col >> 2) & 3 : (col >> 4) & 1); }
     static constexpr size_t lds_bytes(int nco) { return (size_t)NTAPS * NKS * nco * 1024 + (size_t)NBUF * TILE_BYTES + 1024; }
 };
@@ -939,8 +948,11 @@ struct NarrowFrag { uint4 a[2], b0, b1; };
 
 // EPI: 0 = one NHWC fp16 destination, 1 = the same + residual, 2 = THIN: planar fp32 destinations / residuals routed per
 // octet (Dec_last2, Dec_last2_2, flow_occ.conv2, w_gen_2: <= 32 packed couts, NCO == 1)
-template <int NCO, int REC, int EPI, int KS = 3>
-__global__ __launch_bounds__(P_NT, 1) void conv3x3_narrow_persist_kernel(const demfi_conv* __restrict__ d)
+// NDMA: waves that issue the LDS-DMA of a tile (instruction i belongs to DMA wave i % NDMA).  One wave needs 43 x ~80 cycles
+// just to ISSUE a 128-byte-record tile; the thin-output layers (little MFMA work per tile, two tile buffers) are bound by
+// exactly that latency, so they use two.
+template <int NCO, int REC, int EPI, int KS = 3, int NDMA = NarrowCfg<REC, KS>::NDMA>
+__global__ __launch_bounds__(NT + 64 * NDMA, 1) void conv3x3_narrow_persist_kernel(const demfi_conv* __restrict__ d)
 {
     constexpr bool RES = EPI == 1, THIN = EPI == 2;
     static_assert(!THIN || NCO == 1, "thin epilogue: one 32-cout subtile");
@@ -984,8 +996,10 @@ __global__ __launch_bounds__(P_NT, 1) void conv3x3_narrow_persist_kernel(const d
         ox0 = (rem - ty * tiles_x) * TW;
     };
 
-    if (wave == 4) {
-        // ================= DMA wave ==========================================================================
+    if (wave >= 4) {
+        // ================= DMA wave(s) =======================================================================
+        const int dw = wave - 4;                                 // this wave issues instructions i with i % NDMA == dw
+        constexpr int NIW = NI / NDMA;                           // instructions per tile and wave, rounded DOWN (vmcnt waits err on the safe side)
         // the (at most two) real pieces of the chunk; everything else of the record is zero padding
         const demfi_chunk& ch = d->chunks[0];
         const char* src[2] = {nullptr, nullptr};
@@ -1027,6 +1041,7 @@ __global__ __launch_bounds__(P_NT, 1) void conv3x3_narrow_persist_kernel(const d
             const bool interior = oy0 >= PAD && oy0 + TH + PAD <= H && ox0 >= PAD && ox0 + TW + PAD <= W;
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
+                if (NDMA > 1 && (i % NDMA) != dw) continue;      // wave-uniform
                 const int sel = meta[i] >> 16;
                 const int iy = oy0 - PAD + (meta[i] & 255), ix = ox0 - PAD + ((meta[i] >> 8) & 255);
                 const bool ok = sel != 2 && (interior || (iy >= 0 && iy < H && ix >= 0 && ix < W));
@@ -1036,15 +1051,15 @@ __global__ __launch_bounds__(P_NT, 1) void conv3x3_narrow_persist_kernel(const d
             }
         };
         const uint4* wsrc = (const uint4*)d->wpack;
-        for (int i = 0; i < NSTEP * NCO; ++i)
+        for (int i = dw; i < NSTEP * NCO; i += NDMA)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + i * 64 + lane),
                                              (__attribute__((address_space(3))) void*)(wlds + i * 1024), 16, 0, 0);
         for (int k = 0; k < NBUF - 1 && k < n_tiles; ++k) issue_tile(k);
         for (int k = 0; k < n_tiles; ++k) {
             // tiles k+1 .. k+NBUF-2 (those that exist) may stay in flight; loads retire in order
             const int ahead = min(NBUF - 2, n_tiles - 1 - k);
-            if (ahead >= 2)      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NI <= 63 ? 2 * NI : 0) : "memory");
-            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI <= 63 ? NI : 0) : "memory");
+            if (ahead >= 2)      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NIW <= 63 ? 2 * NIW : 0) : "memory");
+            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NIW <= 63 ? NIW : 0) : "memory");
             else                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();                                    // hand tile k to the MFMA waves
             // ring slot of tile k+NBUF-1 = slot of tile k-1: every MFMA wave finished reading it before this barrier
@@ -1278,13 +1293,14 @@ int launch_narrow(const demfi_conv* h, const demfi_conv* dev, hipStream_t st, bo
     const int grid = total >= 256 ? 256 : total;
     if (thin) {
         if constexpr (NCO == 1)
-            hipLaunchKernelGGL((conv3x3_narrow_persist_kernel<1, REC, 2, KS>), dim3(grid), dim3(P_NT), lds, st, dev);
+            hipLaunchKernelGGL((conv3x3_narrow_persist_kernel<1, REC, 2, KS>), dim3(grid),
+                               dim3(NT + 64 * NarrowCfg<REC, KS>::NDMA), lds, st, dev);
         else
             return demfi_set_error(DEMFI_ERR_ARG, "demfi_conv2d: thin epilogue needs nco == 1");
     } else if (h->segs[h->sub_seg[0]].res.ptr != nullptr)
-        hipLaunchKernelGGL((conv3x3_narrow_persist_kernel<NCO, REC, 1, KS>), dim3(grid), dim3(P_NT), lds, st, dev);
+        hipLaunchKernelGGL((conv3x3_narrow_persist_kernel<NCO, REC, 1, KS>), dim3(grid), dim3(NT + 64 * NarrowCfg<REC, KS>::NDMA), lds, st, dev);
     else
-        hipLaunchKernelGGL((conv3x3_narrow_persist_kernel<NCO, REC, 0, KS>), dim3(grid), dim3(P_NT), lds, st, dev);
+        hipLaunchKernelGGL((conv3x3_narrow_persist_kernel<NCO, REC, 0, KS>), dim3(grid), dim3(NT + 64 * NarrowCfg<REC, KS>::NDMA), lds, st, dev);
     DEMFI_HIP_CHECK(hipGetLastError());
     return DEMFI_OK;
 }
@@ -1510,8 +1526,13 @@ __device__ __forceinline__ void sep_mfma_waves(const demfi_conv* __restrict__ d,
     }
 }
 
+#ifndef DEMFI_S_NDMA
+#define DEMFI_S_NDMA 2
+#endif
+constexpr int S_NDMA = DEMFI_S_NDMA;                            // waves issuing the unit DMA (S_NI must divide evenly: exact vmcnt counts)
+static_assert(S_NI % S_NDMA == 0, "unit DMA instructions must split evenly over the DMA waves");
 template <int VAR>
-__global__ __launch_bounds__(P_NT, 1) void conv_sep5_c128_persist_kernel(const demfi_conv* __restrict__ d)
+__global__ __launch_bounds__(NT + 64 * S_NDMA, 1) void conv_sep5_c128_persist_kernel(const demfi_conv* __restrict__ d)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -1544,8 +1565,9 @@ __global__ __launch_bounds__(P_NT, 1) void conv_sep5_c128_persist_kernel(const d
     if (a.t_first >= a.t_end) return;                           // uniform per workgroup
     a.cb = a.t_first & ((1 << a.nh_shift) - 1);
 
-    if (wave == 4) {
-        // ================= DMA wave ==========================================================================
+    if (wave >= 4) {
+        // ================= DMA waves (instruction i of a unit belongs to wave i % S_NDMA) ======================
+        const int dw = wave - 4;
         const demfi_piece& p0 = d->pieces[d->chunks[0].first_piece];
         const demfi_piece& p1 = d->pieces[d->chunks[1].first_piece];
         const char* const src0 = (const char*)p0.v.ptr;
@@ -1578,6 +1600,7 @@ __global__ __launch_bounds__(P_NT, 1) void conv_sep5_c128_persist_kernel(const d
             if (interior) {
 #pragma unroll
                 for (int i = 0; i < S_NI; ++i) {
+                    if ((i % S_NDMA) != dw) continue;            // wave-uniform
                     const char* g = base + (second ? off1[i] : off0[i]);
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                                      (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
@@ -1585,6 +1608,7 @@ __global__ __launch_bounds__(P_NT, 1) void conv_sep5_c128_persist_kernel(const d
             } else {
 #pragma unroll
                 for (int i = 0; i < S_NI; ++i) {
+                    if ((i % S_NDMA) != dw) continue;
                     const int is = os0 + (lc[i] & 255), il = ol0 - 2 + (lc[i] >> 8);
                     const char* g = (is < a.Slen && il >= 0 && il < a.Llen) ? base + (second ? off1[i] : off0[i]) : zeros;
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
@@ -1597,7 +1621,7 @@ __global__ __launch_bounds__(P_NT, 1) void conv_sep5_c128_persist_kernel(const d
         const int nco = d->nco;
         for (int c = 0; c < 2; ++c) {
             const uint4* wc = wsrc + d->chunks[c].w_off;
-            for (int g = 0; g < 20; ++g) {
+            for (int g = dw; g < 20; g += S_NDMA) {
                 for (int s = 0; s < 2; ++s)
                     __builtin_amdgcn_global_load_lds(
                         (const __attribute__((address_space(1))) void*)(wc + (g * nco + a.cb * 2 + s) * 64 + lane),
@@ -1611,8 +1635,8 @@ __global__ __launch_bounds__(P_NT, 1) void conv_sep5_c128_persist_kernel(const d
         issue_unit(2);
         for (int u = 0; u < n_units; ++u) {
             // units u+1, u+2 (if they exist) may stay in flight; loads retire in order
-            if (u + 2 < n_units)      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * S_NI) : "memory");
-            else if (u + 1 < n_units) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(S_NI) : "memory");
+            if (u + 2 < n_units)      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * S_NI / S_NDMA) : "memory");
+            else if (u + 1 < n_units) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(S_NI / S_NDMA) : "memory");
             else                      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();                                    // hand unit u to the MFMA waves
             // ring slot of unit u+3 = slot of unit u-1: every MFMA wave finished reading it before reaching this barrier
@@ -1680,7 +1704,7 @@ static int launch_sep(const demfi_conv* h, const demfi_conv* dev, hipStream_t st
     const int Llen = tr ? h->H : h->W, Slen = tr ? h->W : h->H;
     const int total = ((Llen + TW - 1) / TW) * ((Slen + TH - 1) / TH) * h->batch * (h->cout_pad / 64);
     const int grid = total >= 256 ? 256 : total;              // total < 256: one item per workgroup (stride = total, even for 2 halves)
-    hipLaunchKernelGGL(conv_sep5_c128_persist_kernel<VAR>, dim3(grid), dim3(P_NT), (size_t)S_LDS_BYTES, st, dev);
+    hipLaunchKernelGGL(conv_sep5_c128_persist_kernel<VAR>, dim3(grid), dim3(NT + 64 * S_NDMA), (size_t)S_LDS_BYTES, st, dev);
     DEMFI_HIP_CHECK(hipGetLastError());
     return DEMFI_OK;
 }
