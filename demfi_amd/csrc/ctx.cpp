@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <map>
 #include <string>
+#include <stdlib.h>
 #include <string.h>
 #include <vector>
 
@@ -52,6 +53,16 @@ int build_conv(int dtype, int H, int W, int stride, int batch, const float* w, c
     bool sep = esz == 2 && stride == 1 && ((kh == 1 && kw == 5) || (kh == 5 && kw == 1)) && n_srcs == 2 && (cout == 64 || cout == 128);
     for (int i = 0; sep && i < n_srcs; ++i) sep = srcs[i].fat && srcs[i].nch == 64 && !srcs[i].up_shift;
     while (!sep && rec > 32 && LH * LW * (rec + 16) + 2 * (rec / 32) * nco * 1024 > LDS_BUDGET) rec /= 2;
+    // Small grids (the half- and lower-resolution layers: 920 tiles at 720p): with 128-byte records only two workgroups fit a
+    // CU (LDS), so ~1000 workgroups run in two rounds; 64-byte records (five per CU) finish in one.  Not for the single
+    // 64-channel 3x3 shape, which belongs to the persistent kernel (it needs 128-byte records).
+    {
+        const int64_t n_wg = (int64_t)((W + 31) / 32) * ((H + 7) / 8) * batch * ((sub + nco - 1) / nco);
+        const bool persist_shape = n_srcs == 1 && srcs[0].fat && srcs[0].nch == 64 && kh == 3 && kw == 3 && stride == 1;
+        // measured at 720p (same box): the 48 RDB growth convs 0.045-0.072 -> 0.035-0.058 ms, dec2 0.082 -> 0.070; the 96-cout
+        // layers (nco = 3: LFF, GFF.1) get slower with it, hence nco <= 2
+        if (!sep && !persist_shape && rec == 128 && nco <= 2 && n_wg <= 5 * 256) rec = 64;
+    }
 
     // ---- every original input channel must be fed exactly once ------------------------------------------------
     {
