@@ -36,7 +36,7 @@ struct BuiltConv {
 
 int build_conv(int dtype, int H, int W, int stride, int batch, const float* w, const float* bias, int cout, int cin, int kh,
                int kw, const demfi_conv_src* srcs, int n_srcs, const demfi_conv_dst* dsts, int n_dsts, BuiltConv& out,
-               bool size_only, const char* name)
+               bool size_only, const char* name, int pad_y = -1, int pad_x = -1)
 {
     if (dtype != DEMFI_F16 && dtype != DEMFI_F32) return demfi_set_error(DEMFI_ERR_ARG, "%s: dtype", name);
     if (!srcs || !dsts || n_srcs <= 0 || n_dsts <= 0 || n_dsts > DEMFI_MAX_SEGS || (stride != 1 && stride != 2))
@@ -186,8 +186,8 @@ int build_conv(int dtype, int H, int W, int stride, int batch, const float* w, c
     d.inH = stride == 2 ? H * stride : H;
     d.inW = stride == 2 ? W * stride : W;
     d.kh = kh; d.kw = kw; d.stride = stride;
-    d.pad_y = stride == 2 ? 1 : kh / 2;
-    d.pad_x = stride == 2 ? 1 : kw / 2;
+    d.pad_y = pad_y >= 0 ? pad_y : (stride == 2 ? 1 : kh / 2);      // explicit: the 2x2 phase filters of an upsampled 3x3 layer
+    d.pad_x = pad_x >= 0 ? pad_x : (stride == 2 ? 1 : kw / 2);
     d.batch = batch; d.cout_pad = cout_pad; d.nco = nco; d.rec_bytes = rec;
     d.n_chunks = (int)chunks.size(); d.n_pieces = (int)pieces.size(); d.n_segs = n_dsts;
     const int taps = kh * kw;
@@ -538,7 +538,7 @@ struct Builder {
 
     void conv(OpList& seg, const std::string& name, const std::vector<Src>& srcs, const std::vector<Dst>& dsts, int H, int W,
               int stride = 1, int batch = 1, const std::vector<float>* wt = nullptr, const std::vector<float>* bs = nullptr,
-              const Layer* shape = nullptr)
+              const Layer* shape = nullptr, int pad_y = -1, int pad_x = -1)
     {
         if (status < 0) return;
         Layer l;
@@ -577,7 +577,7 @@ struct Builder {
         auto hit = c->pack_cache.find(sig);
         BuiltConv bc;
         status = build_conv(c->dtype, H, W, stride, batch, w, b, l.cout, l.cin, l.kh, l.kw, cs.data(), (int)cs.size(), cd.data(),
-                            (int)cd.size(), bc, dry || hit != c->pack_cache.end(), name.c_str());
+                            (int)cd.size(), bc, dry || hit != c->pack_cache.end(), name.c_str(), pad_y, pad_x);
         if (status < 0) return;
         int64_t w_off, b_off;
         if (hit != c->pack_cache.end()) { w_off = hit->second.first; b_off = hit->second.second; }
@@ -817,6 +817,52 @@ struct Builder {
         conv(th, p + "dec1", {fsrc(B["d0"], 0, 0, -1, -1, 1), fsrc(B["u2"], 256)}, {D(fview(B["d1"]), range(0, 128), R)}, H4, W4);
         conv(th, p + "dec2", {fsrc(B["d1"], 0, 0, -1, -1, 1), fsrc(B["u1"], 128)}, {D(fview(B["d2"]), range(0, 64), R)}, H2, W2);
         // + cat[flow_t0, flow_t1, occ_0_logit, aF0, aF1] (78-80), tanh on the feature part (86-87)
+        if (c->dtype == DEMFI_F16) {
+            // dec3 = conv3x3(NN-upsample x2 (d2)) (DeMFInet.py:600-602).  A 3x3 filter over a 2x nearest-neighbour upsampled image
+            // reads, for the output pixels of parity (dy, dx), only 2x2 DISTINCT low-resolution pixels: rows {y-1, y} with weights
+            // {W[0], W[1]+W[2]} for dy = 0, rows {y, y+1} with {W[0]+W[1], W[2]} for dy = 1 (columns alike).  Four 2x2 convolutions
+            // on the half-resolution grid, each writing its parity of the full-resolution outputs (views with doubled strides),
+            // do 4 taps per output instead of 9: 2.25x fewer MACs, no upsampled gather.
+            auto it = c->table.find(p + "dec3");
+            const Layer l3 = it->second;
+            auto iw = c->weights.find(p + "dec3.weight"), ib = c->weights.find(p + "dec3.bias");
+            if (!dry && (iw == c->weights.end() || ib == c->weights.end())) {
+                status = demfi_set_error(DEMFI_ERR_ARG, "demfi_ctx_bind: weight '%s' was not loaded", (p + "dec3").c_str());
+                return;
+            }
+            auto phase_view = [&](demfi_view v, int dy, int dx) {           // pixels (2y+dy, 2x+dx) of a full-resolution view
+                const int64_t elt = v.is_f32 ? 4 : 2;
+                v.ptr = (char*)v.ptr + ((int64_t)dy * v.sy + (int64_t)dx * v.sx) * elt;
+                v.sx *= 2; v.sy *= 2;
+                return v;
+            };
+            const Layer l2 = {l3.cout, l3.cin, 2, 2};
+            for (int dy = 0; dy < 2 && status >= 0; ++dy)
+                for (int dx = 0; dx < 2 && status >= 0; ++dx) {
+                    std::vector<float> w2, b2;
+                    if (!dry) {
+                        w2.assign((size_t)l3.cout * l3.cin * 4, 0.0f);
+                        for (int co = 0; co < l3.cout; ++co)
+                            for (int ci = 0; ci < l3.cin; ++ci) {
+                                const float* w9 = &iw->second.data[((size_t)co * l3.cin + ci) * 9];
+                                float* w4 = &w2[((size_t)co * l3.cin + ci) * 4];
+                                for (int ky = 0; ky < 3; ++ky)
+                                    for (int kx = 0; kx < 3; ++kx) {
+                                        const int a = dy == 0 ? (ky >= 1) : (ky >= 2), b = dx == 0 ? (kx >= 1) : (kx >= 2);
+                                        w4[a * 2 + b] += w9[ky * 3 + kx];
+                                    }
+                            }
+                        b2 = ib->second.data;
+                    }
+                    const std::string nm = p + "dec3#p" + std::to_string(dy) + std::to_string(dx);
+                    conv(th, nm, {fsrc(B["d2"], 0)},
+                         {D(phase_view(fview(B["rF"], 0, 0), dy, dx), range(5, 69), T, DEMFI_MODE_STORE, phase_view(fview(aF, 0, 0), dy, dx)),
+                          D(phase_view(fview(B["rF"], 0, 1), dy, dx), range(69, 133), T, DEMFI_MODE_STORE, phase_view(fview(aF, 0, 1), dy, dx)),
+                          D(phase_view(delta_v(0, 0), dy, dx), range(0, 4), DEMFI_ACT_NONE, DEMFI_MODE_STORE, phase_view(tview(B["ft"]), dy, dx)),
+                          D(phase_view(delta_v(0, 4), dy, dx), {4}, DEMFI_ACT_NONE, DEMFI_MODE_STORE, phase_view(tview(ffo, 4), dy, dx))},
+                         H2, W2, 1, 1, &w2, &b2, &l2, 1 - dy, 1 - dx);
+                }
+        } else
         conv(th, p + "dec3", {fsrc(B["d2"], 0, 0, -1, -1, 1)},
              {D(fview(B["rF"], 0, 0), range(5, 69), T, DEMFI_MODE_STORE, fview(aF, 0, 0)),
               D(fview(B["rF"], 0, 1), range(69, 133), T, DEMFI_MODE_STORE, fview(aF, 0, 1)),

@@ -95,7 +95,12 @@ class PlanSim:
                 assert fill == ch.nks * cpk
             X = torch.cat(xs, 0)[None]
             Wt = self.unpack_weights(d)
-            y = F.conv2d(X, Wt, None, stride=d.stride, padding=(d.pad_y, d.pad_x))[0]
+            # explicit zero padding: pad_y / pad_x on the top / left, whatever the output size needs on the bottom / right (the
+            # kernels zero-fill every out-of-range tap: 2x2 phase filters use pad 1 or 0)
+            need_h = (d.H - 1) * d.stride + d.kh - d.inH - d.pad_y
+            need_w = (d.W - 1) * d.stride + d.kw - d.inW - d.pad_x
+            Xp = F.pad(X, [d.pad_x, max(need_w, 0), d.pad_y, max(need_h, 0)])
+            y = F.conv2d(Xp, Wt, None, stride=d.stride)[0][:, :d.H, :d.W]
             assert y.shape[1:] == (d.H, d.W), (y.shape, d.H, d.W)
             bflat, boff = self._flat(d.bias, True)
             y = y + bflat[boff:boff + d.cout_pad].view(-1, 1, 1)
