@@ -400,7 +400,12 @@ void alloc_trunk(Layout& L, BufSet& s)
     L.thin(s, "gate", 2, H, W);
     L.fat(s, "aF", H, W, 64, 2);
     L.thin(s, "overlay", 3, H, W);
-    if (L.c->dtype == DEMFI_F16) L.fat(s, "u1a", H2, W2, 64);     // t-independent part of Refine_Module.enc1 (see build_trunk)
+    if (L.c->dtype == DEMFI_F16) {
+        L.fat(s, "u1a", H2, W2, 64);                // t-independent part of Refine_Module.enc1 (see build_trunk)
+        L.fat(s, "xff16", H, W, 16);                // window-constant planes of the Mixer / D2 inputs: 4 frames x 3 colours | flow_10, flow_01
+        L.fat(s, "re1w", H, W, 32);                 // their share of Mixer.conv_ref1 ...
+        L.fat(s, "g_pw", H, W, 64);                 // ... and of Dec_first_2
+    }
 }
 
 void alloc_t(Layout& L, BufSet& s)
@@ -440,14 +445,14 @@ void alloc_t(Layout& L, BufSet& s)
     L.thin(s, "stnew", 3, H, W);
     // planar flows / logits / frames packed to NHWC once, so the consuming convs stage them with vector loads
     L.fat(s, "misc16", H, W, 16);
-    L.fat(s, "ref32", H, W, 32);
-    L.fat(s, "agg3s", H, W, 32);
+    if (L.c->dtype == DEMFI_F16) { L.fat(s, "ref16", H, W, 16); L.fat(s, "agg16", H, W, 16); }     // per-t planes only (fp16 plan)
+    else { L.fat(s, "ref32", H, W, 32); L.fat(s, "agg3s", H, W, 32); }
     L.fat(s, "agg3d", H, W, 8);
     L.fat(s, "delta8", H, W, 8);
     L.fat(s, "g_a", H, W, 64);
     L.fat(s, "g_t", H, W, 64);
     L.fat(s, "g_b", H, W, 64);
-    if (L.c->dtype == DEMFI_F16) { L.fat(s, "g_p", H, W, 64); L.fat(s, "g_p2", H, W, 64); }   // partial sums of Dec_first_2
+    if (L.c->dtype == DEMFI_F16) L.fat(s, "g_p2", H, W, 64);     // partial sum of Dec_first_2 (everything but the F_rec part)
     L.thin(s, "finals", 9 * N, H, W);               // [N][3 frames][3 colours]
 }
 
@@ -754,6 +759,22 @@ struct Builder {
             SubW wa = sub_weight("Refine_Module.enc1", range(0, 128), true);
             conv(tr, "Refine_Module.enc1#aF", {fsrc(B["aF"], 0, 0, -1, 0), fsrc(B["aF"], 64, 0, -1, 1)},
                  {D(fview(B["u1a"]), range(0, 64))}, H2, W2, 2, 1, &wa.w, &wa.b, &wa.shape);
+            // Mixer.conv_ref1 (7x7 over 30 planes) and Dec_first_2 read the 4 input frames and flow_10 | flow_01: 16 planes that do
+            // not change within a window.  Packed once (xff16) and their share of both layers computed once per window; the
+            // per-t parts then fit the narrow persistent kernels (16-channel records) and take these as residuals.
+            std::vector<const float*> pl;
+            for (int f = 0; f < 4; ++f)
+                for (int col = 0; col < 3; ++col) pl.push_back(plane(B["x"], col * 4 + f));
+            for (int i : {2, 3, 0, 1}) pl.push_back(plane(B["ffo"], i));
+            pack(tr, pl, B["xff16"]);
+            SubW w1 = sub_weight("Booster_Module.Mixer.conv_ref1", range(9, 25), false);
+            conv(tr, "Booster_Module.Mixer.conv_ref1#win", {fsrc_map(B["xff16"], range(0, 16))}, {D(fview(B["re1w"]), range(0, 32))}, H, W, 1, 1,
+                 &w1.w, &w1.b, &w1.shape);
+            std::vector<int32_t> sel = range(87, 99);                    // frames, then flow_10 | flow_01 (Agg3 order, DeMFInet.py:151-155)
+            for (int i = 78; i < 82; ++i) sel.push_back(i);
+            SubW w2 = sub_weight("Dec_first_2", sel, false);
+            conv(tr, "Dec_first_2#win", {fsrc_map(B["xff16"], range(0, 16))}, {D(fview(B["g_pw"]), range(0, 64))}, H, W, 1, 1, &w2.w, &w2.b,
+                 &w2.shape);
         }
     }
 
@@ -882,20 +903,38 @@ struct Builder {
         std::vector<const float*> xpl;                              // B0, B1, B-1, B2 colour planes (cat order)
         for (int f = 0; f < 4; ++f)
             for (int col = 0; col < 3; ++col) xpl.push_back(plane(x, col * 4 + f));
-        {
+        std::vector<int32_t> agg3s_cin = range(0, 6);                // fp32 plan: channel map of the 27-plane pack
+        if (c->dtype == DEMFI_F16) {
+            // per-t planes only; the window-constant 16 planes were done in the trunk (xff16 -> re1w, g_pw)
             std::vector<const float*> pl;
             for (int i = 0; i < 9; ++i) pl.push_back(plane(B["sharp1"], i));
-            pl.insert(pl.end(), xpl.begin(), xpl.end());
-            for (int i : {2, 3, 0, 1}) pl.push_back(plane(ffo, i));
             for (int i = 0; i < 5; ++i) pl.push_back(delta_p(0, i));
-            pack(th, pl, B["ref32"]);
-            std::vector<int32_t> m = range(0, 30);
+            pack(th, pl, B["ref16"]);
+            std::vector<int32_t> sel = range(0, 9), m = range(0, 14);
+            for (int i = 25; i < 30; ++i) sel.push_back(i);
             m.insert(m.end(), 2, -1);
-            conv(th, p + "Mixer.conv_ref1", {fsrc_map(B["ref32"], m)}, {D(fview(B["re1"]), range(0, 32), R)}, H, W);
-        }
-        // iteration-invariant part of Agg3 (DeMFInet.py:151-155): S0p,S1p | occ_0 | rflow_t0,t1 | flow_10,flow_01 | frames
-        std::vector<int32_t> agg3s_cin = range(0, 6);
-        {
+            SubW w1 = sub_weight(p + "Mixer.conv_ref1", sel, true);
+            conv(th, p + "Mixer.conv_ref1#t", {fsrc_map(B["ref16"], m)}, {D(fview(B["re1"]), range(0, 32), R, DEMFI_MODE_STORE, fview(TB["re1w"]))},
+                 H, W, 1, 1, &w1.w, &w1.b, &w1.shape);
+            // iteration-invariant, t-dependent part of Agg3 (DeMFInet.py:151-155): S0p,S1p | occ_0 | rflow_t0,t1
+            std::vector<const float*> pa;
+            for (int i = 0; i < 6; ++i) pa.push_back(plane(B["sharp1"], i));
+            pa.push_back(plane(B["occ"], 0));
+            for (int i = 0; i < 4; ++i) pa.push_back(delta_p(0, i));
+            pack(th, pa, B["agg16"]);
+        } else {
+            {
+                std::vector<const float*> pl;
+                for (int i = 0; i < 9; ++i) pl.push_back(plane(B["sharp1"], i));
+                pl.insert(pl.end(), xpl.begin(), xpl.end());
+                for (int i : {2, 3, 0, 1}) pl.push_back(plane(ffo, i));
+                for (int i = 0; i < 5; ++i) pl.push_back(delta_p(0, i));
+                pack(th, pl, B["ref32"]);
+                std::vector<int32_t> m = range(0, 30);
+                m.insert(m.end(), 2, -1);
+                conv(th, p + "Mixer.conv_ref1", {fsrc_map(B["ref32"], m)}, {D(fview(B["re1"]), range(0, 32), R)}, H, W);
+            }
+            // iteration-invariant part of Agg3 (DeMFInet.py:151-155): S0p,S1p | occ_0 | rflow_t0,t1 | flow_10,flow_01 | frames
             std::vector<const float*> pl;
             for (int i = 0; i < 6; ++i) pl.push_back(plane(B["sharp1"], i));
             pl.push_back(plane(B["occ"], 0));
@@ -910,21 +949,19 @@ struct Builder {
         }
         conv(th, p + "Mixer.conv_ref2", {fsrc(B["re1"], 0)}, {D(fview(B["ref_enc"]), range(0, 32), R)}, H, W);
         // Dec_first_2 = relu(conv3x3(Agg3)) with Agg3 = cat[F_rec (64, changes per recursion) | 27 recursion-invariant planes |
-        // 8 planes of the current recursion] (DeMFInet.py:151-157).  fp16 plan: the invariant part + bias once per t (g_p), per
-        // recursion the 8-plane part on the narrow kernel (+ g_p -> g_p2) and the F_rec part on the persistent 64 -> 64 kernel
-        // (+ g_p2, ReLU) instead of one 112-channel launch of the general kernel.
-        std::vector<int32_t> a3_sel;                     // original input channels held by agg3s, in buffer order
-        for (int32_t ch : agg3s_cin) if (ch >= 0) a3_sel.push_back(ch);
+        // 8 planes of the current recursion] (DeMFInet.py:151-157), split by linearity in the fp16 plan (see below).
         const std::vector<int32_t> a3d_sel = {6, 7, 8, 82, 83, 84, 85, 86};
-        SubW w_inv, w_dyn, w_rec;
+        SubW w_dyn, w_rec;
+        std::vector<int32_t> dyn_m16 = range(0, 11);
         if (c->dtype == DEMFI_F16) {
-            w_inv = sub_weight("Dec_first_2", a3_sel, true);
-            w_dyn = sub_weight("Dec_first_2", a3d_sel, false);
+            // per recursion: ONE narrow launch over [agg16 (11 t-dependent, recursion-invariant planes) | agg3d (8 planes of this
+            // recursion)] + bias + the window-constant share (g_pw, trunk) -> g_p2; then the F_rec part on the 64 -> 64 kernel
+            std::vector<int32_t> sel = range(0, 6);                  // S0p, S1p | occ_0 | rflow_t0, rflow_t1 (agg16 order)
+            for (int i = 73; i < 78; ++i) sel.push_back(i);
+            sel.insert(sel.end(), a3d_sel.begin(), a3d_sel.end());
+            w_dyn = sub_weight("Dec_first_2", sel, true);
             w_rec = sub_weight("Dec_first_2", range(9, 73), false);
-            std::vector<int32_t> m = range(0, (int)a3_sel.size());
-            m.insert(m.end(), 32 - (int)a3_sel.size(), -1);
-            conv(th, "Dec_first_2#inv", {fsrc_map(B["agg3s"], m)}, {D(fview(B["g_p"]), range(0, 64))}, H, W, 1, 1, &w_inv.w, &w_inv.b,
-                 &w_inv.shape);
+            dyn_m16.insert(dyn_m16.end(), 5, -1);
         }
         // ============================ recursive boosting, one list per iteration ====================================
         // SepConvGRU (838-857): z | r share their input -> one 128-cout conv
@@ -982,13 +1019,13 @@ struct Builder {
                 pack(sg, pl, B["agg3d"]);
             }
             if (c->dtype == DEMFI_F16) {
-                conv(sg, "Dec_first_2#dyn", {fsrc_map(B["agg3d"], range(0, 8))},
-                     {D(fview(B["g_p2"]), range(0, 64), DEMFI_ACT_NONE, DEMFI_MODE_STORE, fview(B["g_p"]))}, H, W, 1, 1, &w_dyn.w, &w_dyn.b,
+                conv(sg, "Dec_first_2#dyn", {fsrc_map(B["agg16"], dyn_m16), fsrc_map(B["agg3d"], range(11, 19))},
+                     {D(fview(B["g_p2"]), range(0, 64), DEMFI_ACT_NONE, DEMFI_MODE_STORE, fview(TB["g_pw"]))}, H, W, 1, 1, &w_dyn.w, &w_dyn.b,
                      &w_dyn.shape);
                 conv(sg, "Dec_first_2#rec", {fsrc(hout, 0)}, {D(fview(B["g_a"]), range(0, 64), R, DEMFI_MODE_STORE, fview(B["g_p2"]))}, H, W,
                      1, 1, &w_rec.w, &w_rec.b, &w_rec.shape);
             } else
-            conv(sg, "Dec_first_2", {fsrc(hout, 9), fsrc_map(B["agg3s"], agg3s_cin), fsrc_map(B["agg3d"], {6, 7, 8, 82, 83, 84, 85, 86})},
+            conv(sg, "Dec_first_2", {fsrc(hout, 9), fsrc_map(B["agg3s"], agg3s_cin), fsrc_map(B["agg3d"], a3d_sel)},
                  {D(fview(B["g_a"]), range(0, 64), R)}, H, W);
             const Tensor* g = resblocks(sg, "Decoder_res_2", c->hp.num_resb_dec, B["g_a"], B["g_t"], B["g_b"], H, W, 1);
             conv(sg, "Dec_last1_2", {fsrc(*g, 0)}, {D(fview(B["g_t"]), range(0, 64), R)}, H, W);

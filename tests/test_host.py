@@ -168,7 +168,8 @@ def test_fp16_plan_with_hoisted_partial_convs(synthetic_sd):
     eng = Engine(synthetic_sd, H, W, torch.float16, 'cpu', max_updates=N)
     names = [op.name.decode() for op in eng.ops(0)] + [op.name.decode() for op in eng.ops(1)] + [op.name.decode() for op in eng.ops(2, 0)]
     assert 'Refine_Module.enc1#aF' in names and 'Refine_Module.enc1#t' in names and 'Refine_Module.enc1' not in names
-    assert {'Dec_first_2#inv', 'Dec_first_2#dyn', 'Dec_first_2#rec'} <= set(names) and 'Dec_first_2' not in names
+    assert {'Dec_first_2#win', 'Dec_first_2#dyn', 'Dec_first_2#rec', 'Booster_Module.Mixer.conv_ref1#win'} <= set(names)
+    assert 'Dec_first_2' not in names and 'Booster_Module.Mixer.conv_ref1' not in names
     x = synthetic_window(H, W, 4)
     PlanSim(eng).forward(x, 0.375, N)
     with torch.no_grad():
