@@ -88,6 +88,8 @@ _SIGS = {
                                        C.c_void_p, C.c_void_p]),
     'demfi_warp_blend': (C.c_int, [C.POINTER(View), C.c_void_p, C.POINTER(View), C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.POINTER(View), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'demfi_warp_blend_pack': (C.c_int, [C.POINTER(View), C.c_void_p, C.POINTER(View), C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.POINTER(View), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     'demfi_fgac_gather': (C.c_int, [C.POINTER(View), C.c_void_p, C.POINTER(View), C.c_int, C.c_int, C.c_int,
                                     C.c_void_p, C.c_void_p]),
     'demfi_fgac_window': (C.c_int, [C.POINTER(View), C.POINTER(View), C.c_void_p, C.POINTER(View), C.c_int, C.c_int, C.c_int,

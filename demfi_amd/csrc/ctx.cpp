@@ -779,11 +779,11 @@ struct Builder {
     }
 
     void warp(OpList& seg, const char* name, int C, demfi_view A, demfi_view Bv, demfi_view O, const void* fa, const void* fb,
-              const void* logit, const void* occ_out, const void* t)
+              const void* logit, const void* occ_out, const void* t, const void* pack8 = nullptr)
     {
         demfi_op o = blank();
         o.nch = C; o.a = A; o.b = Bv; o.o = O;
-        o.p[0] = fa; o.p[1] = fb; o.p[2] = logit; o.p[3] = occ_out; o.t = t;
+        o.p[0] = fa; o.p[1] = fb; o.p[2] = logit; o.p[3] = occ_out; o.p[4] = pack8; o.t = t;
         simple(seg, DEMFI_OP_WARP, name, o);
     }
 
@@ -1008,16 +1008,10 @@ struct Builder {
             conv(sg, p + "flow_occ.conv1", {fsrc(hout, 0)}, {D(fview(B["fo1"]), range(0, 32), R)}, H, W);
             conv(sg, p + "flow_occ.conv2", {fsrc(B["fo1"], 0)},
                  {D(delta_v(it + 1, 0), range(0, 5), DEMFI_ACT_NONE, DEMFI_MODE_STORE, delta_v(it, 0))}, H, W);
+            // PWB of the recursion; the kernel also writes Agg3's per-recursion planes [St_new | rflow_t0, rflow_t1 | occ]
+            // (DeMFInet.py:151-155) as the NHWC record Dec_first_2 reads (agg3d): no plane-packing launch
             warp(sg, "warp_thin", 3, tview(B["sharp1"], 0), tview(B["sharp1"], 3), tview(B["stnew"]), delta_p(it + 1, 0), delta_p(it + 1, 2),
-                 delta_p(it + 1, 4), plane(B["occ"], it + 1), tp);
-            // Agg3 (DeMFInet.py:151-155)
-            {
-                std::vector<const float*> pl;
-                for (int i = 0; i < 3; ++i) pl.push_back(plane(B["stnew"], i));
-                for (int i = 0; i < 4; ++i) pl.push_back(delta_p(it + 1, i));
-                pl.push_back(plane(B["occ"], it + 1));
-                pack(sg, pl, B["agg3d"]);
-            }
+                 delta_p(it + 1, 4), plane(B["occ"], it + 1), tp, ptr(B["agg3d"]));
             if (c->dtype == DEMFI_F16) {
                 conv(sg, "Dec_first_2#dyn", {fsrc_map(B["agg16"], dyn_m16), fsrc_map(B["agg3d"], range(11, 19))},
                      {D(fview(B["g_p2"]), range(0, 64), DEMFI_ACT_NONE, DEMFI_MODE_STORE, fview(TB["g_pw"]))}, H, W, 1, 1, &w_dyn.w, &w_dyn.b,
@@ -1327,6 +1321,9 @@ extern "C" int demfi_run_op(demfi_ctx* c, const demfi_op* op, void* stream)
         return demfi_cfr_flow_align((const float*)op->p[0], (const float*)op->p[1], (const float*)op->t, H, W, (int64_t*)op->p[2],
                                     (float*)op->p[3], nullptr, stream);
     case DEMFI_OP_WARP:
+        if (op->p[4])
+            return demfi_warp_blend_pack(&op->a, (const float*)op->p[0], &op->b, (const float*)op->p[1], (const float*)op->p[2],
+                                         (const float*)op->t, &op->o, H, W, (float*)op->p[3], (void*)op->p[4], c->dtype, stream);
         return demfi_warp_blend(&op->a, (const float*)op->p[0], &op->b, (const float*)op->p[1], (const float*)op->p[2],
                                 (const float*)op->t, &op->o, op->nch, H, W, (float*)op->p[3], nullptr, stream);
     }

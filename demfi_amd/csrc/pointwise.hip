@@ -487,10 +487,13 @@ __global__ __launch_bounds__(ROWS * 64) void warp_blend_fat_kernel(demfi_view A,
 }
 
 // Thin (any strides) warp+blend, one thread per pixel, loops over C channels (C = 3 frames).
+// pack8 (optional, C == 3 only): the 8 planes the next layer reads -- [out 0..2 | fa x,y | fb x,y | sigmoid(logit)] -- written
+// as ONE NHWC record of the path dtype per pixel (Agg3's per-recursion part, DeMFInet.py:151-155: St_new, rflow_t0, rflow_t1,
+// occ), so that no separate plane-packing launch is needed.
 __global__ void warp_blend_thin_kernel(demfi_view A, const float* __restrict__ fa, demfi_view B,
                                        const float* __restrict__ fb, const float* __restrict__ logit,
                                        const float* __restrict__ tptr, demfi_view O, int C, int H, int W,
-                                       float* __restrict__ occ_out, int* __restrict__ dbg)
+                                       float* __restrict__ occ_out, int* __restrict__ dbg, void* __restrict__ pack8, int pack_f32)
 {
     const int64_t hw = (int64_t)H * W;
     const int64_t pix = (int64_t)blockIdx.x * NT + threadIdx.x;
@@ -506,6 +509,7 @@ __global__ void warp_blend_thin_kernel(demfi_view A, const float* __restrict__ f
     if (dbg) { dbg_store(dbg, 0, hw, pix, ma, va); dbg_store(dbg, 1, hw, pix, mb, vb); }
     const float ka = (1.0f - t) * o0, kb = t * o1;
     const float den = ka + kb;
+    float rec[8] = {0.0f, 0.0f, 0.0f, fa[pix], fa[hw + pix], fb[pix], fb[hw + pix], o0};
     for (int c = 0; c < C; ++c) {
         float a = 0.0f, b = 0.0f;
 #pragma unroll
@@ -517,7 +521,21 @@ __global__ void warp_blend_thin_kernel(demfi_view A, const float* __restrict__ f
         }
         a = va ? a : 0.0f;
         b = vb ? b : 0.0f;
-        view_store(O, (int64_t)c * O.sc + (int64_t)y * O.sy + (int64_t)x * O.sx, (ka * a + kb * b) / den);
+        const float v = (ka * a + kb * b) / den;
+        view_store(O, (int64_t)c * O.sc + (int64_t)y * O.sy + (int64_t)x * O.sx, v);
+        if (c < 3) rec[c] = v;
+    }
+    if (pack8) {
+        if (pack_f32) {
+            float* q = (float*)pack8 + pix * 8;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) q[j] = rec[j];
+        } else {
+            h8_t o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (half_t)rec[j];
+            st_global16((char*)pack8 + pix * 16, __builtin_bit_cast(uint4, o));
+        }
     }
 }
 
@@ -754,9 +772,9 @@ extern "C" int demfi_cfr_flow_align(const float* flow01, const float* flow10, co
     return DEMFI_OK;
 }
 
-extern "C" int demfi_warp_blend(const demfi_view* A, const float* fa, const demfi_view* B, const float* fb,
-                                const float* logit, const float* t, const demfi_view* out, int C, int H, int W,
-                                float* occ_out, int32_t* dbg_maps, void* stream)
+static int warp_blend_impl(const demfi_view* A, const float* fa, const demfi_view* B, const float* fb, const float* logit,
+                           const float* t, const demfi_view* out, int C, int H, int W, float* occ_out, int32_t* dbg_maps,
+                           void* pack8, int pack_dtype, void* stream)
 {
     if (!A || !B || !out || !A->ptr || !B->ptr || !out->ptr || !fa || !fb || !logit || !t || C <= 0 || H <= 0 || W <= 0)
         return demfi_set_error(DEMFI_ERR_ARG, "demfi_warp_blend: bad args");
@@ -764,6 +782,7 @@ extern "C" int demfi_warp_blend(const demfi_view* A, const float* fa, const demf
     const int64_t hw = (int64_t)H * W;
     const bool fat = A->sc == 1 && B->sc == 1 && out->sc == 1 && A->is_f32 == B->is_f32 && A->is_f32 == out->is_f32
                      && (C * (A->is_f32 ? 4 : 2)) % 16 == 0;
+    if (fat && pack8) return demfi_set_error(DEMFI_ERR_ARG, "demfi_warp_blend_pack: planar views expected");
     if (fat) {
         int f32 = 0;
         const int sh = fat_lpp_shift(A, C, "demfi_warp_blend", &f32);
@@ -789,11 +808,28 @@ extern "C" int demfi_warp_blend(const demfi_view* A, const float* fa, const demf
         }
 #undef DEMFI_WARP_LAUNCH
     } else {
+        if (pack8 && C != 3) return demfi_set_error(DEMFI_ERR_ARG, "demfi_warp_blend_pack: the packed record is defined for C == 3");
         hipLaunchKernelGGL(warp_blend_thin_kernel, dim3(blocks_for(hw)), dim3(NT), 0, st, *A, fa, *B, fb, logit, t, *out, C,
-                           H, W, occ_out, dbg_maps);
+                           H, W, occ_out, dbg_maps, pack8, pack_dtype == DEMFI_F32 ? 1 : 0);
     }
     DEMFI_HIP_CHECK(hipGetLastError());
     return DEMFI_OK;
+}
+
+extern "C" int demfi_warp_blend(const demfi_view* A, const float* fa, const demfi_view* B, const float* fb,
+                                const float* logit, const float* t, const demfi_view* out, int C, int H, int W,
+                                float* occ_out, int32_t* dbg_maps, void* stream)
+{
+    return warp_blend_impl(A, fa, B, fb, logit, t, out, C, H, W, occ_out, dbg_maps, nullptr, 0, stream);
+}
+
+extern "C" int demfi_warp_blend_pack(const demfi_view* A, const float* fa, const demfi_view* B, const float* fb,
+                                     const float* logit, const float* t, const demfi_view* out, int H, int W, float* occ_out,
+                                     void* pack8, int pack_dtype, void* stream)
+{
+    if (!pack8 || (pack_dtype != DEMFI_F16 && pack_dtype != DEMFI_F32) || !A || A->sc == 1)
+        return demfi_set_error(DEMFI_ERR_ARG, "demfi_warp_blend_pack: planar 3-channel views and a pack buffer expected");
+    return warp_blend_impl(A, fa, B, fb, logit, t, out, 3, H, W, occ_out, nullptr, pack8, pack_dtype, stream);
 }
 
 extern "C" int demfi_fgac_gather(const demfi_view* src, const float* flow, const demfi_view* out, int C, int H, int W,

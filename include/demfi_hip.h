@@ -214,6 +214,13 @@ int demfi_warp_blend(const demfi_view* A, const float* fa, const demfi_view* B, 
                      const float* logit, const float* t, const demfi_view* out, int C, int H, int W,
                      float* occ_out, int32_t* dbg_maps, void* stream);
 
+/* The same for 3-channel planar frames (the PWB of the recursion, DeMFInet.py:140-149) with the packed copy the next layer
+ * reads: pack8 = NHWC [H,W,8] of pack_dtype holding [out 0..2 | fa | fb | sigmoid(logit)] (Agg3's per-recursion planes,
+ * DeMFInet.py:151-155) -- replaces a demfi_pack_planes launch. */
+int demfi_warp_blend_pack(const demfi_view* A, const float* fa, const demfi_view* B, const float* fb,
+                          const float* logit, const float* t, const demfi_view* out, int H, int W, float* occ_out,
+                          void* pack8, int pack_dtype, void* stream);
+
 /* bilinear_sampler at ABSOLUTE flow coordinates (FGAC, DeMFInet.py:413-419, 499-514; rr = sr = 0):
  * src, out fat views with C channels; flow planar fp32 [2,H,W]. */
 int demfi_fgac_gather(const demfi_view* src, const float* flow, const demfi_view* out, int C, int H,
@@ -340,7 +347,7 @@ typedef struct demfi_op {
     int32_t _pad;           /* FGAC_WINDOW: index map (0 reference code, 1 pixel-centred)                */
     int64_t macs;           /* CONV: algorithmic multiply-accumulates of the launch                      */
     demfi_view a, b, o;     /* WARP: A, B, out; FGAC: src, -, out; GATE: source, e, out; PACK: o = dst     */
-    const void* p[32];      /* PACK: plane pointers; WARP: fa, fb, logit, occ_out; FGAC: flow; GATE: w;
+    const void* p[32];      /* PACK: plane pointers; WARP: fa, fb, logit, occ_out, pack8 (or NULL); FGAC: flow; GATE: w;
                                CFR: flow01, flow10, acc, out; S2D / OVERLAY: x, out; all: t where needed  */
     const void* t;          /* device fp32 time instant (CFR, WARP)                                      */
     char name[64];

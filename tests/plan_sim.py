@@ -200,6 +200,9 @@ class PlanSim:
                 out.copy_(r[0].to(out.dtype))
                 if op.p[3] is not None:
                     self.planes(op.p[3], 1, H, W).copy_(torch.sigmoid(lg))
+                if op.p[4] is not None:                                    # packed NHWC record [out | fa | fb | occ] for the next conv
+                    pk = self.strided(L.View(op.p[4], 8, W * 8, 1, 0, 1 if f32 else 0, 0), 8, H, W)
+                    pk.copy_(torch.cat([r[0], self.planes(op.p[0], 2, H, W), self.planes(op.p[1], 2, H, W), torch.sigmoid(lg)], 0).to(pk.dtype))
             else:
                 raise AssertionError(k)
 

@@ -512,3 +512,33 @@ def test_s2d_reflect_overlay(golden_dir):
     assert torch.equal(ov.cpu(), torch.mean(x[:, 0:2], dim=1).cpu())
     assert torch.equal(xp.cpu(), torch.nn.functional.pad(xs.cpu()[None], [0, 26, 0, 14], mode='reflect')[0])
     assert lib.demfi_reflect_pad(xs.data_ptr(), xp.data_ptr(), 12, 50, 70, 128, 96, _stream()) == -1   # pad >= size
+
+
+@pytest.mark.parametrize('dtype,dt', [(torch.float16, L.F16), (torch.float32, L.F32)])
+def test_warp_blend_pack_writes_the_next_layers_record(dtype, dt):
+    """demfi_warp_blend_pack = demfi_warp_blend on 3-channel planar frames + the NHWC record [out | fa | fb | sigmoid(logit)]
+    the next convolution reads (replaces a demfi_pack_planes launch): outputs identical to the plain call, record == planes."""
+    torch.manual_seed(2)
+    H, W = 37, 75
+    lib = L.load()
+    A = torch.rand(3, H, W, device=DEV) * 2 - 1
+    B = torch.rand(3, H, W, device=DEV) * 2 - 1
+    fl = (torch.randn(4, H, W, device=DEV) * 5).contiguous()
+    logit = torch.randn(H, W, device=DEV)
+    t = torch.tensor([0.625], device=DEV)
+    o1, o2 = torch.zeros(3, H, W, device=DEV), torch.zeros(3, H, W, device=DEV)
+    occ1, occ2 = torch.zeros(H, W, device=DEV), torch.zeros(H, W, device=DEV)
+    pk = torch.zeros(H, W, 8, device=DEV, dtype=dtype)
+    va, vb, v1, v2 = _view_planar(A), _view_planar(B), _view_planar(o1), _view_planar(o2)
+    L.check(lib.demfi_warp_blend(C.byref(va), fl.data_ptr(), C.byref(vb), fl[2:].data_ptr(), logit.data_ptr(), t.data_ptr(),
+                                 C.byref(v1), 3, H, W, occ1.data_ptr(), None, _stream()))
+    L.check(lib.demfi_warp_blend_pack(C.byref(va), fl.data_ptr(), C.byref(vb), fl[2:].data_ptr(), logit.data_ptr(), t.data_ptr(),
+                                      C.byref(v2), H, W, occ2.data_ptr(), pk.data_ptr(), dt, _stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(o1, o2) and torch.equal(occ1, occ2)
+    exp = torch.cat([o1, fl, occ1[None]], 0).permute(1, 2, 0).to(dtype)
+    assert torch.equal(pk, exp)
+    fat = torch.zeros(H, W, 64, device=DEV, dtype=torch.float16)
+    vf = _view_nhwc(fat)
+    assert lib.demfi_warp_blend_pack(C.byref(vf), fl.data_ptr(), C.byref(vf), fl[2:].data_ptr(), logit.data_ptr(), t.data_ptr(),
+                                     C.byref(vf), H, W, None, pk.data_ptr(), dt, _stream()) == -1
