@@ -935,11 +935,16 @@ template <int REC, int KS = 3> struct NarrowCfg {                // KS: filter s
     static constexpr int PPI = 1024 / REC;                      // records per DMA instruction
     static constexpr int NI = (NP + PPI - 1) / PPI;             // DMA instructions per tile: 43 / 22 / 11 (3x3), 17 (7x7, REC 32)
     static constexpr int TILE_BYTES = NI * 1024;
-    static constexpr int NBUF = REC == 128 ? 2 : (REC == 64 ? 3 : 4);
-    static_assert((NBUF - 1) * NI <= 63, "tiles in flight must be countable in vmcnt");
+#ifndef DEMFI_N64_NBUF                                           // A/B switches of the narrow kernel's ring depth / DMA waves (same-box bench:
+#define DEMFI_N64_NBUF 3                                        // 4 DMA waves for 64-byte records and 2 for 32-byte ones +0.5 %; a 4th buffer nothing)
+#define DEMFI_N64_NDMA 4
+#define DEMFI_N32_NDMA 2
+#endif
+    static constexpr int NBUF = REC == 128 ? 2 : (REC == 64 ? DEMFI_N64_NBUF : 4);
     static_assert(KS == 3 || (KS == 7 && REC == 32), "7x7: one 16-channel k-step per tap (49 KiB of resident weights)");
     // waves issuing the tile DMA (see the kernel): one wave needs NI x ~80 cycles to issue a tile
-    static constexpr int NDMA = REC == 128 ? 4 : (REC == 64 ? 2 : (KS == 7 ? 2 : 1));
+    static constexpr int NDMA = REC == 128 ? 4 : (REC == 64 ? DEMFI_N64_NDMA : (KS == 7 ? 2 : DEMFI_N32_NDMA));
+    static_assert((NBUF - 1) * ((NI + NDMA - 1) / NDMA) <= 63, "a DMA wave's tiles in flight must be countable in vmcnt");
     static __device__ __forceinline__ int swz(int col) { return REC == 128 ? (col >> 1) & 7 : (REC == 64 ? (col >> 2) & 3 : (col >> 4) & 1); }
     static constexpr size_t lds_bytes(int nco) { return (size_t)NTAPS * NKS * nco * 1024 + (size_t)NBUF * TILE_BYTES + 1024; }
 };
