@@ -84,6 +84,7 @@ _SIGS = {
     'demfi_reflect_pad': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'demfi_overlay_mean': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     'demfi_cfr_workspace_bytes': (C.c_int64, [C.c_int, C.c_int]),
+    'demfi_cfr_reset': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     'demfi_cfr_flow_align': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p]),
     'demfi_warp_blend': (C.c_int, [C.POINTER(View), C.c_void_p, C.POINTER(View), C.c_void_p, C.c_void_p, C.c_void_p,

@@ -3,6 +3,9 @@
 #include <stdarg.h>
 #include <string.h>
 #include <vector>
+#include <mutex>
+#include <set>
+#include <utility>
 
 static thread_local char g_err[512] = "";
 
@@ -124,3 +127,18 @@ extern "C" int demfi_graph_destroy(void* graph_exec)
     if (graph_exec) DEMFI_HIP_CHECK(hipGraphExecDestroy((hipGraphExec_t)graph_exec));
     return DEMFI_OK;
 }
+
+// ---- per-(function, device) dynamic-LDS attribute ----------------------------------------------------
+int demfi_ensure_lds_attr(const void* fn, int bytes)
+{
+    static std::mutex mu;
+    static std::set<std::pair<const void*, int>> done;
+    int dev = 0;
+    DEMFI_HIP_CHECK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    if (done.count({fn, dev})) return DEMFI_OK;
+    DEMFI_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    done.insert({fn, dev});
+    return DEMFI_OK;
+}
+

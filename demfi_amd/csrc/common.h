@@ -102,3 +102,13 @@ __device__ __forceinline__ SampleMap make_sample_map(float ix, float iy, int H, 
     m.w[3] = (m.inb & 8) ? se : 0.0f;
     return m;
 }
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is per (function, device): remember which pairs were set -- thread-safe and
+// correct when one process drives several GPUs (a function-local `static bool` is neither).
+int demfi_ensure_lds_attr(const void* fn, int bytes);
+#define DEMFI_LDS_ATTR(fn)                                                                    \
+    do {                                                                                      \
+        const int st__ = demfi_ensure_lds_attr((const void*)(fn), 160 * 1024);                \
+        if (st__ < 0) return st__;                                                            \
+    } while (0)
+

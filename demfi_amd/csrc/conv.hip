@@ -896,14 +896,8 @@ template <int NCO, int VAR = 0, bool PIPE = false>
 int launch_persist(const demfi_conv* h, const demfi_conv* dev, hipStream_t st)
 {
     const size_t lds = 9 * 4 * NCO * 1024 + 2 * P_TILE_BYTES + 1024;      // weights + 2 tiles + bias
-    static bool attr_done = false;
-    if (!attr_done) {
-        DEMFI_HIP_CHECK(hipFuncSetAttribute((const void*)conv3x3_c64_persist_kernel<NCO, VAR, PIPE, true>,
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        DEMFI_HIP_CHECK(hipFuncSetAttribute((const void*)conv3x3_c64_persist_kernel<NCO, VAR, PIPE, false>,
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_done = true;
-    }
+    DEMFI_LDS_ATTR((conv3x3_c64_persist_kernel<NCO, VAR, PIPE, true>));
+    DEMFI_LDS_ATTR((conv3x3_c64_persist_kernel<NCO, VAR, PIPE, false>));
     const int total = ((h->W + TW - 1) / TW) * ((h->H + TH - 1) / TH) * h->batch;
     const int grid = total >= 256 ? 256 : total;
     if (h->segs[h->sub_seg[0]].res.ptr != nullptr)
@@ -1283,16 +1277,10 @@ template <int NCO, int REC, int KS = 3>
 int launch_narrow(const demfi_conv* h, const demfi_conv* dev, hipStream_t st, bool thin)
 {
     const size_t lds = NarrowCfg<REC, KS>::lds_bytes(NCO);
-    static bool attr_done = false;
-    if (!attr_done) {
-        DEMFI_HIP_CHECK(hipFuncSetAttribute((const void*)conv3x3_narrow_persist_kernel<NCO, REC, 1, KS>,
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        DEMFI_HIP_CHECK(hipFuncSetAttribute((const void*)conv3x3_narrow_persist_kernel<NCO, REC, 0, KS>,
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        if constexpr (NCO == 1)
-            DEMFI_HIP_CHECK(hipFuncSetAttribute((const void*)conv3x3_narrow_persist_kernel<1, REC, 2, KS>,
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_done = true;
+    DEMFI_LDS_ATTR((conv3x3_narrow_persist_kernel<NCO, REC, 1, KS>));
+    DEMFI_LDS_ATTR((conv3x3_narrow_persist_kernel<NCO, REC, 0, KS>));
+    if constexpr (NCO == 1) {
+        DEMFI_LDS_ATTR((conv3x3_narrow_persist_kernel<1, REC, 2, KS>));
     }
     const int total = ((h->W + TW - 1) / TW) * ((h->H + TH - 1) / TH) * h->batch;
     const int grid = total >= 256 ? 256 : total;
@@ -1699,12 +1687,7 @@ static bool sep_eligible(const demfi_conv* h)
 template <int VAR = 0>
 static int launch_sep(const demfi_conv* h, const demfi_conv* dev, hipStream_t st)
 {
-    static bool attr_done = false;
-    if (!attr_done) {
-        DEMFI_HIP_CHECK(hipFuncSetAttribute((const void*)conv_sep5_c128_persist_kernel<VAR>,
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_done = true;
-    }
+    DEMFI_LDS_ATTR((conv_sep5_c128_persist_kernel<VAR>));
     const bool tr = h->kh == 5;
     const int Llen = tr ? h->H : h->W, Slen = tr ? h->W : h->H;
     const int total = ((Llen + TW - 1) / TW) * ((Slen + TH - 1) / TH) * h->batch * (h->cout_pad / 64);
@@ -1787,12 +1770,7 @@ static bool persist_out_eligible(const demfi_conv* h)
 template <typename T, int NCO>
 int launch(const demfi_conv* h, const demfi_conv* dev, hipStream_t st, size_t lds)
 {
-    static bool attr_done = false;
-    if (!attr_done) {
-        DEMFI_HIP_CHECK(hipFuncSetAttribute((const void*)conv_kernel<T, NCO>,
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_done = true;
-    }
+    DEMFI_LDS_ATTR((conv_kernel<T, NCO>));
     const int tiles = ((h->W + TW - 1) / TW) * ((h->H + TH - 1) / TH);
     dim3 grid(tiles, h->cout_pad / (32 * h->nco), h->batch);
     hipLaunchKernelGGL((conv_kernel<T, NCO>), grid, dim3(NT), lds, st, dev);

@@ -228,12 +228,8 @@ extern "C" int demfi_fgac_window(const demfi_view* ref_k, const demfi_view* sour
     hipStream_t st = (hipStream_t)stream;
     const int R = 2 * rr + 1;
     const size_t lds = mode == 1 ? (size_t)32 * (R + 1) * (R + 1) * 128 : 0;
-    static bool attr_done = false;
-    if (!attr_done) {
-        DEMFI_HIP_CHECK(hipFuncSetAttribute((const void*)fgac_window_kernel<3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        DEMFI_HIP_CHECK(hipFuncSetAttribute((const void*)fgac_window_kernel<5, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_done = true;
-    }
+    DEMFI_LDS_ATTR((fgac_window_kernel<3, 1>));
+    DEMFI_LDS_ATTR((fgac_window_kernel<5, 1>));
     if (rr == 1 && mode == 0) hipLaunchKernelGGL((fgac_window_kernel<3, 0>), grid, blk, lds, st, *ref_k, *source_k, flow, *out, H, W, attn_out);
     else if (rr == 1) hipLaunchKernelGGL((fgac_window_kernel<3, 1>), grid, blk, lds, st, *ref_k, *source_k, flow, *out, H, W, attn_out);
     else if (mode == 0) hipLaunchKernelGGL((fgac_window_kernel<5, 0>), grid, blk, lds, st, *ref_k, *source_k, flow, *out, H, W, attn_out);

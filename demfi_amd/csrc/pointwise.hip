@@ -755,6 +755,15 @@ extern "C" int64_t demfi_cfr_workspace_bytes(int H, int W)
     return 6 * (int64_t)H * W * 8 + ((tiles * 4 + 255) & ~255ll);
 }
 
+// The accumulators are self-cleaning, which holds only for launches that run to completion: after an aborted launch (a
+// failed hipGraph replay, a device reset survived by the allocation) the caller re-zeroes them here.
+extern "C" int demfi_cfr_reset(int64_t* acc, int H, int W, void* stream)
+{
+    if (!acc || H <= 0 || W <= 0) return demfi_set_error(DEMFI_ERR_ARG, "demfi_cfr_reset: bad args");
+    DEMFI_HIP_CHECK(hipMemsetAsync(acc, 0, (size_t)demfi_cfr_workspace_bytes(H, W), (hipStream_t)stream));
+    return DEMFI_OK;
+}
+
 extern "C" int demfi_cfr_flow_align(const float* flow01, const float* flow10, const float* t, int H, int W,
                                     int64_t* acc, float* out, int32_t* dbg_idx, void* stream)
 {

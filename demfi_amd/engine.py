@@ -291,6 +291,14 @@ class Engine:
         self.__dict__.update(self._ctxs[self.trunk][c])
         self.ctx = c
 
+    def reset_cfr(self, stream=None):
+        """Re-zero the splat accumulators of every per-t context (they clean themselves after every completed launch; call
+        this after an aborted one: a failed graph replay leaves garbage that every later call would add)."""
+        st = stream if stream is not None else torch.cuda.current_stream(self.device).cuda_stream
+        for row in self._ctxs:
+            for ctx in row:
+                L.check(self.lib.demfi_cfr_reset(ctx['cfr_acc'].data_ptr(), self.H, self.W, st), 'cfr_reset')
+
     def regions(self):
         return [self.workspace]
 

@@ -200,6 +200,7 @@ int demfi_overlay_mean(const float* x, float* out, int H, int W, void* stream);
  * [2 flows][4 corners][H*W] flat target index of every source pixel, -1 where masked off
  * (sample_one's ids / mask, DeMFInet.py:712-719) for the index-parity tests. */
 int64_t demfi_cfr_workspace_bytes(int H, int W);
+int demfi_cfr_reset(int64_t* acc, int H, int W, void* stream);      /* re-zero the workspace after an aborted launch */
 int demfi_cfr_flow_align(const float* flow01, const float* flow10, const float* t, int H, int W,
                          int64_t* acc, float* out, int32_t* dbg_idx, void* stream);
 

@@ -460,6 +460,13 @@ def test_cfr_is_deterministic():
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
     a, b = O.cfr_flow_align(f01.cpu()[None], f10.cpu()[None], t.cpu().view(1, 1, 1, 1))
     assert (outs[0] - torch.cat([a[0], b[0]], 0)).abs().max() < 1e-3
+    # a workspace left dirty by an aborted launch poisons later calls; demfi_cfr_reset repairs it
+    acc = torch.full((lib.demfi_cfr_workspace_bytes(H, W) // 8,), 12345, dtype=torch.int64, device=DEV)
+    L.check(lib.demfi_cfr_reset(acc.data_ptr(), H, W, _stream()))
+    out = torch.zeros(4, H, W, device=DEV)
+    L.check(lib.demfi_cfr_flow_align(f01.data_ptr(), f10.data_ptr(), t.data_ptr(), H, W, acc.data_ptr(), out.data_ptr(), None, _stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(out.cpu(), outs[0]) and int(acc.abs().max()) == 0
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.float16])
