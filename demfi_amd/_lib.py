@@ -40,7 +40,7 @@ class Conv(C.Structure):
                 ('kh', C.c_int32), ('kw', C.c_int32), ('stride', C.c_int32), ('pad_y', C.c_int32),
                 ('pad_x', C.c_int32), ('batch', C.c_int32), ('cout_pad', C.c_int32), ('nco', C.c_int32),
                 ('rec_bytes', C.c_int32), ('n_chunks', C.c_int32), ('n_pieces', C.c_int32), ('n_segs', C.c_int32),
-                ('_pad', C.c_int32), ('w_blk_stride', C.c_int64), ('wpack', C.c_void_p), ('bias', C.c_void_p), ('zero_page', C.c_void_p),
+                ('cout_perm', C.c_int32), ('w_blk_stride', C.c_int64), ('wpack', C.c_void_p), ('bias', C.c_void_p), ('zero_page', C.c_void_p),
                 ('chunks', Chunk * MAX_CHUNKS), ('pieces', Piece * MAX_PIECES), ('segs', Seg * MAX_SEGS),
                 ('oct_seg', C.c_int32 * MAX_OCTS), ('oct_n', C.c_int32 * MAX_OCTS), ('oct_ch', C.c_int32 * MAX_OCTS),
                 ('sub_seg', C.c_int32 * (MAX_OCTS // 4)),

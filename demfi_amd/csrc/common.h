@@ -13,6 +13,9 @@ typedef float f4_t __attribute__((ext_vector_type(4)));
 
 // host-side error plumbing (abi.cpp)
 int demfi_set_error(int code, const char* fmt, ...);
+
+struct demfi_conv;
+bool demfi_persist_eligible(const demfi_conv* h);   // conv.hip: the descriptor belongs to the persistent 64-channel 3x3 kernel
 #define DEMFI_HIP_CHECK(expr)                                                                   \
     do {                                                                                        \
         hipError_t e__ = (expr);                                                                \

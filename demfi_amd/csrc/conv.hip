@@ -436,8 +436,9 @@ __global__ __launch_bounds__(NT, (NCO <= 1 ? 4 : (NCO == 2 ? 3 : 2))) void conv_
 //     traffic and no per-tap barriers;
 //   * the haloed input tile is fetched by LDS-DMA (global_load_lds, no VGPR round trip, zero padding through a
 //     zero page) into a double buffer: tile k+1 streams in while tile k is on the matrix cores;
-//   * the epilogue needs no LDS: a v_permlane32_swap per accumulator-quad pair gives every lane 8 consecutive
-//     output channels of its pixel (16-byte stores / residual loads), so there is ONE barrier per tile;
+//   * the epilogue needs no LDS and no cross-lane traffic: the layers of this kernel are packed in a permuted cout order
+//     (demfi_conv.cout_perm) in which the two accumulator quads a lane owns are 8 consecutive output channels of its
+//     pixel (16-byte stores / residual loads straight from registers), so there is ONE barrier per tile;
 //   * pixel records are unpadded (128 B); bank conflicts are removed by an XOR swizzle of the 16-byte slot,
 //     applied on the DMA's per-lane SOURCE address and on the ds_read address (the LDS image stays lane-linear).
 // ======================================================================================================
@@ -572,10 +573,13 @@ __global__ __launch_bounds__(NT + 64 * P_NDMA, 1) void conv3x3_c64_persist_kerne
     const int64_t d_sx = sg0.dst.sx, d_sy = sg0.dst.sy, d_sb = sg0.dst.sb;
     const int64_t r_sx = sg0.res.sx, r_sy = sg0.res.sy, r_sb = sg0.res.sb;
     const float act_floor = sg0.act == DEMFI_ACT_RELU ? 0.0f : -__builtin_huge_valf();
+    h8_t act_floor8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) act_floor8[j] = (half_t)act_floor;
     const int ch0 = d->oct_ch[0];
-    // Epilogue layout: after a v_permlane32_swap of each accumulator-quad pair, lane (lx, hi) holds 8 consecutive output
-    // channels of pixel lx (couts s*32 + 16m + 8hi ..): 16-byte stores / residual loads straight from registers, no LDS
-    // transpose.  The bias (NCO*32 floats) sits in the 2 KiB of LDS behind the tile buffers.
+    // Epilogue layout (cout_perm): quads 2m and 2m+1 of lane (lx, hi) are the 8 consecutive output channels
+    // s*32 + 16m + 8hi .. of pixel lx: 16-byte stores / residual loads straight from registers, no LDS transpose, no
+    // lane exchange.  The bias (NCO*32 floats, MFMA-row order) sits in the 2 KiB of LDS behind the tile buffers.
     float* const bias_lds = (float*)(tbuf + 2 * P_TILE_BYTES);
     if (tid < NCO * 32) bias_lds[tid] = d->bias[tid];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the write is in LDS before this wave's first (raw) barrier A
@@ -855,37 +859,31 @@ __global__ __launch_bounds__(NT + 64 * P_NDMA, 1) void conv3x3_c64_persist_kerne
         for (int s = 0; s < NCO; ++s) {
 #pragma unroll
             for (int m2 = 0; m2 < 2; ++m2) {
-                const f4_t b0 = *(const f4_t*)(bias_lds + s * 32 + m2 * 16 + hi * 8);
-                const f4_t b1 = *(const f4_t*)(bias_lds + s * 32 + m2 * 16 + hi * 8 + 4);
+                // cout_perm: MFMA row (quad g, half hi, j) holds channel (g>>1)*16 + hi*8 + (g&1)*4 + j, so quads 2*m2 and 2*m2+1
+                // of this lane are the 8 consecutive channels 16*m2 + 8*hi .. +7 of its pixel -- no cross-lane exchange (round 1
+                // used a v_permlane32_swap per accumulator pair here); bias_lds is in MFMA-row order
+                const f4_t b0 = *(const f4_t*)(bias_lds + s * 32 + (2 * m2) * 8 + hi * 4);
+                const f4_t b1 = *(const f4_t*)(bias_lds + s * 32 + (2 * m2 + 1) * 8 + hi * 4);
 #pragma unroll
                 for (int p = 0; p < 2; ++p) {
                     float v[8];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        // quad g = 2*m2 (couts 16m2 + 4hi + j) and g = 2*m2+1 (couts 16m2 + 8 + 4hi + j) of this lane
-                        float qa = acc[s][p][(2 * m2) * 4 + j];
-                        float qb = acc[s][p][(2 * m2 + 1) * 4 + j];
-                        // lanes 32-63 of qa <-> lanes 0-31 of qb: lower half gets (own A | upper's A) = couts 16m2 .. +7,
-                        // upper half gets (lower's B | own B) = couts 16m2+8 .. +15.  Inline asm: on ROCm 7.2 the
-                        // __builtin_amdgcn_permlane32_swap builtin returned the same value in both result slots.
-#if defined(__HIP_DEVICE_COMPILE__)
-                        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(qa), "+v"(qb));
-#endif
-                        v[j] = qa;
-                        v[4 + j] = qb;
+                        v[j] = acc[s][p][(2 * m2) * 4 + j] + b0[j];
+                        v[4 + j] = acc[s][p][(2 * m2 + 1) * 4 + j] + b1[j];
                     }
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) { v[j] += b0[j]; v[4 + j] += b1[j]; }
                     if constexpr (RES) {
                         const h8_t r = __builtin_bit_cast(h8_t, rreg[s][p][m2]);
 #pragma unroll
                         for (int j = 0; j < 8; ++j) v[j] += (float)r[j];
                     }
+                    h8_t o;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], act_floor);   // ReLU or identity, branch-free
+                    for (int j = 0; j < 8; ++j) o[j] = (half_t)v[j];
+                    o = __builtin_elementwise_max(o, act_floor8);   // ReLU or identity (floor -inf), branch-free; rounding is monotonic: max after the conversion gives the same value
                     const int oy = oy0 + wave * 2 + p, oxx = ox0 + lx;
                     if (oy < H && oxx < W)
-                        store8<half_t>(dstp + bimg * d_sb + oy * d_sy + oxx * d_sx + ch0 + s * 32 + m2 * 16 + hi * 8, v);
+                        *gp<u4_t>(dstp + bimg * d_sb + oy * d_sy + oxx * d_sx + ch0 + s * 32 + m2 * 16 + hi * 8) = __builtin_bit_cast(u4_t, o);
                 }
             }
         }
@@ -1793,6 +1791,8 @@ int dispatch(const demfi_conv* h, const demfi_conv* dev, hipStream_t st, size_t 
 
 }  // namespace
 
+bool demfi_persist_eligible(const demfi_conv* h) { return persist_eligible(h); }
+
 extern "C" int64_t demfi_conv_lds_bytes(const demfi_conv* h)
 {
     const int64_t LW = (int64_t)(TW - 1) * h->stride + h->kw;
@@ -1854,6 +1854,8 @@ extern "C" int demfi_conv2d(const demfi_conv* h, const demfi_conv* dev, void* st
         if (!ok) return demfi_set_error(DEMFI_ERR_ARG, "demfi_conv2d: subtile %d is not eligible for the staged epilogue", sb);
     }
     hipStream_t st = (hipStream_t)stream;
+    if (h->cout_perm && !persist_eligible(h))
+        return demfi_set_error(DEMFI_ERR_ARG, "demfi_conv2d: descriptor packed for the persistent 3x3 kernel (cout_perm) but not eligible for it (zero_page missing?)");
     if (sep_eligible(h)) {
 #ifdef DEMFI_ABLATION
         static const int svar = getenv("DEMFI_SEP_VARIANT") ? atoi(getenv("DEMFI_SEP_VARIANT")) : 0;
@@ -1866,6 +1868,8 @@ extern "C" int demfi_conv2d(const demfi_conv* h, const demfi_conv* dev, void* st
         return launch_sep(h, dev, st);
     }
     if (persist_eligible(h)) {
+        if (!h->cout_perm)
+            return demfi_set_error(DEMFI_ERR_ARG, "demfi_conv2d: persistent 3x3 layer without cout_perm (build the descriptor with demfi_conv_build)");
 #ifdef DEMFI_ABLATION
         static const int var = getenv("DEMFI_PERSIST_VARIANT") ? atoi(getenv("DEMFI_PERSIST_VARIANT")) : 0;
         if (var == -1) goto general;

@@ -162,23 +162,8 @@ int build_conv(int dtype, int H, int W, int stride, int batch, const float* w, c
         octs.push_back({0, 0, 0});
         cout_map.insert(cout_map.end(), 8, -1);
     }
-    // ---- weights / bias ----------------------------------------------------------------------------------------
     std::vector<int32_t> nks;
     for (auto& c : chunks) nks.push_back(c.nks);
-    int64_t nbytes = 0;
-    int st = demfi_pack_conv_weights(w, cout, cin, kh, kw, cin_map.data(), (int)cin_map.size(), nks.data(), (int)nks.size(),
-                                     cout_map.data(), cout_pad, nco, dtype, nullptr, &nbytes);
-    if (st < 0) return st;
-    out.wbytes = nbytes;
-    out.wpack.resize(size_only ? 0 : nbytes);
-    out.bias.assign(cout_pad, 0.0f);
-    if (!size_only) {
-        st = demfi_pack_conv_weights(w, cout, cin, kh, kw, cin_map.data(), (int)cin_map.size(), nks.data(), (int)nks.size(),
-                                     cout_map.data(), cout_pad, nco, dtype, out.wpack.data(), &nbytes);
-        if (st < 0) return st;
-        for (int i = 0; i < cout_pad; ++i)
-            if (cout_map[i] >= 0 && bias) out.bias[i] = bias[cout_map[i]];
-    }
     // ---- descriptor ----------------------------------------------------------------------------------------------
     demfi_conv& d = out.d;
     memset(&d, 0, sizeof(d));
@@ -233,6 +218,39 @@ int build_conv(int dtype, int H, int W, int stride, int batch, const float* w, c
     }
     d.lw_magic = (uint32_t)((0x100000000ull + LW - 1) / LW);
     out.macs = (int64_t)cout * cin * taps * H * W * batch;
+    // ---- weights / bias ----------------------------------------------------------------------------------------
+    // Layers of the persistent 64-channel 3x3 kernel (conv.hip, conv3x3_c64_persist_kernel) are packed in its cout order: MFMA
+    // row r of a 32-cout subtile holds channel (r>>4)*16 + ((r>>2)&1)*8 + ((r>>3)&1)*4 + (r&3), which makes the two accumulator
+    // quads of a lane 8 consecutive channels (a 16-byte store without any cross-lane exchange).  The octet tables keep
+    // describing the un-permuted routing (that kernel only reads oct_ch[0]).
+    {
+        demfi_conv probe = d;
+        probe.zero_page = &probe;                                   // the context / caller sets the real one later
+        if (!probe.pieces[0].v.ptr) probe.pieces[0].v.ptr = &probe; // sizing pass
+        if (demfi_persist_eligible(&probe)) {
+            d.cout_perm = 1;
+            std::vector<int32_t> pm(cout_map.size());
+            for (size_t i = 0; i < cout_map.size(); ++i) {
+                const int sb = (int)i / 32, r = (int)i % 32;
+                pm[i] = cout_map[sb * 32 + (r >> 4) * 16 + ((r >> 2) & 1) * 8 + ((r >> 3) & 1) * 4 + (r & 3)];
+            }
+            cout_map.swap(pm);
+        }
+    }
+    int64_t nbytes = 0;
+    int st = demfi_pack_conv_weights(w, cout, cin, kh, kw, cin_map.data(), (int)cin_map.size(), nks.data(), (int)nks.size(),
+                                     cout_map.data(), cout_pad, nco, dtype, nullptr, &nbytes);
+    if (st < 0) return st;
+    out.wbytes = nbytes;
+    out.wpack.resize(size_only ? 0 : nbytes);
+    out.bias.assign(cout_pad, 0.0f);
+    if (!size_only) {
+        st = demfi_pack_conv_weights(w, cout, cin, kh, kw, cin_map.data(), (int)cin_map.size(), nks.data(), (int)nks.size(),
+                                     cout_map.data(), cout_pad, nco, dtype, out.wpack.data(), &nbytes);
+        if (st < 0) return st;
+        for (int i = 0; i < cout_pad; ++i)
+            if (cout_map[i] >= 0 && bias) out.bias[i] = bias[cout_map[i]];
+    }
     return DEMFI_OK;
 }
 
@@ -579,11 +597,18 @@ struct Builder {
         for (auto& s : srcs) { sig += s.fat ? 'F' : 'T'; for (int32_t ch : s.cin) sig += std::to_string(ch) + ","; sig += ';'; }
         sig += "|";
         for (auto& d : dsts) { for (int32_t ch : d.couts) sig += std::to_string(ch) + ","; sig += ';'; }
-        auto hit = c->pack_cache.find(sig);
         BuiltConv bc;
         status = build_conv(c->dtype, H, W, stride, batch, w, b, l.cout, l.cin, l.kh, l.kw, cs.data(), (int)cs.size(), cd.data(),
-                            (int)cd.size(), bc, dry || hit != c->pack_cache.end(), name.c_str(), pad_y, pad_x);
+                            (int)cd.size(), bc, true, name.c_str(), pad_y, pad_x);        // descriptor + sizes
         if (status < 0) return;
+        sig += bc.d.cout_perm ? "|P" : "|N";                    // (which kernel owns the layer decides the packed cout order)
+        auto hit = c->pack_cache.find(sig);
+        if (!dry && hit == c->pack_cache.end()) {
+            bc = BuiltConv();
+            status = build_conv(c->dtype, H, W, stride, batch, w, b, l.cout, l.cin, l.kh, l.kw, cs.data(), (int)cs.size(), cd.data(),
+                                (int)cd.size(), bc, false, name.c_str(), pad_y, pad_x);
+            if (status < 0) return;
+        }
         int64_t w_off, b_off;
         if (hit != c->pack_cache.end()) { w_off = hit->second.first; b_off = hit->second.second; }
         else {

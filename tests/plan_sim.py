@@ -104,6 +104,15 @@ class PlanSim:
             assert y.shape[1:] == (d.H, d.W), (y.shape, d.H, d.W)
             bflat, boff = self._flat(d.bias, True)
             y = y + bflat[boff:boff + d.cout_pad].view(-1, 1, 1)
+            if d.cout_perm:
+                # layers of the persistent 64-channel 3x3 kernel: MFMA row r of a 32-cout subtile holds channel
+                # (r>>4)*16 + ((r>>2)&1)*8 + ((r>>3)&1)*4 + (r&3) (include/demfi_hip.h); the octet tables describe the channel order
+                r = torch.arange(d.cout_pad)
+                q = r % 32
+                chan = (r // 32) * 32 + (q >> 4) * 16 + ((q >> 2) & 1) * 8 + ((q >> 3) & 1) * 4 + (q & 3)
+                yc = torch.empty_like(y)
+                yc[chan] = y
+                y = yc
             outs.append(y)
         for b, y in enumerate(outs):
             for o in range(d.cout_pad // 8):

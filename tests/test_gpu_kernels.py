@@ -46,6 +46,8 @@ CONV_CASES = [
     # cin, cout, kh, kw, stride, H, W (output), act, res
     (64, 64, 3, 3, 1, 16, 64, L.ACT_RELU, True),
     (64, 64, 3, 3, 1, 13, 45, L.ACT_NONE, False),      # ragged tile edges
+    (64, 64, 3, 3, 1, 133, 530, L.ACT_RELU, True),     # 289 tiles > 256 workgroups: the persistent tile walk, both accumulator roles
+    (64, 32, 3, 3, 1, 141, 499, L.ACT_NONE, False),    # same, one 32-cout subtile
     (48, 96, 5, 5, 1, 16, 32, L.ACT_NONE, False),
     (96, 32, 3, 3, 1, 8, 32, L.ACT_RELU, False),
     (224, 96, 1, 1, 1, 8, 40, L.ACT_NONE, True),
