@@ -175,8 +175,11 @@ def main():
                        'h2d_bytes_per_step': 4 * a.height * a.width * 3, 'd2h_bytes_per_step': (a.mfi + 1) * a.height * a.width * 3},
         }
         # ---- roofline of the dominant kernel, measured live with HIP events on the launch stream (mean of 5 launches per op) ----
-        prof = eng.profile(a.n_tst, isolated=True)
-        per_t = sum(p[3] for p in prof if p[0] != 'trunk')
+        # batched runner: every convolution launch covers the nb per-t contexts of a trunk set (batch x nb), point-wise
+        # kernels run once per context
+        nb = eng.n_ctx if runner.tb else 1
+        prof = eng.profile(a.n_tst, isolated=True, batched=runner.tb)
+        per_t = sum(p[3] for p in prof if p[0] != 'trunk') / nb
         trunk = sum(p[3] for p in prof if p[0] == 'trunk')
         convs = [p for p in prof if p[1] == 'conv']
         dom = max(convs, key=lambda p: p[3])
@@ -190,13 +193,14 @@ def main():
         pmc = load_pmc_traffic() if a.dtype == 'fp16' and (eng.H, eng.W) == (736, 1280) else None
         kname = runner.engine.dominant_kernel_name() if hasattr(runner.engine, 'dominant_kernel_name') else \
             ('conv3x3_c64_persist_kernel<2>' if a.dtype == 'fp16' else 'conv_kernel<float,2>')
-        out['roofline'] = {'kernel': '%s: D1 residual blocks, 3x3 64->64, batch 3 (%d launches/frame)' % (kname, len(grp)),
+        out['roofline'] = {'kernel': '%s: D1 residual blocks, 3x3 64->64, batch 3 x %d time instants per launch (%d launches per %d frames)' % (kname, nb, len(grp), nb),
                            'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak,
                            'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
                            # HBM bytes per launch from rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE, gfx950 correction), read from
                            # the committed summary of the same code (profiles/r02_pmc_traffic.json)
-                           'traffic': pmc.get('dominant_traffic_bytes') if pmc else None,
-                           'algorithmic_bytes': pmc.get('dominant_algorithmic_bytes') if pmc else None,
+                           # (the PMC summary is per batch-3 image group: x nb for a launch of the batched plan)
+                           'traffic': pmc.get('dominant_traffic_bytes') * nb if pmc else None,
+                           'algorithmic_bytes': pmc.get('dominant_algorithmic_bytes') * nb if pmc else None,
                            'traffic_source': pmc.get('source') if pmc else None,
                            'avg_launch_ms': round(g_ms, 4), 'flop_per_launch': g_fl, 'timing': 'mean of 5 launches per op, HIP events on the launch stream around each launch (agrees with the rocprofv3 in-sequence kernel durations in profiles/r02d_seq_trace_by_op.md; events BETWEEN consecutive launches of a whole pass read 5-8 us higher: launch gaps)',
                            'all_convs_TFLOPs': round(tot_conv_fl / (tot_conv_ms * 1e-3) / 1e12, 2),
@@ -212,8 +216,9 @@ def main():
                                'avg_launch_ms': round(wb_ms, 4), 'bytes_per_launch': wb_bytes}
         cfr = [p for p in prof if p[1] == 'cfr']
         out['breakdown_ms'] = {'trunk_once_per_window': round(trunk, 2), 'per_t': round(per_t, 2),
-                               'launches_per_t': len([p for p in prof if p[0] != 'trunk']),
-                               'conv_share_of_per_t': round(sum(p[3] for p in convs if p[0] != 'trunk') / per_t, 3),
+                               'time_instants_per_launch_sequence': nb,
+                               'launches_per_sequence': len([p for p in prof if p[0] != 'trunk']),
+                               'conv_share_of_per_t': round(sum(p[3] for p in convs if p[0] != 'trunk') / nb / per_t, 3),
                                'cfr_flow_align': round(cfr[0][3], 4) if cfr else None}
         if a.profile_ops:
             with open(a.profile_ops, 'w') as f:

@@ -1112,21 +1112,24 @@ __global__ __launch_bounds__(NT + 64 * NDMA, 1) void conv3x3_narrow_persist_kern
     }
     // optional uint8 sink (demfi_u8_sink, read at run time so that one captured graph serves every destination): octet g
     // = one 3-channel frame segment whose channels all sit in the hi == 0 lane's quad
+    // Batch image b uses the record DEMFI_U8_SINK_STRIDE * b bytes behind it (the batched per-t plan: one record per context);
+    // a workgroup's tile band crosses an image boundary once or twice per launch, so the record is re-read only then.
     unsigned char* s_dst[4] = {nullptr, nullptr, nullptr, nullptr};
-    int s_h = 0, s_w = 0;
-    if constexpr (THIN) {
-        const demfi_u8_sink* sk = d->u8_sink;
-        if (sk != nullptr && sk->iter == d->u8_iter) {
-            s_h = sk->h; s_w = sk->w;
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-                if (t_on[g] == 3 && d->oct_ch[g] == 0) s_dst[g] = sk->frame[d->oct_seg[g]];
-        }
-    }
+    int s_h = 0, s_w = 0, s_img = -1;
     int slot = 0;
     for (int k = 0; k < n_tiles; ++k) {
         int bimg, oy0, ox0;
         tile_coords(t_first + k * t_step, bimg, oy0, ox0);
+        if constexpr (THIN) {
+            if (d->u8_sink != nullptr && bimg != s_img) {        // wave-uniform
+                s_img = bimg;
+                const demfi_u8_sink* sk = (const demfi_u8_sink*)((const char*)d->u8_sink + (int64_t)bimg * DEMFI_U8_SINK_STRIDE);
+                const bool on = sk->iter == d->u8_iter;
+                s_h = sk->h; s_w = sk->w;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) s_dst[g] = (on && t_on[g] == 3 && d->oct_ch[g] == 0) ? sk->frame[d->oct_seg[g]] : nullptr;
+            }
+        }
         u4_t rreg[NCO][2][2];
         float tr[4][2][4];                                      // THIN: residual [octet][row][j], prefetched like rreg
         if constexpr (THIN) {

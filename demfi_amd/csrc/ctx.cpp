@@ -262,6 +262,7 @@ struct Tensor {
     int kind = 0;              // 0 fat [B,h,w,C] path dtype, 1 thin [C,h,w] fp32, 2 raw int64
     int d[4] = {0, 0, 0, 0};   // fat: B,h,w,C; thin: C,h,w,1; raw: n,1,1,1
     int64_t bytes = 0;
+    int64_t cstride = 0;       // per-t buffers: bytes between the copies of consecutive per-t contexts (tensor-major layout), 0 = trunk buffer
 };
 
 struct Weight { std::vector<float> data; std::vector<int64_t> shape; };
@@ -289,6 +290,10 @@ struct demfi_ctx {
     std::vector<OpList> tr_ops;                        // [trunk]
     std::vector<std::vector<OpList>> head_ops;         // [trunk][c]
     std::vector<std::vector<std::vector<OpList>>> iter_ops;   // [trunk][c][it]
+    // the same per-t segment as ONE launch sequence over all n_ctx contexts of a trunk set (demfi_forward_tb): every
+    // convolution runs once with batch x n_ctx (the copies of a per-t buffer are contiguous), point-wise ops once per context
+    std::vector<OpList> tb_head_ops;                   // [trunk]
+    std::vector<std::vector<OpList>> tb_iter_ops;      // [trunk][it]
     std::vector<uint8_t> host_blob;                    // packed weights + biases staged on the host
     std::map<std::string, std::pair<int64_t, int64_t>> pack_cache;   // layer signature -> (w_off, b_off) inside the blob
     int64_t blob_fill = 0;
@@ -372,21 +377,27 @@ void layer_table(demfi_ctx* c)
 struct Layout {
     demfi_ctx* c;
     int64_t cur;
+    int rep = 0;               // > 0: per-t buffers, `rep` copies of every buffer back to back (copy q at off + q * cstride)
     int64_t take(int64_t bytes) { const int64_t o = cur; cur = (cur + bytes + 255) & ~255ll; return o; }
+    void place(Tensor& t)
+    {
+        if (rep > 0) { t.cstride = (t.bytes + 15) & ~15ll; t.off = take(t.cstride * rep); }
+        else t.off = take(t.bytes);
+    }
     void fat(BufSet& s, const char* n, int h, int w, int ch, int b = 1)
     {
         Tensor t; t.kind = 0; t.d[0] = b; t.d[1] = h; t.d[2] = w; t.d[3] = ch;
-        t.bytes = (int64_t)b * h * w * ch * esz_of(c); t.off = take(t.bytes); s[n] = t;
+        t.bytes = (int64_t)b * h * w * ch * esz_of(c); place(t); s[n] = t;
     }
     void thin(BufSet& s, const char* n, int ch, int h, int w)
     {
         Tensor t; t.kind = 1; t.d[0] = ch; t.d[1] = h; t.d[2] = w; t.d[3] = 1;
-        t.bytes = (int64_t)ch * h * w * 4; t.off = take(t.bytes); s[n] = t;
+        t.bytes = (int64_t)ch * h * w * 4; place(t); s[n] = t;
     }
     void raw(BufSet& s, const char* n, int64_t bytes)
     {
         Tensor t; t.kind = 2; t.d[0] = (int)(bytes / 8); t.d[1] = t.d[2] = t.d[3] = 1;
-        t.bytes = bytes; t.off = take(bytes); s[n] = t;
+        t.bytes = bytes; place(t); s[n] = t;
     }
 };
 
@@ -487,7 +498,15 @@ void compute_layout(demfi_ctx* c, int64_t w_bytes, int64_t n_descs)
     c->t_bufs.assign(c->n_trunk, std::vector<BufSet>(c->n_ctx));
     for (int k = 0; k < c->n_trunk; ++k) {
         alloc_trunk(L, c->tr_bufs[k]);
-        for (int q = 0; q < c->n_ctx; ++q) alloc_t(L, c->t_bufs[k][q]);
+        // tensor-major: the n_ctx copies of a per-t buffer are contiguous, so a convolution over "batch x n_ctx" addresses
+        // all of them with one batch stride (demfi_forward_tb)
+        L.rep = c->n_ctx;
+        alloc_t(L, c->t_bufs[k][0]);
+        L.rep = 0;
+        for (int q = 1; q < c->n_ctx; ++q) {
+            c->t_bufs[k][q] = c->t_bufs[k][0];
+            for (auto& kv : c->t_bufs[k][q]) kv.second.off += q * kv.second.cstride;
+        }
     }
     c->total = L.cur;
 }
@@ -507,6 +526,42 @@ struct Builder {
     int status = DEMFI_OK;
     const demfi_u8_sink* sink_for_next = nullptr;   // uint8 sink record of the NEXT conv() call (Dec_last2_2)
     int sink_iter = 0;
+    // ---- batched per-t plan (demfi_forward_tb): build_t on context 0 of trunk set tb_k with tb = n_ctx -----------------
+    int tb = 1, tb_k = 0;
+    // the buffer a device pointer lies in: per-t buffer of context 0 (returns its context stride in bytes), trunk buffer (0),
+    // or neither (-1: weights, zero page, NULL)
+    int64_t ctx_stride_of(const void* p) const
+    {
+        if (!p) return -1;
+        const int64_t off = (const char*)p - c->base;
+        for (const auto& kv : c->t_bufs[tb_k][0])
+            if (off >= kv.second.off && off < kv.second.off + kv.second.bytes) return kv.second.cstride;
+        for (const auto& kv : c->tr_bufs[tb_k])
+            if (off >= kv.second.off && off < kv.second.off + kv.second.bytes) return 0;
+        return -1;
+    }
+    // view of a convolution of the batched plan: the conv runs with batch nb * tb, image index = q * nb + f
+    bool tb_view(demfi_view& v, int nb, const char* name)
+    {
+        if (!v.ptr) return true;
+        const int64_t cs = ctx_stride_of(v.ptr), elt = v.is_f32 ? 4 : 2;
+        if (cs < 0) { status = demfi_set_error(DEMFI_ERR_ARG, "%s: view outside the context's buffers in the batched plan", name); return false; }
+        if (cs == 0) {                                           // trunk buffer: the same image for every context
+            if (nb != 1 && v.sb != 0) { status = demfi_set_error(DEMFI_ERR_ARG, "%s: batched trunk view in a batch-%d layer", name, nb); return false; }
+            v.sb = 0;
+        } else if (nb == 1) v.sb = cs / elt;                     // one image per context
+        else if (v.sb * nb * elt != cs) {                        // nb images per context: they must tile the context stride
+            status = demfi_set_error(DEMFI_ERR_ARG, "%s: %d images of stride %lld do not tile the context stride %lld", name, nb,
+                                     (long long)(v.sb * elt), (long long)cs);
+            return false;
+        }
+        return true;
+    }
+    const void* tb_ptr(const void* p, int q) const
+    {
+        const int64_t cs = ctx_stride_of(p);
+        return cs > 0 ? (const char*)p + q * cs : p;
+    }
 
     char* ptr(const Tensor& t) const { return c->base + t.off; }
     // input piece from a fat buffer [B,h,w,C]: channels [c0, c0+nch) feed original cin [cin0, cin0+nch); b < 0 keeps the
@@ -591,6 +646,11 @@ struct Builder {
         for (size_t i = 0; i < dsts.size(); ++i)
             cd[i] = {dsts[i].dst, dsts[i].res, dsts[i].aux, dsts[i].act, dsts[i].mode, dsts[i].scale, dsts[i].dy, dsts[i].dx,
                      (int32_t)dsts[i].couts.size(), dsts[i].couts.data()};
+        if (tb > 1) {
+            for (auto& x : cs) if (!tb_view(x.v, batch, name.c_str())) return;
+            for (auto& x : cd) if (!tb_view(x.dst, batch, name.c_str()) || !tb_view(x.res, batch, name.c_str()) || !tb_view(x.aux, batch, name.c_str())) return;
+            batch *= tb;
+        }
         // the packed blob of a call site depends on its channel maps only (not on buffer addresses): per-t contexts and
         // the two FGAC directions share one copy
         std::string sig = name + "|";
@@ -664,7 +724,16 @@ struct Builder {
     {
         op.kind = kind;
         strncpy(op.name, name, sizeof(op.name) - 1);
-        seg.push_back(op);
+        if (tb <= 1) { seg.push_back(op); return; }
+        for (int q = 0; q < tb; ++q) {                          // batched plan: the point-wise launch of every context, pointers rebased
+            demfi_op o = op;
+            o.a.ptr = (void*)tb_ptr(op.a.ptr, q);
+            o.b.ptr = (void*)tb_ptr(op.b.ptr, q);
+            o.o.ptr = (void*)tb_ptr(op.o.ptr, q);
+            for (int i = 0; i < 32; ++i) o.p[i] = tb_ptr(op.p[i], q);
+            o.t = tb_ptr(op.t, q);
+            seg.push_back(o);
+        }
     }
     static demfi_op blank() { demfi_op o; memset(&o, 0, sizeof(o)); return o; }
 
@@ -816,7 +885,7 @@ struct Builder {
     {
         BufSet& TB = c->tr_bufs[k];
         BufSet& B = c->t_bufs[k][q];
-        OpList& th = c->head_ops[k][q];
+        OpList& th = tb > 1 ? c->tb_head_ops[k] : c->head_ops[k][q];
         const int H = c->H, W = c->W, N = c->N;
         const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4, H8 = H / 8, W8 = W / 8;
         const int R = DEMFI_ACT_RELU, T = DEMFI_ACT_TANH;
@@ -1005,7 +1074,7 @@ struct Builder {
             }
         }
         for (int it = 0; it < N; ++it) {
-            OpList& sg = c->iter_ops[k][q][it];
+            OpList& sg = tb > 1 ? c->tb_iter_ops[k][it] : c->iter_ops[k][q][it];
             const Tensor& hin = B[it % 2 ? "frec1" : "frec0"];
             const Tensor& hout = B[it % 2 ? "frec0" : "frec1"];
             {
@@ -1066,10 +1135,17 @@ int run_builder(demfi_ctx* c, bool dry)
     c->tr_ops.assign(c->n_trunk, OpList());
     c->head_ops.assign(c->n_trunk, std::vector<OpList>(c->n_ctx));
     c->iter_ops.assign(c->n_trunk, std::vector<std::vector<OpList>>(c->n_ctx, std::vector<OpList>(c->N)));
+    c->tb_head_ops.assign(c->n_trunk, OpList());
+    c->tb_iter_ops.assign(c->n_trunk, std::vector<OpList>(c->N));
     Builder b{c, esz_of(c), c->dtype == DEMFI_F32, dry};
     for (int k = 0; k < c->n_trunk && b.status >= 0; ++k) {
         b.build_trunk(k);
         for (int q = 0; q < c->n_ctx && b.status >= 0; ++q) b.build_t(k, q);
+        if (c->n_ctx > 1 && b.status >= 0) {                    // the batched plan over all contexts of this trunk set
+            b.tb = c->n_ctx; b.tb_k = k;
+            b.build_t(k, 0);
+            b.tb = 1;
+        }
     }
     return b.status;
 }
@@ -1287,10 +1363,24 @@ extern "C" int demfi_forward_t(demfi_ctx* c, int trunk, int q, int n_updates, vo
     return st;
 }
 
+extern "C" int demfi_forward_tb(demfi_ctx* c, int trunk, int n_updates, void* stream)
+{
+    if (!c || !c->bound || c->on_host || trunk < 0 || trunk >= c->n_trunk)
+        return demfi_set_error(DEMFI_ERR_ARG, "demfi_forward_tb: context not bound to device memory / bad trunk index");
+    if (c->n_ctx < 2) return demfi_set_error(DEMFI_ERR_ARG, "demfi_forward_tb: the context has one per-t context (use demfi_forward_t)");
+    if (n_updates < 1 || n_updates > c->N)
+        return demfi_set_error(DEMFI_ERR_ARG, "num_update=%d outside 1..%d the context was built for", n_updates, c->N);
+    int st = run_ops(c, c->tb_head_ops[trunk], stream);
+    for (int it = 0; it < n_updates && st >= 0; ++it) st = run_ops(c, c->tb_iter_ops[trunk][it], stream);
+    return st;
+}
+
 static const OpList* seg_ops(const demfi_ctx* c, int segment, int trunk, int q, int iter)
 {
     if (!c || !c->bound || trunk < 0 || trunk >= c->n_trunk) return nullptr;
     if (segment == DEMFI_SEG_TRUNK) return &c->tr_ops[trunk];
+    if (segment == DEMFI_SEG_TB_HEAD) return &c->tb_head_ops[trunk];
+    if (segment == DEMFI_SEG_TB_ITER && iter >= 0 && iter < c->N) return &c->tb_iter_ops[trunk][iter];
     if (q < 0 || q >= c->n_ctx) return nullptr;
     if (segment == DEMFI_SEG_T_HEAD) return &c->head_ops[trunk][q];
     if (segment == DEMFI_SEG_ITER && iter >= 0 && iter < c->N) return &c->iter_ops[trunk][q][iter];

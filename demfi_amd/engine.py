@@ -181,7 +181,7 @@ class Plan:
         L.check(self.lib.demfi_conv2d(C.byref(self._descs[i]), self.desc_dev.data_ptr() + i * self._desc_sz, stream), what)
 
 
-SEG_TRUNK, SEG_HEAD, SEG_ITER = 0, 1, 2
+SEG_TRUNK, SEG_HEAD, SEG_ITER, SEG_TB_HEAD, SEG_TB_ITER = 0, 1, 2, 3, 4
 KIND_NAME = {0: 'conv', 1: 'pack', 2: 's2d', 3: 'overlay', 4: 'fgac', 5: 'gate', 6: 'cfr', 7: 'warp', 8: 'fgac_window', 9: 'avg_pool'}
 
 
@@ -232,6 +232,7 @@ class Engine:
         self._views = {}
         self._ctxs = [[self._ctx_dict(k, c) for c in range(self._n_ctx)] for k in range(self._n_trunk)]
         self._trunks = [self._trunk_dict(k) for k in range(self._n_trunk)]
+        self._tb = [self._tb_dict(k) for k in range(self._n_trunk)] if self._n_ctx > 1 else None
         self.use_ctx(0, trunk=0)
 
     def __del__(self):
@@ -274,6 +275,21 @@ class Engine:
                 'finals': self.buffer('finals', k, c).view(N, 3, 3, H, W), 'delta': self.buffer('delta', k, c).view(N + 1, 5, H, W),
                 'occ': self.buffer('occ', k, c), 'ft': self.buffer('ft', k, c), 'cfr_acc': self.buffer('cfr_acc', k, c),
                 'sink': self.buffer('sink', k, c)}
+
+    def _tb_dict(self, k):
+        """The per-t contexts' "t" and "sink" buffers of trunk set k as ONE tensor each (the copies of a per-t buffer are
+        contiguous in the workspace): t_col [n_ctx] fp32 (strided view), sink_all [n_ctx, 32] int64."""
+        n = self._n_ctx
+        t0, t1 = self.buffer('t', k, 0), self.buffer('t', k, 1)
+        s0, s1 = self.buffer('sink', k, 0), self.buffer('sink', k, 1)
+        t_stride, s_stride = t1.data_ptr() - t0.data_ptr(), s1.data_ptr() - s0.data_ptr()
+        if t_stride % 4 or s_stride != 256:
+            raise RuntimeError('unexpected per-t context strides (%d, %d)' % (t_stride, s_stride))
+        lo = t0.data_ptr() - self.workspace.data_ptr()
+        t_col = self.workspace[lo:lo + n * t_stride].view(torch.float32).view(n, t_stride // 4)[:, 0]
+        lo = s0.data_ptr() - self.workspace.data_ptr()
+        sink_all = self.workspace[lo:lo + n * 256].view(torch.int64).view(n, 32)
+        return {'t_col': t_col, 'sink_all': sink_all}
 
     @property
     def n_ctx(self):
@@ -327,6 +343,13 @@ class Engine:
             raise ValueError('num_update=%d outside 1..%d the engine was built for' % (n_updates, self.N))
         L.check(self.lib.demfi_forward_t(self._ctx, self.trunk, self.ctx, n_updates, stream), 'forward_t')
 
+    def run_tb(self, stream, n_updates):
+        """The per-t segment of ALL per-t contexts of the bound trunk set as one launch sequence (convolutions batched over
+        the contexts); every context reads its own t / sink buffers."""
+        if not 1 <= n_updates <= self.N:
+            raise ValueError('num_update=%d outside 1..%d the engine was built for' % (n_updates, self.N))
+        L.check(self.lib.demfi_forward_tb(self._ctx, self.trunk, n_updates, stream), 'forward_tb')
+
     # ---- introspection -------------------------------------------------------------------------------------------
     def ops(self, segment, it=0, trunk=None, c=None):
         """The launch ops (L.Op structs) of one segment of one context."""
@@ -353,7 +376,7 @@ class Engine:
     def run_op(self, op, stream):
         L.check(self.lib.demfi_run_op(self._ctx, C.byref(op), stream), 'run_op')
 
-    def profile(self, n_updates, reps=5, isolated=False):
+    def profile(self, n_updates, reps=5, isolated=False, batched=False):
         """Per-launch durations (ms, MEAN over ``reps`` passes after one warm-up pass) of the trunk and one per-t pass, measured
         with HIP events on the stream the kernels are launched on.  Default: IN SEQUENCE -- the whole forward is launched op
         after op with an event between consecutive launches, so every kernel sees the cache state the real pipeline leaves it
@@ -362,8 +385,12 @@ class Engine:
         Returns a list of (segment, op kind, name, ms, macs)."""
         stream = torch.cuda.current_stream(self.device)
         h = stream.cuda_stream
-        segs = [('trunk', self.ops(SEG_TRUNK)), ('t_head', self.ops(SEG_HEAD))] + \
-               [('iter%d' % i, self.ops(SEG_ITER, i)) for i in range(n_updates)]
+        if batched:                                           # the batched per-t plan: every launch covers all n_ctx contexts
+            segs = [('trunk', self.ops(SEG_TRUNK)), ('t_head', self.ops(SEG_TB_HEAD))] + \
+                   [('iter%d' % i, self.ops(SEG_TB_ITER, i)) for i in range(n_updates)]
+        else:
+            segs = [('trunk', self.ops(SEG_TRUNK)), ('t_head', self.ops(SEG_HEAD))] + \
+                   [('iter%d' % i, self.ops(SEG_ITER, i)) for i in range(n_updates)]
         flat = [(sname, op) for sname, ops in segs for op in ops]
         tot = [0.0] * len(flat)
         if isolated:

@@ -63,16 +63,17 @@ class DeMFInet(nn.Module):
         self._engines = {}
         self._weights_version += 1
 
-    def engine(self, H, W, num_update, n_ctx=1, n_trunk=1):
+    def engine(self, H, W, num_update, n_ctx=1, n_trunk=1, exact_ctx=False):
         """Engine for a frame size (built on first use: weight repack + buffer allocation).  n_ctx: independent per-t
-        buffer sets (WindowRunner runs two time instants concurrently)."""
+        buffer sets (WindowRunner batches / overlaps the time instants of a window over them); exact_ctx: the batched plan
+        covers ALL per-t contexts of an engine, so a cached engine with more of them does not do."""
         from .engine import Engine
         if not torch.cuda.is_available():
             raise RuntimeError('demfi_amd.DeMFInet.forward needs an MI355X: the forward path is HIP-only '
                                '(no CPU fallback)')
         key = (H, W, self.path_dtype)
         eng = self._engines.get(key)
-        if eng is None or eng.N < num_update or eng.n_ctx < n_ctx or eng.n_trunk < n_trunk:
+        if eng is None or eng.N < num_update or eng.n_ctx < n_ctx or eng.n_trunk < n_trunk or (exact_ctx and eng.n_ctx != n_ctx):
             sd = {k: v.detach() for k, v in self.state_dict().items()}
             eng = Engine(sd, H, W, self.path_dtype, self.device, max(num_update, 3), self.hp, n_ctx=n_ctx, n_trunk=n_trunk)
             self._engines[key] = eng

@@ -24,11 +24,27 @@ class WindowRunner:
         self.h, self.w = height, width
         H = (height + 31) // 32 * 32
         W = (width + 31) // 32 * 32
-        self.n_ctx = min(int(os.environ.get('DEMFI_NCTX', 5)), max(1, mfi - 1)) if (use_graph and mfi > 2) else 1
         self.n_trunk = int(os.environ.get('DEMFI_NTRUNK', 2)) if use_graph else 1
+        # batched mode (default): the time instants of a window run as ONE launch sequence whose convolutions are batched
+        # over n_ctx per-t contexts (demfi_forward_tb); n_ctx = the largest divisor of M-1 (<= DEMFI_NCTX, default 8) whose
+        # workspace fits the GPU.  DEMFI_TB=0: one graph per time instant on n_ctx streams (round-2a scheduling).
+        self.tb = bool(use_graph and mfi > 2 and os.environ.get('DEMFI_TB', '1') != '0')
+        if self.tb:
+            cap = int(os.environ.get('DEMFI_NCTX', 8))
+            free = torch.cuda.mem_get_info(model.device)[0]
+            lib = L.load()
+            dt = L.F32 if model.path_dtype == torch.float32 else L.F16
+            self.n_ctx = 1
+            for d in range(min(cap, mfi - 1), 1, -1):
+                if (mfi - 1) % d == 0 and 0 < lib.demfi_workspace_bytes(H, W, max(n_tst, 3), dt, self.n_trunk, d) < 0.85 * free:
+                    self.n_ctx = d
+                    break
+            self.tb = self.n_ctx > 1
+        if not self.tb:
+            self.n_ctx = min(int(os.environ.get('DEMFI_NCTX', 5)), max(1, mfi - 1)) if (use_graph and mfi > 2) else 1
         self.model = model
         self._HW = (H, W)
-        self.engine = model.engine(H, W, n_tst, n_ctx=self.n_ctx, n_trunk=self.n_trunk)
+        self.engine = model.engine(H, W, n_tst, n_ctx=self.n_ctx, n_trunk=self.n_trunk, exact_ctx=self.tb)
         self._weights_version = model._weights_version
         self.n_tst, self.mfi = n_tst, mfi
         self.ts = [float(t) for t in t_schedule(mfi)]
@@ -80,15 +96,21 @@ class WindowRunner:
         for k in range(self.n_trunk):                # warm every context (module load, attributes) before capture
             e.use_ctx(0, trunk=k)
             e.run_trunk(h)
-            for c in range(self.n_ctx):
-                e.use_ctx(c)
-                e.run_t(h, self.n_tst)
+            if self.tb:
+                e.run_tb(h, self.n_tst)
+            else:
+                for c in range(self.n_ctx):
+                    e.use_ctx(c)
+                    e.run_t(h, self.n_tst)
         self.stream.synchronize()
-        self._g_trunk, self._g_t, self._g_body = [], [], []
+        self._g_trunk, self._g_t, self._g_body, self._g_tb = [], [], [], []
         for k in range(self.n_trunk):
             e.use_ctx(0, trunk=k)
             self._g_trunk.append(self._capture(e.run_trunk, self.stream))
             self._g_body.append(self._capture(e.run_trunk_body, self.stream))     # trunk after the fused uint8 ingest
+            if self.tb:
+                self._g_tb.append(self._capture(lambda s: e.run_tb(s, self.n_tst), self.t_streams[0]))
+                continue
             gs = []
             for c in range(self.n_ctx):
                 e.use_ctx(c)
@@ -121,6 +143,25 @@ class WindowRunner:
                 e.run_trunk(h)
             ev_trunk = torch.cuda.Event()
             ev_trunk.record(self.stream)
+        if self.tb:
+            # batched: chunks of n_ctx consecutive time instants, each ONE graph replay over all per-t contexts of trunk set k
+            st = self.t_streams[0]
+            st.wait_event(ev_trunk)
+            with torch.cuda.stream(st):
+                for j0 in range(0, self.mfi - 1, self.n_ctx):
+                    e._tb[k]['t_col'].copy_(self.t_all[j0:j0 + self.n_ctx], non_blocking=True)
+                    if pre is not None:
+                        for c in range(self.n_ctx):
+                            pre(j0 + c, e._ctxs[k][c])
+                    else:
+                        e._tb[k]['sink_all'].zero_()  # float path: a sink left by an earlier uint8 run must not fire
+                    L.check(self.lib.demfi_graph_launch(self._g_tb[k], st.cuda_stream), 'graph_launch')
+                    for c in range(self.n_ctx):
+                        emit(j0 + c, e._ctxs[k][c]['finals'][self.n_tst - 1], st.cuda_stream)
+                ev = torch.cuda.Event()
+                ev.record(st)
+            self._t_done[k] = [ev]
+            return
         used = set()
         for j in range(self.mfi - 1):
             c = self._next_ctx
@@ -154,6 +195,8 @@ class WindowRunner:
         self._g_body = None
         for row in (self._g_t or []):
             gs += list(row)
+        gs += list(getattr(self, '_g_tb', None) or [])
+        self._g_tb = None
         for g in gs:
             if g is not None:
                 self.lib.demfi_graph_destroy(g)
@@ -164,7 +207,7 @@ class WindowRunner:
             # the model's weights were reloaded: the old engine's blob (and the graphs pointing at it) are stale
             torch.cuda.synchronize(self.engine.device)
             self._destroy_graphs()
-            self.engine = self.model.engine(self._HW[0], self._HW[1], self.n_tst, n_ctx=self.n_ctx, n_trunk=self.n_trunk)
+            self.engine = self.model.engine(self._HW[0], self._HW[1], self.n_tst, n_ctx=self.n_ctx, n_trunk=self.n_trunk, exact_ctx=self.tb)
             self._weights_version = self.model._weights_version
             self._t_done = [None] * self.n_trunk
         cur = torch.cuda.current_stream(self.engine.device)

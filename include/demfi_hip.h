@@ -147,6 +147,7 @@ typedef struct demfi_conv {
  * s of the convolution additionally writes crop + denorm255_np + uint8 truncation (utils.py:718-721, main.py:1165-1178:
  * float64 arithmetic) of its 3 channels to frame[s] as [h, w, 3] bytes (NULL = that frame is not wanted) and skips the
  * fp32 store of that segment. */
+#define DEMFI_U8_SINK_STRIDE 256   /* bytes between the sink records of consecutive batch images (the per-t contexts' "sink" buffers) */
 typedef struct demfi_u8_sink {
     uint8_t* frame[DEMFI_MAX_SEGS];
     int32_t  h, w;              /* crop (top-left h x w of the padded H x W) */
@@ -342,7 +343,8 @@ enum demfi_op_kind {
     DEMFI_OP_CONV = 0, DEMFI_OP_PACK = 1, DEMFI_OP_S2D = 2, DEMFI_OP_OVERLAY = 3, DEMFI_OP_FGAC = 4, DEMFI_OP_GATE = 5,
     DEMFI_OP_CFR = 6, DEMFI_OP_WARP = 7, DEMFI_OP_FGAC_WINDOW = 8, DEMFI_OP_AVG_POOL = 9
 };
-enum demfi_segment { DEMFI_SEG_TRUNK = 0, DEMFI_SEG_T_HEAD = 1, DEMFI_SEG_ITER = 2 };   /* TRUNK: ops 0, 1 = s2d, overlay (the prologue demfi_ingest_u8 replaces) */
+enum demfi_segment { DEMFI_SEG_TRUNK = 0, DEMFI_SEG_T_HEAD = 1, DEMFI_SEG_ITER = 2,     /* TRUNK: ops 0, 1 = s2d, overlay (the prologue demfi_ingest_u8 replaces) */
+                     DEMFI_SEG_TB_HEAD = 3, DEMFI_SEG_TB_ITER = 4 };                     /* the batched per-t plan of demfi_forward_tb (context index ignored) */
 
 /* One launch of the plan (introspection for tests / per-launch profiling; pointers are already bound). */
 typedef struct demfi_op {
@@ -389,6 +391,14 @@ int     demfi_forward_trunk_body(demfi_ctx* ctx, int trunk, void* stream);
 int     demfi_forward_trunk(demfi_ctx* ctx, int trunk, const float* x, void* stream);
 /* per-t segment (DeMFInet.py:63-165) of per-t context c reading trunk context `trunk`; t is read from buffer "t". */
 int     demfi_forward_t(demfi_ctx* ctx, int trunk, int c, int n_updates, void* stream);
+/* The same per-t segment for ALL n_ctx per-t contexts of trunk set `trunk` as one launch sequence: every convolution runs
+ * once over batch x n_ctx images (the copies of a per-t buffer are contiguous in the workspace: copy c of buffer b sits
+ * c * stride(b) bytes behind copy 0, see demfi_ctx_buffer), the point-wise kernels once per context.  Context c reads its
+ * own "t" and "sink" buffers; results are bit-identical to n_ctx calls of demfi_forward_t.  The time instants of a window
+ * are independent given the trunk (DeMFInet.py:63-165 runs once per t in the reference's loop, main.py:1121-1178): at
+ * x8 the 7 instants of a window are one batch, which takes the launch tails / pipeline fill of the small per-t grids
+ * out of the picture.  n_ctx >= 2. */
+int     demfi_forward_tb(demfi_ctx* ctx, int trunk, int n_updates, void* stream);
 /* introspection / per-launch execution */
 int     demfi_ctx_num_ops(const demfi_ctx* ctx, int segment, int trunk, int c, int iter);
 int     demfi_ctx_get_op(const demfi_ctx* ctx, int segment, int trunk, int c, int iter, int index, demfi_op* out);

@@ -225,6 +225,19 @@ class PlanSim:
             self.run(e.ops(SEG_ITER, it))
 
 
+    def forward_tb(self, x, ts, n):
+        """The batched per-t plan (demfi_forward_tb): context c gets time instant ts[c]; one op list for all contexts."""
+        from demfi_amd.engine import SEG_TB_HEAD, SEG_TB_ITER
+        e = self.e
+        e.x.copy_(x[0])
+        for c, t in enumerate(ts):
+            e._ctxs[e.trunk][c]['t_dev'].fill_(float(t))
+        self.run(e.ops(SEG_TRUNK))
+        self.run(e.ops(SEG_TB_HEAD))
+        for it in range(n):
+            self.run(e.ops(SEG_TB_ITER, it))
+
+
 def _act(v, act):
     if act == L.ACT_RELU:
         return torch.relu(v)

@@ -152,15 +152,18 @@ def test_window_runner_graph_replay_matches_module(model16):
                 assert torch.equal(s01[0], ref[1][N - 1][0][0]) and torch.equal(s01[1], ref[1][N - 1][1][0])
 
 
-def test_window_runner_pipelined_windows_match_module(model16):
-    """run_windows (trunk of window w+1 under the last time instants of window w, several time instants in flight on
-    separate streams, two trunk contexts x five per-t contexts) returns bit-identical frames to one forward per (window, t)."""
+@pytest.mark.parametrize('batched', [True, False])
+def test_window_runner_pipelined_windows_match_module(model16, batched, monkeypatch):
+    """run_windows (trunk of window w+1 under the time instants of window w; the 7 time instants of a window either as ONE
+    launch sequence batched over 7 per-t contexts -- the default -- or one graph per time instant on five streams) returns
+    bit-identical frames to one forward per (window, t)."""
     from demfi_amd.harness import t_schedule
     from demfi_amd.runner import WindowRunner
+    monkeypatch.setenv('DEMFI_TB', '1' if batched else '0')
     h, w, N, M = 40, 72, 2, 8
     xs = [synthetic_window(h, w, 30 + i).to(DEV) for i in range(5)]
     runner = WindowRunner(model16, h, w, n_tst=N, mfi=M, use_graph=True)
-    assert runner.n_trunk == 2 and runner.n_ctx == 5
+    assert runner.n_trunk == 2 and runner.tb == batched and runner.n_ctx == (7 if batched else 5)
     for rep in range(2):
         st, s01 = runner.run_windows(xs)
         torch.cuda.synchronize()

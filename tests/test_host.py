@@ -177,3 +177,36 @@ def test_fp16_plan_with_hoisted_partial_convs(synthetic_sd):
     for i in range(3):
         assert O.psnr(eng.finals[N - 1, i].float().numpy(), ref[1][N - 1][i][0].numpy()) > 42.0
     assert (eng.delta[N, 0:4].float() - ref[2][N][0]).abs().median() < 2e-2
+
+
+@pytest.mark.parametrize('dtype', [torch.float16, torch.float32])
+def test_batched_per_t_plan_equals_per_context_plans(synthetic_sd, dtype):
+    """demfi_forward_tb: ONE op list for all per-t contexts (convolutions batched over the contexts through the contiguous
+    copies of every per-t buffer, point-wise ops once per context).  Interpreted on CPU it must leave in every context exactly
+    what that context's own op lists leave there -- also for the batch-3 D1 layers, the window-level residuals (batch stride
+    0) and the pinned-frame pieces of Ch_Reducer."""
+    H, W, N, NC = 32, 64, 2, 3
+    eng = Engine(synthetic_sd, H, W, dtype, 'cpu', max_updates=N, n_ctx=NC)
+    x = synthetic_window(H, W, 6)
+    ts = [0.25, 0.5, 0.875]
+    sim = PlanSim(eng)
+    want = []
+    for c, t in enumerate(ts):
+        eng.use_ctx(c)
+        sim.forward(x, t, N)
+        want.append({k: eng._ctxs[0][c][k].clone() for k in ('finals', 'delta', 'occ', 'sharp1')})
+        for k in ('finals', 'delta', 'occ', 'sharp1'):
+            eng._ctxs[0][c][k].zero_()
+    eng.use_ctx(0)
+    sim.forward_tb(x, ts, N)
+    for c in range(NC):
+        for k, v in want[c].items():
+            assert torch.equal(eng._ctxs[0][c][k], v), (c, k)
+    assert not torch.equal(want[0]['finals'], want[1]['finals'])
+    # one launch per convolution for all contexts, NC launches per point-wise op
+    from demfi_amd.engine import SEG_HEAD, SEG_TB_HEAD
+    one, tb = eng.ops(SEG_HEAD), eng.ops(SEG_TB_HEAD)
+    n_conv = sum(1 for o in one if o.kind == 0)
+    assert len(tb) == n_conv + NC * (len(one) - n_conv)
+    d1 = [o for o in tb if o.name.decode() == 'Dec_first'][0]
+    assert eng.conv_desc(d1.conv).batch == 3 * NC
