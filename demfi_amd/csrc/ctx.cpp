@@ -36,7 +36,7 @@ struct BuiltConv {
 
 int build_conv(int dtype, int H, int W, int stride, int batch, const float* w, const float* bias, int cout, int cin, int kh,
                int kw, const demfi_conv_src* srcs, int n_srcs, const demfi_conv_dst* dsts, int n_dsts, BuiltConv& out,
-               bool size_only, const char* name, int pad_y = -1, int pad_x = -1)
+               bool size_only, const char* name, int pad_y = -1, int pad_x = -1, int grid_div = 1)
 {
     if (dtype != DEMFI_F16 && dtype != DEMFI_F32) return demfi_set_error(DEMFI_ERR_ARG, "%s: dtype", name);
     if (!srcs || !dsts || n_srcs <= 0 || n_dsts <= 0 || n_dsts > DEMFI_MAX_SEGS || (stride != 1 && stride != 2))
@@ -57,7 +57,9 @@ int build_conv(int dtype, int H, int W, int stride, int batch, const float* w, c
     // CU (LDS), so ~1000 workgroups run in two rounds; 64-byte records (five per CU) finish in one.  Not for the single
     // 64-channel 3x3 shape, which belongs to the persistent kernel (it needs 128-byte records).
     {
-        const int64_t n_wg = (int64_t)((W + 31) / 32) * ((H + 7) / 8) * batch * ((sub + nco - 1) / nco);
+        // grid_div: the batched per-t plan runs the layer over batch = images x contexts; the choice is made on the grid of ONE
+        // context so that both plans use the same record size, i.e. the same summation order: bit-identical results
+        const int64_t n_wg = (int64_t)((W + 31) / 32) * ((H + 7) / 8) * (batch / grid_div) * ((sub + nco - 1) / nco);
         const bool persist_shape = n_srcs == 1 && srcs[0].fat && srcs[0].nch == 64 && kh == 3 && kw == 3 && stride == 1;
         // measured at 720p (same box): the 48 RDB growth convs 0.045-0.072 -> 0.035-0.058 ms, dec2 0.082 -> 0.070; the 96-cout
         // layers (nco = 3: LFF, GFF.1) get slower with it, hence nco <= 2
@@ -659,14 +661,17 @@ struct Builder {
         for (auto& d : dsts) { for (int32_t ch : d.couts) sig += std::to_string(ch) + ","; sig += ';'; }
         BuiltConv bc;
         status = build_conv(c->dtype, H, W, stride, batch, w, b, l.cout, l.cin, l.kh, l.kw, cs.data(), (int)cs.size(), cd.data(),
-                            (int)cd.size(), bc, true, name.c_str(), pad_y, pad_x);        // descriptor + sizes
+                            (int)cd.size(), bc, true, name.c_str(), pad_y, pad_x, tb);    // descriptor + sizes
         if (status < 0) return;
-        sig += bc.d.cout_perm ? "|P" : "|N";                    // (which kernel owns the layer decides the packed cout order)
+        // which kernel owns the layer decides the packed cout order; the record size / cout blocking (they depend on the grid,
+        // i.e. on the batch: the batched plan may choose differently) decide the chunk order of the blob
+        sig += bc.d.cout_perm ? "|P" : "|N";
+        sig += "|r" + std::to_string(bc.d.rec_bytes) + "n" + std::to_string(bc.d.nco);
         auto hit = c->pack_cache.find(sig);
         if (!dry && hit == c->pack_cache.end()) {
             bc = BuiltConv();
             status = build_conv(c->dtype, H, W, stride, batch, w, b, l.cout, l.cin, l.kh, l.kw, cs.data(), (int)cs.size(), cd.data(),
-                                (int)cd.size(), bc, false, name.c_str(), pad_y, pad_x);
+                                (int)cd.size(), bc, false, name.c_str(), pad_y, pad_x, tb);
             if (status < 0) return;
         }
         int64_t w_off, b_off;

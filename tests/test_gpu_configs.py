@@ -109,6 +109,28 @@ def test_config2_720p_fp16_n3_psnr_bounds(oracle_720p_n5):
     torch.cuda.empty_cache()
 
 
+def test_config2_720p_runner_batched_equals_module():
+    """The benched scheduler at the benched size: the 7 time instants of a 720p window as ONE launch sequence batched over 7
+    per-t contexts (demfi_forward_tb; at this size the batched convolutions choose other record sizes / grids than the
+    per-context ones, i.e. other packed-weight blobs) == one pad -> forward -> crop per t, bit for bit."""
+    from demfi_amd.runner import WindowRunner
+    h, w, N, M = 720, 1280, 3, 8
+    m = _model(torch.float16)
+    x = synthetic_window(h, w, 77).to(DEV)
+    runner = WindowRunner(m, h, w, n_tst=N, mfi=M)
+    assert runner.tb and runner.n_ctx == 7
+    st, s01 = runner.run_window(x)
+    torch.cuda.synchronize()
+    ts = t_schedule(M)
+    for k in (0, 3, 6):
+        ref = pad_forward_crop(m, x, torch.tensor([[float(ts[k])]], device=DEV), N)
+        assert torch.equal(st[k], ref[1][N - 1][2][0]), k
+        if k == 0:
+            assert torch.equal(s01[0], ref[1][N - 1][0][0]) and torch.equal(s01[1], ref[1][N - 1][1][0])
+    del runner, m
+    torch.cuda.empty_cache()
+
+
 # ------------------------------------------------------------------------------------------------------
 # configs[4]: 1080p -> 1088x1920, x16 (15 time instants, t_schedule(16)), N_tst = 3, fp16
 # ------------------------------------------------------------------------------------------------------
