@@ -199,7 +199,8 @@ def main():
                            # HBM bytes per launch from rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE, gfx950 correction), read from
                            # the committed summary of the same code (profiles/r02_pmc_traffic.json)
                            # (the PMC summary is per batch-3 image group: x nb for a launch of the batched plan)
-                           'traffic': pmc.get('dominant_traffic_bytes') * nb if pmc else None,
+                           'traffic': (pmc.get('dominant_traffic_bytes_b21') if nb == 7 and pmc.get('dominant_traffic_bytes_b21')
+                                       else pmc.get('dominant_traffic_bytes') * nb) if pmc else None,
                            'algorithmic_bytes': pmc.get('dominant_algorithmic_bytes') * nb if pmc else None,
                            'traffic_source': pmc.get('source') if pmc else None,
                            'avg_launch_ms': round(g_ms, 4), 'flop_per_launch': g_fl, 'timing': 'mean of 5 launches per op, HIP events on the launch stream around each launch (agrees with the rocprofv3 in-sequence kernel durations in profiles/r02d_seq_trace_by_op.md; events BETWEEN consecutive launches of a whole pass read 5-8 us higher: launch gaps)',

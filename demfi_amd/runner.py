@@ -5,11 +5,13 @@ unpadded window is reflect-padded straight into the engine's input buffer, the t
 then the per-t segment runs for t = k/M.  Launch sequences are captured once into hipGraphs through the C ABI and
 replayed (t lives in device memory, so one graph serves every t).
 
-Concurrency (all on ONE GPU, results identical to the sequential order):
-  * the time instants of a window only share the trunk's outputs: ``n_ctx`` per-t contexts (buffer set + descriptors +
-    graph) run consecutive t on separate streams, filling the launch gaps and tails of the ~107 kernels of a pass;
-  * ``run_windows`` pipelines windows over ``n_trunk`` = 2 trunk contexts: the trunk of window w+1 runs while the last
-    time instants of window w are in flight."""
+Scheduling (all on ONE GPU, results bit-identical to one forward per (window, t)):
+  * the time instants of a window only share the trunk's outputs.  Default: they run as ONE launch sequence over ``n_ctx``
+    per-t contexts (``demfi_forward_tb``): every convolution once with batch x n_ctx, the point-wise kernels once per
+    context -- the small per-t grids stop paying launch tails / pipeline fill / weight loads once per time instant.
+    ``DEMFI_TB=0``: one graph per time instant, consecutive t on ``n_ctx`` separate streams;
+  * ``run_windows`` pipelines windows over ``n_trunk`` = 2 trunk contexts: the trunk of window w+1 is queued beside the
+    time instants of window w."""
 import ctypes as C
 import os
 

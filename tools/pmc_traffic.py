@@ -107,6 +107,16 @@ def main():
         # GRBM_GUI_ACTIVE is summed over the 8 XCDs, SQ_VALU_MFMA_BUSY_CYCLES over the 1024 SIMDs
         out['dominant_mfma_busy_frac'] = conv[0].get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / max(1.0, conv[0].get('GRBM_GUI_ACTIVE', 1) * 128)
         out['dominant_clock_GHz'] = conv[0].get('GRBM_GUI_ACTIVE', 0) / 8 / max(1e-9, conv[0].get('avg_us', {}).get('fetch', 0) * 1e3)
+    # the batched per-t plan launches the same kernel over batch 3 x 7 time instants = 21 images
+    big = {c: run(c, os.path.join(outdir, 'b21'), {'PROBE_DATA': 'relu', 'PROBE_B': '21'}) for c in ('c3x3', 'c3x3res')}
+    summary['c3x3_b21'], summary['c3x3res_b21'] = big['c3x3'], big['c3x3res']
+    cb = [v for k, v in big['c3x3'].items() if 'persist' in k]
+    cbr = [v for k, v in big['c3x3res'].items() if 'persist' in k]
+    if cb and cbr:
+        out['dominant_traffic_bytes_b21'] = (hbm(cb[0]) + hbm(cbr[0])) / 2
+        out['dominant_algorithmic_bytes_b21'] = 7 * (723.5e6 + 1085.2e6) / 2
+        out['dominant_mfma_busy_frac_b21'] = cb[0].get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / max(1.0, cb[0].get('GRBM_GUI_ACTIVE', 1) * 128)
+        out['dominant_clock_GHz_b21'] = cb[0].get('GRBM_GUI_ACTIVE', 0) / 8 / max(1e-9, cb[0].get('avg_us', {}).get('fetch', 0) * 1e3)
     if warp:
         out['warp_traffic_bytes'] = hbm(warp[0])
     innet = run_bench_pmc(outdir)

@@ -1,10 +1,10 @@
-"""Map a rocprofv3 kernel trace of a SEQUENTIAL bench run (DEMFI_NCTX=1 DEMFI_NTRUNK=1: one stream, plan order) back to
-the ops of the launch plan and average the true kernel durations per op.
+"""Map a rocprofv3 kernel trace of a SEQUENTIAL bench run (DEMFI_NTRUNK=1: the trunk of the next window does not overlap; plan
+order) back to the ops of the launch plan and average the true kernel durations per op.
 
-    python tools/trace_by_op.py <kernel_trace.csv> <ops.txt written by bench.py --profile-ops> [out.md]
+    python tools/trace_by_op.py <kernel_trace.csv> <ops.txt written by bench.py --profile-ops> [out.md] [passes per window]
 
-The trace holds, per window, the trunk ops followed by 7 per-t passes; a per-t pass is recognised as the longest
-period of the kernel-name sequence.  Output: per op (plan order) the kernel name, calls and mean / min duration --
+The trace holds, per window, the trunk ops followed by `passes` per-t sequences: 1 for the batched plan (every launch
+covers the 7 time instants of the window; the default runner), 7 for one graph per time instant (DEMFI_TB=0 DEMFI_NCTX=1).  Output: per op (plan order) the kernel name, calls and mean / min duration --
 the in-sequence ground truth the per-launch HIP-event numbers of bench.py are compared with."""
 import csv
 import sys
@@ -14,6 +14,7 @@ from collections import defaultdict
 def main():
     trace, ops_path = sys.argv[1], sys.argv[2]
     out = open(sys.argv[3], 'w') if len(sys.argv) > 3 else sys.stdout
+    passes = int(sys.argv[4]) if len(sys.argv) > 4 else 1
     rows = []
     for r in csv.DictReader(open(trace)):
         rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']) - int(r['Start_Timestamp']), r['Kernel_Name']))
@@ -36,7 +37,7 @@ def main():
     prefix = k_trunk + k_t
     body0 = 2
     k_body = sum(per[body0:n_trunk])
-    win = k_body + 7 * k_t
+    win = k_body + passes * k_t
     nwin = (len(idx) - prefix) // win
     acc = defaultdict(list)
     first = None
@@ -54,7 +55,7 @@ def main():
             d = sum(rows[idx[base + pos + j]][1] for j in range(per[oi]))
             acc[oi].append((d, rows[idx[base + pos]][2]))
             pos += per[oi]
-        for t in range(7):
+        for t in range(passes):
             for oi in range(n_trunk, len(ops)):
                 d = sum(rows[idx[base + pos + j]][1] for j in range(per[oi]))
                 acc[oi].append((d, rows[idx[base + pos]][2]))
