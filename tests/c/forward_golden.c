@@ -8,7 +8,8 @@
  * case.bin    : int32 H, W, N; float t; float x[3*4*H*W]; float St[3*H*W]; float flows[4*H*W]
  *               (inputs + the reference's outputs frozen in tests/golden/e2e_*.npz)
  * Checks (fp32 path): |PSNR(St, B0) - PSNR(St_ref, B0)| <= 1e-3 dB (the north-star tolerance), median |St - St_ref|
- * < 2e-5, median |flow - flow_ref| < 2e-4.  Exit code 0 and "C-ABI forward OK" on success.
+ * < 2e-5, median |flow - flow_ref| < 2e-4; then the batched plan (demfi_forward_tb over two per-t contexts) bit-identical to
+ * demfi_forward_t.  Exit code 0 and "C-ABI forward OK" on success.
  */
 #include <math.h>
 #include <stdint.h>
@@ -88,7 +89,7 @@ int main(int argc, char** argv)
 
     /* ---- context: create, load the state_dict, size + allocate + bind the workspace ------------------------- */
     demfi_ctx* ctx = NULL;
-    CHECK(demfi_ctx_create(H, W, N, DEMFI_F32, NULL, 1, 1, &ctx));
+    CHECK(demfi_ctx_create(H, W, N, DEMFI_F32, NULL, 1, 2, &ctx));     /* two per-t contexts: the batched plan is checked below */
     FILE* fw = fopen(argv[1], "rb");
     if (!fw) { perror(argv[1]); return 1; }
     int32_t nt = 0;
@@ -109,7 +110,7 @@ int main(int argc, char** argv)
     }
     fclose(fw);
     const int64_t ws_bytes = demfi_ctx_workspace_bytes(ctx);
-    if (ws_bytes != demfi_workspace_bytes(H, W, N, DEMFI_F32, 1, 1)) { fprintf(stderr, "workspace size mismatch\n"); return 1; }
+    if (ws_bytes != demfi_workspace_bytes(H, W, N, DEMFI_F32, 1, 2)) { fprintf(stderr, "workspace size mismatch\n"); return 1; }
     char* ws = NULL;
     hipStream_t stream;
     HIPCHECK(hipStreamCreate(&stream));
@@ -147,6 +148,25 @@ int main(int argc, char** argv)
     if (!(med_st < 2e-5)) { fprintf(stderr, "St differs\n"); bad = 1; }
     if (!(med_fl < 2e-4)) { fprintf(stderr, "flows differ\n"); bad = 1; }
     if (demfi_forward_t(ctx, 0, 0, N + 1, stream) != DEMFI_ERR_ARG) { fprintf(stderr, "num_update > N was not rejected\n"); bad = 1; }
+    /* ---- the batched plan: both per-t contexts in ONE launch sequence (every convolution over batch x 2) must leave in each
+     * of them exactly what demfi_forward_t left in context 0 */
+    {
+        int64_t off_t1, off_fin1;
+        CHECK(demfi_ctx_buffer(ctx, 0, 1, "t", &off_t1, &kind, dims));
+        CHECK(demfi_ctx_buffer(ctx, 0, 1, "finals", &off_fin1, &kind, dims));
+        const size_t fin_bytes = (size_t)N * 9 * hw * 4;
+        if ((size_t)(off_fin1 - off_fin) != fin_bytes) { fprintf(stderr, "per-t copies of a buffer are not contiguous\n"); bad = 1; }
+        HIPCHECK(hipMemsetAsync(ws + off_fin, 0, 2 * fin_bytes, stream));
+        HIPCHECK(hipMemcpyAsync(ws + off_t1, &t, 4, hipMemcpyHostToDevice, stream));
+        CHECK(demfi_forward_tb(ctx, 0, N, stream));
+        float* st2 = (float*)malloc(3 * hw * 4);
+        for (int c = 0; c < 2; ++c) {
+            HIPCHECK(hipMemcpyAsync(st2, ws + (c ? off_fin1 : off_fin) + ((size_t)(N - 1) * 9 + 6) * hw * 4, 3 * hw * 4, hipMemcpyDeviceToHost, stream));
+            HIPCHECK(hipStreamSynchronize(stream));
+            if (memcmp(st2, st, 3 * hw * 4) != 0) { fprintf(stderr, "demfi_forward_tb: context %d differs from demfi_forward_t\n", c); bad = 1; }
+        }
+        free(st2);
+    }
     CHECK(demfi_ctx_destroy(ctx));
     HIPCHECK(hipFree(ws));
     if (bad) return 1;
