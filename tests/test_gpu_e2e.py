@@ -163,7 +163,7 @@ def test_window_runner_pipelined_windows_match_module(model16, batched, monkeypa
     h, w, N, M = 40, 72, 2, 8
     xs = [synthetic_window(h, w, 30 + i).to(DEV) for i in range(5)]
     runner = WindowRunner(model16, h, w, n_tst=N, mfi=M, use_graph=True)
-    assert runner.n_trunk == 2 and runner.tb == batched and runner.n_ctx == (7 if batched else 5)
+    assert runner.n_trunk == (3 if batched else 2) and runner.tb == batched and runner.n_ctx == (7 if batched else 5)
     for rep in range(2):
         st, s01 = runner.run_windows(xs)
         torch.cuda.synchronize()
