@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DEMFI_ABI_VERSION 3
+#define DEMFI_ABI_VERSION 4
 
 enum demfi_dtype { DEMFI_F16 = 0, DEMFI_F32 = 1 };
 

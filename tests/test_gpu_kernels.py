@@ -96,6 +96,29 @@ def test_conv_vs_torch(case, dtype):
     assert err < tol * max(1.0, ref.abs().max().item()), (case, err)
 
 
+def test_persistent_conv_needs_its_cout_order():
+    """The 64-channel 3x3 layers of the persistent kernel are packed in a permuted cout order (demfi_conv.cout_perm, set by
+    demfi_conv_build): a descriptor of that shape without the flag, or a flagged one the kernel cannot take (no zero page),
+    is refused instead of computing with the wrong channel order."""
+    pl = Plan(16, 64, torch.float16, DEV)
+    x, out = pl._fat(16, 64, 64), pl._fat(16, 64, 64)
+    seg = []
+    pl.conv(seg, 'p', [pl.fsrc(x, 0)], [_Dst(pl.fview(out), range(64), L.ACT_RELU)], 16, 64, weight=torch.randn(64, 64, 3, 3) * 0.05,
+            bias=torch.zeros(64))
+    assert pl._descs[0].cout_perm == 1
+    pl._upload()
+    pl.launch_conv(0, _stream())                               # fine as built
+    d = pl._descs[0]
+    d.cout_perm = 0
+    with pytest.raises(L.DemfiError, match='cout_perm'):
+        L.check(pl.lib.demfi_conv2d(C.byref(d), pl.desc_dev.data_ptr(), _stream()), 'conv')
+    d.cout_perm = 1
+    d.zero_page = None
+    with pytest.raises(L.DemfiError, match='cout_perm'):
+        L.check(pl.lib.demfi_conv2d(C.byref(d), pl.desc_dev.data_ptr(), _stream()), 'conv')
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize('dtype', [torch.float32, torch.float16])
 def test_conv_multi_piece_routing_upsample_shuffle(dtype):
     """Mixed fat/thin/upsampled inputs, PixelShuffle store, planar outputs with residual, GRU modes."""
