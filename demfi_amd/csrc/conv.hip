@@ -460,6 +460,9 @@ template <int NCO> struct FragSet { uint4 a[2][NCO]; uint4 b[2][2]; };
 #ifndef DEMFI_P_NDMA
 #define DEMFI_P_NDMA 2
 #endif
+#ifndef DEMFI_P_KYREUSE
+#define DEMFI_P_KYREUSE 1        // 0: one (tap, k-step pair) at a time, 12 ds_reads per 12 MFMAs (A/B builds)
+#endif
 constexpr int P_NDMA = DEMFI_P_NDMA;                            // waves issuing the tile DMA (instruction i -> wave i % P_NDMA)
 template <int NCO, int VAR, bool PIPE = false, bool RES = true>   // RES: the segment has a residual input (compile time: keeps the loads free of phis).  VAR: 0 = product; 1 no epilogue, 2 no MFMA phase, 3 no tile DMA, 4 epilogue only (ablation builds)
 __global__ __launch_bounds__(NT + 64 * P_NDMA, 1) void conv3x3_c64_persist_kernel(const demfi_conv* __restrict__ d)
@@ -760,6 +763,52 @@ __global__ __launch_bounds__(NT + 64 * P_NDMA, 1) void conv3x3_c64_persist_kerne
                     }
                 }
             };
+            if constexpr (VAR == 0 && !PIPE && DEMFI_P_KYREUSE != 0) {
+                // Input-row reuse across ky: for one (kx, k-step) the taps ky = 0..2 of output rows p = 0, 1 read input rows
+                // p + ky = 0..3 at the same column offset -- 4 distinct B fragments feed 6 (ky, p) combinations.  One group =
+                // 4 row fragments + 3*NCO weight fragments -> 6*NCO MFMAs: 10 ds_reads per 12 MFMAs instead of 12 (NCO = 2).
+                struct RowFrag { uint4 a[3][NCO]; uint4 b[4]; };
+                auto load_g = [&](RowFrag& f, int g) {          // g = kx*4 + ks
+                    const int kx = g >> 2, ks = g & 3;
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+                        for (int s = 0; s < NCO; ++s) f.a[ky][s] = *(const uint4*)(wl + (((ky * 3 + kx) * NKS + ks) * NCO + s) * 1024);
+                    }
+                    const char* p0 = tb + boff[kx * 4 + ks];    // row index is an immediate of the ds_read
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) f.b[r] = *(const uint4*)(p0 + r * (P_LW * 128));
+                };
+                auto mma_g = [&](const RowFrag& f) {
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+                        for (int s = 0; s < NCO; ++s) {
+                            Mma<half_t>::run(acc[s][0], f.a[ky][s], f.b[ky]);
+                            Mma<half_t>::run(acc[s][1], f.a[ky][s], f.b[ky + 1]);
+                        }
+                    }
+                };
+                auto groups = [&](bool loads) {
+#pragma unroll
+                    for (int q = 0; q < 6 * NCO; ++q) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                      // 1 MFMA
+                        if (loads && q < 3 * NCO + 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read of the next group
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+                RowFrag f0, f1;
+                load_g(f0, 0);
+                static_for<0, 6>([&](auto I) {
+                    constexpr int i = decltype(I)::value;
+                    load_g(f1, 2 * i + 1);
+                    mma_g(f0);
+                    groups(true);
+                    if constexpr (i < 5) load_g(f0, 2 * i + 2);
+                    mma_g(f1);
+                    groups(i < 5);
+                });
+            } else
             if constexpr (VAR == 11) {
                 // ablation: ring of four k-step fragment sets, loads three k-steps (12 MFMAs) ahead of their use, one ds_read
                 // issued per MFMA
