@@ -203,7 +203,7 @@ def main():
                                        else pmc.get('dominant_traffic_bytes') * nb) if pmc else None,
                            'algorithmic_bytes': pmc.get('dominant_algorithmic_bytes') * nb if pmc else None,
                            'traffic_source': pmc.get('source') if pmc else None,
-                           'avg_launch_ms': round(g_ms, 4), 'flop_per_launch': g_fl, 'timing': 'mean of 5 launches per op, HIP events on the launch stream around each launch (agrees with the rocprofv3 in-sequence kernel durations in profiles/r02e_seq_trace_by_op.md; events BETWEEN consecutive launches of a whole pass read 5-8 us higher: launch gaps)',
+                           'avg_launch_ms': round(g_ms, 4), 'flop_per_launch': g_fl, 'timing': 'mean of 5 launches per op, HIP events on the launch stream around each launch (agrees with the rocprofv3 in-sequence kernel durations in profiles/r02f_seq_trace_by_op.md; events BETWEEN consecutive launches of a whole pass read 5-8 us higher: launch gaps)',
                            'all_convs_TFLOPs': round(tot_conv_fl / (tot_conv_ms * 1e-3) / 1e12, 2),
                            'slowest_conv': '%s %.3f ms' % (dom[2], dom[3])}
         wb = [p for p in prof if p[1] == 'warp_fat']
