@@ -226,6 +226,22 @@ def main():
                 for p in prof:
                     tf = 2.0 * p[4] / (p[3] * 1e-3) / 1e12 if p[4] else 0.0
                     f.write('%-7s %-10s %-48s %9.4f ms %8.1f TFLOP/s\n' % (p[0], p[1], p[2], p[3], tf))
+        if world == 1 and runner.tb:
+            # the same K steps for a consumer of the LAST recursion's frames only (what the reference's test / test_custom write,
+            # utils.py:1430-1434): the warp + D2 tail of recursions 0..N-2 feeds nothing else and is not run.  Reported beside
+            # the headline, which computes every Sharps_final entry like the reference module does.
+            fo = WindowRunner(model, a.height, a.width, a.n_tst, a.mfi, use_graph=not a.no_graph, final_only=True)
+            fo.run_clip_u8(frames, pick(0, max(a.warmup, 1)), sink, batch=a.batch, reuse_frames=False)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            fo.run_clip_u8(frames, pick(a.warmup, a.steps), sink, batch=a.batch, reuse_frames=False)
+            torch.cuda.synchronize()
+            dt_fo = time.perf_counter() - t1
+            out['final_frames_only'] = {'value': round((a.mfi - 1) * a.steps / dt_fo, 3), 'unit': 'frames/s',
+                                        'ms_per_step': round(1e3 * dt_fo / a.steps, 2),
+                                        'note': 'NOT the headline: D2 of recursions 0..N-2 skipped (outputs-only work); delivered uint8 '
+                                                'frames bit-identical (tests/test_gpu_e2e.py::test_final_only_runner_delivers_the_same_frames)'}
+            del fo
         if world == 1 and not a.no_cpu_baseline:
             out['cpu_baseline'], out['psnr'] = cpu_baseline(a.n_tst, eng.H * eng.W, model, dev)
         print(json.dumps(out))

@@ -130,6 +130,7 @@ _SIGS = {
     'demfi_forward_trunk': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     'demfi_forward_t': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'demfi_forward_tb': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    'demfi_forward_tb_final': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     'demfi_ctx_num_ops': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
     'demfi_ctx_get_op': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Op)]),
     'demfi_ctx_num_convs': (C.c_int, [C.c_void_p]),

@@ -1380,6 +1380,31 @@ extern "C" int demfi_forward_tb(demfi_ctx* c, int trunk, int n_updates, void* st
     return st;
 }
 
+// In a recursion the PWB + D2 tail (warp_thin .. Dec_last2_2) only produces that recursion's frames: the state the next
+// recursion reads is F_rec and the flow / occlusion logits (DeMFInet.py:130-137; Agg3 and D2, 146-165, feed Sharps_final only).
+static size_t d2_start(const OpList& ops)
+{
+    for (size_t i = 0; i < ops.size(); ++i)
+        if (ops[i].kind == DEMFI_OP_WARP && ops[i].nch == 3) return i;
+    return ops.size();
+}
+
+extern "C" int demfi_forward_tb_final(demfi_ctx* c, int trunk, int n_updates, void* stream)
+{
+    if (!c || !c->bound || c->on_host || trunk < 0 || trunk >= c->n_trunk)
+        return demfi_set_error(DEMFI_ERR_ARG, "demfi_forward_tb_final: context not bound to device memory / bad trunk index");
+    if (c->n_ctx < 2) return demfi_set_error(DEMFI_ERR_ARG, "demfi_forward_tb_final: the context has one per-t context");
+    if (n_updates < 1 || n_updates > c->N)
+        return demfi_set_error(DEMFI_ERR_ARG, "num_update=%d outside 1..%d the context was built for", n_updates, c->N);
+    int st = run_ops(c, c->tb_head_ops[trunk], stream);
+    for (int it = 0; it < n_updates && st >= 0; ++it) {
+        const OpList& ops = c->tb_iter_ops[trunk][it];
+        const size_t n = it + 1 < n_updates ? d2_start(ops) : ops.size();
+        for (size_t i = 0; i < n && st >= 0; ++i) st = demfi_run_op(c, &ops[i], stream);
+    }
+    return st;
+}
+
 static const OpList* seg_ops(const demfi_ctx* c, int segment, int trunk, int q, int iter)
 {
     if (!c || !c->bound || trunk < 0 || trunk >= c->n_trunk) return nullptr;

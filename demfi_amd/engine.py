@@ -343,12 +343,14 @@ class Engine:
             raise ValueError('num_update=%d outside 1..%d the engine was built for' % (n_updates, self.N))
         L.check(self.lib.demfi_forward_t(self._ctx, self.trunk, self.ctx, n_updates, stream), 'forward_t')
 
-    def run_tb(self, stream, n_updates):
+    def run_tb(self, stream, n_updates, final_only=False):
         """The per-t segment of ALL per-t contexts of the bound trunk set as one launch sequence (convolutions batched over
-        the contexts); every context reads its own t / sink buffers."""
+        the contexts); every context reads its own t / sink buffers.  final_only: the warp + D2 tail of the recursions before
+        the last one is not run (their frames are outputs only: nothing later reads them)."""
         if not 1 <= n_updates <= self.N:
             raise ValueError('num_update=%d outside 1..%d the engine was built for' % (n_updates, self.N))
-        L.check(self.lib.demfi_forward_tb(self._ctx, self.trunk, n_updates, stream), 'forward_tb')
+        f = self.lib.demfi_forward_tb_final if final_only else self.lib.demfi_forward_tb
+        L.check(f(self._ctx, self.trunk, n_updates, stream), 'forward_tb')
 
     # ---- introspection -------------------------------------------------------------------------------------------
     def ops(self, segment, it=0, trunk=None, c=None):

@@ -22,7 +22,11 @@ from .harness import t_schedule
 
 
 class WindowRunner:
-    def __init__(self, model, height, width, n_tst=3, mfi=8, use_graph=True):
+    def __init__(self, model, height, width, n_tst=3, mfi=8, use_graph=True, final_only=False):
+        """final_only: produce the frames of the LAST recursion only (what test / test_custom consume, utils.py:1430-1434):
+        the warp + D2 tail of the earlier recursions feeds nothing else and is skipped (batched plan only); the delivered
+        frames are bit-identical."""
+        self.final_only = bool(final_only)
         self.h, self.w = height, width
         H = (height + 31) // 32 * 32
         W = (width + 31) // 32 * 32
@@ -49,6 +53,7 @@ class WindowRunner:
                 self.n_trunk = 3
         if not self.tb:
             self.n_ctx = min(int(os.environ.get('DEMFI_NCTX', 5)), max(1, mfi - 1)) if (use_graph and mfi > 2) else 1
+            self.final_only = False                  # a mode of the batched plan
         self.model = model
         self._HW = (H, W)
         self.engine = model.engine(H, W, n_tst, n_ctx=self.n_ctx, n_trunk=self.n_trunk, exact_ctx=self.tb)
@@ -104,7 +109,7 @@ class WindowRunner:
             e.use_ctx(0, trunk=k)
             e.run_trunk(h)
             if self.tb:
-                e.run_tb(h, self.n_tst)
+                e.run_tb(h, self.n_tst, self.final_only)
             else:
                 for c in range(self.n_ctx):
                     e.use_ctx(c)
@@ -116,7 +121,7 @@ class WindowRunner:
             self._g_trunk.append(self._capture(e.run_trunk, self.stream))
             self._g_body.append(self._capture(e.run_trunk_body, self.stream))     # trunk after the fused uint8 ingest
             if self.tb:
-                self._g_tb.append(self._capture(lambda s: e.run_tb(s, self.n_tst), self.t_streams[0]))
+                self._g_tb.append(self._capture(lambda s: e.run_tb(s, self.n_tst, self.final_only), self.t_streams[0]))
                 continue
             gs = []
             for c in range(self.n_ctx):

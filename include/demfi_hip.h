@@ -399,6 +399,12 @@ int     demfi_forward_t(demfi_ctx* ctx, int trunk, int c, int n_updates, void* s
  * x8 the 7 instants of a window are one batch, which takes the launch tails / pipeline fill of the small per-t grids
  * out of the picture.  n_ctx >= 2. */
 int     demfi_forward_tb(demfi_ctx* ctx, int trunk, int n_updates, void* stream);
+/* demfi_forward_tb for a consumer of the LAST recursion's frames only -- which is what the reference's inference pipelines
+ * are (utils.py:1430-1434 "considering list of final", main.py:798, 1153: Sharps_final[-1]).  The pixel-flow warp + D2 tail of
+ * a recursion (DeMFInet.py:146-165) feeds nothing but that recursion's Sharps_final entry (the recursion state is F_rec and the
+ * flow / occlusion logits, 130-137), so it is run for recursion n_updates - 1 only: "finals" / "occ" of the earlier recursions
+ * are NOT written, everything else (flows, logits, the final frames, the uint8 sink) is bit-identical to demfi_forward_tb. */
+int     demfi_forward_tb_final(demfi_ctx* ctx, int trunk, int n_updates, void* stream);
 /* introspection / per-launch execution */
 int     demfi_ctx_num_ops(const demfi_ctx* ctx, int segment, int trunk, int c, int iter);
 int     demfi_ctx_get_op(const demfi_ctx* ctx, int segment, int trunk, int c, int iter, int index, demfi_op* out);

@@ -282,3 +282,33 @@ def test_ragged_frame_size_multiple_of_8_only(dtype):
             _close(got, ref[1][1][i][0].numpy(), 'ragged')
         else:
             assert O.psnr(got, ref[1][1][i][0].numpy()) > 30.0
+
+
+def test_final_only_runner_delivers_the_same_frames(model16):
+    """WindowRunner(final_only=True) skips the warp + D2 tail of the recursions before the last one (their frames are outputs
+    only, DeMFInet.py:146-165): the delivered frames -- fp32 and through the uint8 sink -- are bit-identical, and the earlier
+    recursions' frames are indeed not produced."""
+    from demfi_amd.runner import WindowRunner
+    h, w, N, M = 40, 72, 3, 8
+    x = synthetic_window(h, w, 91).to(DEV)
+    full = WindowRunner(model16, h, w, n_tst=N, mfi=M)
+    st_a, s01_a = full.run_window(x)
+    st_a, s01_a = st_a.clone(), s01_a.clone()
+    g = torch.Generator().manual_seed(3)
+    frames = [torch.randint(0, 256, (h, w, 3), generator=g, dtype=torch.uint8).to(DEV) for _ in range(4)]
+    u_a, us_a = [t.clone() for t in full.run_window_u8(frames)]
+    torch.cuda.synchronize()
+    del full
+    fo = WindowRunner(model16, h, w, n_tst=N, mfi=M, final_only=True)
+    assert fo.tb and fo.final_only
+    eng = fo.engine
+    for row in eng._ctxs:
+        for ctx in row:
+            ctx['finals'].zero_()
+    st_b, s01_b = fo.run_window(x)
+    torch.cuda.synchronize()
+    assert torch.equal(st_a, st_b) and torch.equal(s01_a, s01_b)
+    assert float(eng._ctxs[0][0]['finals'][0].abs().max()) == 0.0 and float(eng._ctxs[0][0]['finals'][N - 1].abs().max()) > 0.0
+    u_b, us_b = fo.run_window_u8(frames)
+    torch.cuda.synchronize()
+    assert torch.equal(u_a, u_b) and torch.equal(us_a, us_b)
