@@ -1,4 +1,4 @@
-// build: hipcc --offload-arch=gfx950 -O3 tools/micro/store_pattern.hip -o tools/micro/store_pattern ; run: ./tools/micro/store_pattern
+// build: hipcc --offload-arch=gfx950 -O3 tools/microbench/store_path_per_cu.hip -o tools/microbench/store_path_per_cu ; run it on the GPU box
 // Micro-benchmark: how fast can 256 persistent workgroups (4 waves each) write an NHWC fp16 64-channel tensor (128-byte pixel
 // records, 3 x 736 x 1280) in 8x32-pixel tiles, depending on how the 16-byte pieces of a store instruction are laid out?
 //   0: (lx, hi) -> pixel lx, 16 B at q*32 + hi*16            (the persistent conv kernel's epilogue: 32-byte runs per pixel)
