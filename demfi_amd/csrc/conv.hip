@@ -1290,23 +1290,16 @@ __global__ __launch_bounds__(NT + 64 * NDMA, 1) void conv3x3_narrow_persist_kern
         for (int s = 0; s < NCO; ++s) {
 #pragma unroll
             for (int m2 = 0; m2 < 2; ++m2) {
-                const f4_t b0 = *(const f4_t*)(bias_lds + s * 32 + m2 * 16 + hi * 8);
-                const f4_t b1 = *(const f4_t*)(bias_lds + s * 32 + m2 * 16 + hi * 8 + 4);
+                const f4_t b0 = *(const f4_t*)(bias_lds + s * 32 + (2 * m2) * 8 + hi * 4);       // bias in MFMA-row order
+                const f4_t b1 = *(const f4_t*)(bias_lds + s * 32 + (2 * m2 + 1) * 8 + hi * 4);
 #pragma unroll
                 for (int p = 0; p < 2; ++p) {
                     float v[8];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        float qa = acc[s][p][(2 * m2) * 4 + j];
-                        float qb = acc[s][p][(2 * m2 + 1) * 4 + j];
-#if defined(__HIP_DEVICE_COMPILE__)
-                        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(qa), "+v"(qb));
-#endif
-                        v[j] = qa;
-                        v[4 + j] = qb;
+                    for (int j = 0; j < 4; ++j) {              // cout_perm: quads 2*m2, 2*m2+1 of this lane = channels 16*m2 + 8*hi + 0..7
+                        v[j] = acc[s][p][(2 * m2) * 4 + j] + b0[j];
+                        v[4 + j] = acc[s][p][(2 * m2 + 1) * 4 + j] + b1[j];
                     }
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) { v[j] += b0[j]; v[4 + j] += b1[j]; }
                     if constexpr (RES) {
                         const h8_t r = __builtin_bit_cast(h8_t, rreg[s][p][m2]);
 #pragma unroll
@@ -1530,23 +1523,16 @@ __device__ __forceinline__ void sep_mfma_waves(const demfi_conv* __restrict__ d,
         for (int s = 0; s < NCO; ++s) {
 #pragma unroll
             for (int m2 = 0; m2 < 2; ++m2) {
-                const f4_t b0 = *(const f4_t*)(bias_lds + s * 32 + m2 * 16 + hi * 8);
-                const f4_t b1 = *(const f4_t*)(bias_lds + s * 32 + m2 * 16 + hi * 8 + 4);
+                const f4_t b0 = *(const f4_t*)(bias_lds + s * 32 + (2 * m2) * 8 + hi * 4);       // bias in MFMA-row order
+                const f4_t b1 = *(const f4_t*)(bias_lds + s * 32 + (2 * m2 + 1) * 8 + hi * 4);
 #pragma unroll
                 for (int p = 0; p < 2; ++p) {
                     float v[8];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        float qa = acc[s][p][(2 * m2) * 4 + j];
-                        float qb = acc[s][p][(2 * m2 + 1) * 4 + j];
-#if defined(__HIP_DEVICE_COMPILE__)
-                        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(qa), "+v"(qb));
-#endif
-                        v[j] = qa;
-                        v[4 + j] = qb;
+                    for (int j = 0; j < 4; ++j) {              // cout_perm: quads 2*m2, 2*m2+1 of this lane = channels 16*m2 + 8*hi + 0..7
+                        v[j] = acc[s][p][(2 * m2) * 4 + j] + b0[j];
+                        v[4 + j] = acc[s][p][(2 * m2 + 1) * 4 + j] + b1[j];
                     }
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) { v[j] += b0[j]; v[4 + j] += b1[j]; }
                     if constexpr (EPI == SEP_SIG) {
 #pragma unroll
                         for (int j = 0; j < 8; ++j) v[j] = fast_sigmoid(v[j]);
@@ -1843,7 +1829,12 @@ int dispatch(const demfi_conv* h, const demfi_conv* dev, hipStream_t st, size_t 
 
 }  // namespace
 
-bool demfi_persist_eligible(const demfi_conv* h) { return persist_eligible(h); }
+// the descriptor belongs to one of the persistent kernels whose epilogue works on 8 consecutive channels per lane: the 64-channel
+// 3x3 kernel, the narrow kernel with an NHWC destination, the SepConvGRU kernel.  Their layers are packed with cout_perm.
+bool demfi_persist_eligible(const demfi_conv* h)
+{
+    return sep_eligible(h) || persist_eligible(h) || (narrow_eligible(h) && persist_out_eligible(h));
+}
 
 extern "C" int64_t demfi_conv_lds_bytes(const demfi_conv* h)
 {
@@ -1906,8 +1897,9 @@ extern "C" int demfi_conv2d(const demfi_conv* h, const demfi_conv* dev, void* st
         if (!ok) return demfi_set_error(DEMFI_ERR_ARG, "demfi_conv2d: subtile %d is not eligible for the staged epilogue", sb);
     }
     hipStream_t st = (hipStream_t)stream;
-    if (h->cout_perm && !persist_eligible(h))
-        return demfi_set_error(DEMFI_ERR_ARG, "demfi_conv2d: descriptor packed for the persistent 3x3 kernel (cout_perm) but not eligible for it (zero_page missing?)");
+    if ((h->cout_perm != 0) != demfi_persist_eligible(h))
+        return demfi_set_error(DEMFI_ERR_ARG, h->cout_perm ? "demfi_conv2d: descriptor packed for a persistent kernel (cout_perm) but not eligible for one (zero_page missing?)"
+                                                           : "demfi_conv2d: persistent-kernel layer without cout_perm (build the descriptor with demfi_conv_build)");
     if (sep_eligible(h)) {
 #ifdef DEMFI_ABLATION
         static const int svar = getenv("DEMFI_SEP_VARIANT") ? atoi(getenv("DEMFI_SEP_VARIANT")) : 0;
@@ -1920,8 +1912,6 @@ extern "C" int demfi_conv2d(const demfi_conv* h, const demfi_conv* dev, void* st
         return launch_sep(h, dev, st);
     }
     if (persist_eligible(h)) {
-        if (!h->cout_perm)
-            return demfi_set_error(DEMFI_ERR_ARG, "demfi_conv2d: persistent 3x3 layer without cout_perm (build the descriptor with demfi_conv_build)");
 #ifdef DEMFI_ABLATION
         static const int var = getenv("DEMFI_PERSIST_VARIANT") ? atoi(getenv("DEMFI_PERSIST_VARIANT")) : 0;
         if (var == -1) goto general;

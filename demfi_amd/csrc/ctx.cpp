@@ -221,7 +221,7 @@ int build_conv(int dtype, int H, int W, int stride, int batch, const float* w, c
     d.lw_magic = (uint32_t)((0x100000000ull + LW - 1) / LW);
     out.macs = (int64_t)cout * cin * taps * H * W * batch;
     // ---- weights / bias ----------------------------------------------------------------------------------------
-    // Layers of the persistent 64-channel 3x3 kernel (conv.hip, conv3x3_c64_persist_kernel) are packed in its cout order: MFMA
+    // Layers of the persistent kernels (conv.hip: 64-channel 3x3, narrow with an NHWC destination, SepConvGRU) are packed in their cout order: MFMA
     // row r of a 32-cout subtile holds channel (r>>4)*16 + ((r>>2)&1)*8 + ((r>>3)&1)*4 + (r&3), which makes the two accumulator
     // quads of a lane 8 consecutive channels (a 16-byte store without any cross-lane exchange).  The octet tables keep
     // describing the un-permuted routing (that kernel only reads oct_ch[0]).

@@ -112,8 +112,9 @@ typedef struct demfi_conv {
     int32_t n_chunks;
     int32_t n_pieces;
     int32_t n_segs;
-    int32_t cout_perm;          /* 1: the packed weights / bias are in the cout order of the persistent 64-channel 3x3
-                                   kernel (set by demfi_conv_build / the context for the layers that kernel owns: within a
+    int32_t cout_perm;          /* 1: the packed weights / bias are in the cout order of the persistent kernels (64-channel
+                                   3x3, narrow with an NHWC destination, SepConvGRU; set by demfi_conv_build / the context for the
+                                   layers those kernels own: within a
                                    32-cout subtile MFMA row r holds channel (r>>4)*16 + ((r>>2)&1)*8 + ((r>>3)&1)*4 + (r&3), so a
                                    lane's two accumulator quads are 8 consecutive channels); demfi_conv2d refuses such a
                                    descriptor when that kernel cannot take it, and an eligible one without the flag */

@@ -105,7 +105,7 @@ class PlanSim:
             bflat, boff = self._flat(d.bias, True)
             y = y + bflat[boff:boff + d.cout_pad].view(-1, 1, 1)
             if d.cout_perm:
-                # layers of the persistent 64-channel 3x3 kernel: MFMA row r of a 32-cout subtile holds channel
+                # layers of the persistent kernels: MFMA row r of a 32-cout subtile holds channel
                 # (r>>4)*16 + ((r>>2)&1)*8 + ((r>>3)&1)*4 + (r&3) (include/demfi_hip.h); the octet tables describe the channel order
                 r = torch.arange(d.cout_pad)
                 q = r % 32
