@@ -42,6 +42,10 @@ def parse():
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--batch', type=int, default=4, help='windows per copy/compute batch of the uint8 pipeline')
     ap.add_argument('--profile-ops', default='', help='write the per-launch timing table to this file')
+    ap.add_argument('--n-ctx', type=int, default=None, help='per-t contexts batched per launch sequence (default: runner decides, printed in config)')
+    ap.add_argument('--n-trunk', type=int, default=None, help='trunk buffer sets pipelined over windows')
+    ap.add_argument('--no-verify', action='store_true', help='skip the byte-for-byte check of one sunk window against the module path')
+    ap.add_argument('--with-png', action='store_true', help='side figure: PNG folder -> PNG folder frames/s of this rank (codec + threads inside)')
     return ap.parse_args()
 
 
@@ -132,16 +136,20 @@ def main():
     # ONE flat broadcast of the 7.4 M parameters (RCCL over xGMI): every rank then owns the real state_dict and packs its
     # own engine, so later engine rebuilds (other frame sizes) are correct on every rank
     D.broadcast_state_dict(model, world, device=dev if backend != 'gloo' else 'cpu')
-    runner = WindowRunner(model, a.height, a.width, a.n_tst, a.mfi, use_graph=not a.no_graph)
+    runner = WindowRunner(model, a.height, a.width, a.n_tst, a.mfi, use_graph=not a.no_graph, n_ctx=a.n_ctx, n_trunk=a.n_trunk)
     # synthetic clip: each rank gets its own 11-frame clip = 8 distinct windows (weak scaling), uint8 frames in PINNED HOST
     # memory: the timed region contains the H2D of every window's 4 frames, the forward, and the D2H of its uint8 outputs
     frames = synthetic_clip_u8(a.height, a.width, 11, seed=1000 * rank + 1)
     wins = window_list(len(frames))
     pick = lambda first, n: [wins[(first + i) % len(wins)] for i in range(n)]
     sunk = [0]
+    kept = {}                                                 # the LAST timed window's delivered bytes (verified after the timed region)
+    keep_k = [-1]
 
     def sink(k, st, s01):                                     # the host consumer: touches every delivered window
         sunk[0] += int(st.shape[0])
+        if k == keep_k[0]:
+            kept['st'], kept['s01'] = st.clone(), s01.clone()
     if a.warmup:
         runner.run_clip_u8(frames, pick(0, a.warmup), sink, batch=a.batch, reuse_frames=False)
     torch.cuda.synchronize()
@@ -151,12 +159,26 @@ def main():
     # a step = one window: H2D (4 uint8 frames, 11 MB) -> reflect pad + normalise -> trunk once -> 7 time instants x N_tst
     # boosts -> crop + denorm + uint8 -> D2H (7 St + S0/S1, 25 MB); the K steps are handed to the scheduler together so that
     # copies, the trunk of window w+1 and the time instants of window w overlap (WindowRunner.run_clip_u8)
-    runner.run_clip_u8(frames, pick(a.warmup, a.steps), sink, batch=a.batch, reuse_frames=False)
+    timed = pick(a.warmup, a.steps)
+    keep_k[0] = a.steps - 1
+    runner.run_clip_u8(frames, timed, sink, batch=a.batch, reuse_frames=False)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     dt = D.max_over_ranks(dt, dev if backend != 'gloo' else 'cpu')
     D.barrier()
     assert sunk[0] == (a.mfi - 1) * a.steps, 'frames delivered to the host: %d' % sunk[0]
+    verify = None
+    if not a.no_verify:
+        # Self-verification of the measured path: the bytes the timed run delivered for its last window (fused uint8 ingest ->
+        # batched per-t plan -> uint8 sink epilogue -> D2H) against the REFERENCE-shaped path on the same frames: one
+        # DeMFInet.forward per t through pad_forward_crop, separate normalise / denorm kernels.  Any difference fails the run.
+        from demfi_amd.harness import module_window_u8
+        st_ref, s01_ref = module_window_u8(model, [frames[i] for i in timed[-1]], a.n_tst, a.mfi)
+        bad = int((kept['st'] != st_ref.cpu()).sum()) + int((kept['s01'] != s01_ref.cpu()).sum())
+        verify = {'window': list(timed[-1]), 'frames_compared': a.mfi + 1, 'bytes_compared': int(kept['st'].numel() + kept['s01'].numel()),
+                  'mismatching_bytes': bad, 'against': 'DeMFInet.forward per t via harness.pad_forward_crop + demfi_frame_to_u8 (module path)'}
+        if bad:
+            raise SystemExit('bench.py: the timed path delivered %d bytes that differ from the module path: %s' % (bad, json.dumps(verify)))
     frames_out = (a.mfi - 1) * a.steps * world
     eng = runner.engine
     if rank == 0:
@@ -172,13 +194,18 @@ def main():
                                    'excluded), %d distinct windows' % (a.n_tst, a.mfi, a.height, a.width, eng.H, eng.W, a.dtype,
                                                                          min(len(wins), a.steps)),
                        'frames_per_step': a.mfi - 1, 'graph': not a.no_graph, 'parallelism': 'clip%d' % world,
+                       'n_ctx': runner.n_ctx, 'n_trunk': runner.n_trunk, 'runner': runner.config,
                        'h2d_bytes_per_step': 4 * a.height * a.width * 3, 'd2h_bytes_per_step': (a.mfi + 1) * a.height * a.width * 3},
         }
-        # ---- roofline of the dominant kernel, measured live with HIP events on the launch stream (mean of 5 launches per op) ----
+        if verify is not None:
+            out['verified'] = verify
+        # ---- roofline of the dominant kernel, measured live with HIP events on the launch stream, IN SEQUENCE: the whole launch plan
+        # runs op after op with an event between consecutive launches (mean of 5 passes), so every kernel sees the clock and cache
+        # state the pipeline leaves it -- an isolated repeat loop lets the clock recover and read 4-5 % faster ----
         # batched runner: every convolution launch covers the nb per-t contexts of a trunk set (batch x nb), point-wise
         # kernels run once per context
         nb = eng.n_ctx if runner.tb else 1
-        prof = eng.profile(a.n_tst, isolated=True, batched=runner.tb)
+        prof = eng.profile(a.n_tst, isolated=False, batched=runner.tb)
         per_t = sum(p[3] for p in prof if p[0] != 'trunk') / nb
         trunk = sum(p[3] for p in prof if p[0] == 'trunk')
         convs = [p for p in prof if p[1] == 'conv']

@@ -6,6 +6,7 @@ Frames are uint8 ``[h, w, 3]`` arrays in cv2's B,G,R order.  PNG goes through th
 files are the fast lane for pipelines that do not need PNG.  The ctypes calls release the GIL, so ``FramePool`` fans
 frames out over host threads: 8 GPUs x ~70 frames/s is ~550 PNGs/s to encode.
 """
+import collections
 import ctypes as C
 import os
 from concurrent.futures import ThreadPoolExecutor
@@ -70,22 +71,31 @@ def write_frame(path, img, level=1):
 
 class FramePool:
     """Thread pool for decode / encode; ``submit_write`` copies the frame first (the caller's buffer may be a reused
-    pinned staging area)."""
+    pinned staging area).  At most ``max_pending`` writes are queued: a producer that outruns the encoders blocks in
+    ``submit_write`` on the oldest one, so host memory stays bounded whatever the clip length (each queued write holds
+    one frame copy)."""
 
-    def __init__(self, threads=None):
-        self.pool = ThreadPoolExecutor(max_workers=threads or min(32, os.cpu_count() or 4))
-        self._pending = []
+    def __init__(self, threads=None, max_pending=None):
+        self.threads = threads or min(32, os.cpu_count() or 4)
+        self.pool = ThreadPoolExecutor(max_workers=self.threads)
+        self.max_pending = max_pending or 4 * self.threads
+        self._pending = collections.deque()
 
     def read_all(self, paths):
         return list(self.pool.map(read_frame, paths))
 
+    def submit_read(self, path):
+        """Future of ``read_frame(path)`` (streaming decode: ClipRunner keeps a few frames ahead of the GPU)."""
+        return self.pool.submit(read_frame, path)
+
     def submit_write(self, path, img, level=1):
+        while len(self._pending) >= self.max_pending:
+            self._pending.popleft().result()             # back-pressure (and surfaces an encoder's exception early)
         self._pending.append(self.pool.submit(write_frame, path, np.array(img, copy=True), level))
 
     def wait(self):
-        for f in self._pending:
-            f.result()
-        self._pending = []
+        while self._pending:
+            self._pending.popleft().result()
 
     def close(self):
         self.wait()

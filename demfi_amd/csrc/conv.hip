@@ -27,6 +27,11 @@
 
 namespace {
 
+// Run-time experiment switches of the persistent kernels (env DEMFI_KNOB, read once on the host and copied into this
+// word; 0 = product behaviour):  bit 0: DMA waves at s_setprio 3;  bit 1 (pair kernel): epilogue at priority 2, MFMA
+// phase at 0;  bit 2 (pair kernel): MFMA phase at priority 2, epilogue at 0.
+__device__ int g_knob = 0;
+
 constexpr int TH = 8;
 constexpr int TW = 32;
 constexpr int NT = 256;
@@ -508,6 +513,7 @@ __global__ __launch_bounds__(NT + 64 * P_NDMA, 1) void conv3x3_c64_persist_kerne
 
     if (wave >= 4) {
         // ================= DMA waves: own every global->LDS transfer, so only THEIR vmcnt tracks them ============
+        if (g_knob & 1) __builtin_amdgcn_s_setprio(3);
         const int dw = wave - 4;
         const demfi_piece& pc = d->pieces[0];
         const char* const src = (const char*)pc.v.ptr;
@@ -957,6 +963,287 @@ int launch_persist(const demfi_conv* h, const demfi_conv* dev, hipStream_t st)
 
 
 // ======================================================================================================
+// PAIR variant of the 64 -> 64 kernel: TWO MFMA waves per SIMD in complementary phases.
+// The 4-wave kernel above runs one MFMA wave per SIMD, so the phases of a tile ADD (MFMA 4 608 + LDS-read waits +
+// hand-over + epilogue VALU + stores = 10 700 cycles per tile, profiles/r02_notes.md).  Here the workgroup has eight
+// MFMA waves: wave w owns row pair (w & 3) of the tile -- as before -- but only ONE 32-cout subtile (w >> 2), so the two
+// waves of a SIMD share their input rows and split the couts.  The halves run SKEWED by half a period:
+//     half 0:  barrier(k)  MFMA(k)         epilogue(k)
+//     half 1:  barrier(k)  epilogue(k-1)   MFMA(k)
+// so on every SIMD one wave's epilogue (VALU + stores) runs under the other wave's MFMAs, and where both are in their
+// MFMA phase they fill each other's issue gaps (the matrix pipe is per SIMD and serves both).  Same LDS image, same
+// DMA waves, same weight blob (cout_perm) and the same one raw barrier per tile as the 4-wave kernel: tile k's buffer
+// is read in period k by both halves, the DMA of tile k+1 fills the other buffer during period k.
+// Price: a wave reuses a B (input) fragment for 32 couts only: 7 ds_read_b128 per 6 MFMAs instead of 10 per 12.
+// ======================================================================================================
+#ifndef DEMFI_PAIR_NDMA
+#define DEMFI_PAIR_NDMA 2
+#endif
+constexpr int PR_NDMA = DEMFI_PAIR_NDMA;
+constexpr int PR_NT = 8 * 64 + 64 * PR_NDMA;
+template <bool RES, bool SKEW>
+__global__ __launch_bounds__(PR_NT, 1) void conv3x3_c64_pair_kernel(const demfi_conv* __restrict__ d)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NTAPS = 9, NKS = 4, NCO = 2;
+    constexpr int WBYTES = NTAPS * NKS * NCO * 1024;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int H = d->H, W = d->W;
+    const int tiles_x = (W + TW - 1) / TW;
+    const int tiles_y = (H + TH - 1) / TH;
+    const int tiles_img = tiles_x * tiles_y;
+    const int total = tiles_img * d->batch;
+    char* const wlds = smem;
+    char* const tbuf = smem + WBYTES;
+    const int G = gridDim.x;
+    int t_first, t_end, t_step;
+    if ((G & 7) == 0 && total >= G) {
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        const int q = total >> 3, r = total & 7;
+        const int lo = xcd * q + min(xcd, r);
+        t_first = lo + idx;
+        t_end = lo + q + (xcd < r ? 1 : 0);
+        t_step = G >> 3;
+    } else {
+        t_first = blockIdx.x;
+        t_end = total;
+        t_step = G;
+    }
+    if (t_first >= t_end) return;
+    auto tile_coords = [&](int t, int& bimg, int& oy0, int& ox0) {
+        bimg = t / tiles_img;
+        const int rem = t - bimg * tiles_img;
+        const int ty = rem / tiles_x;
+        oy0 = ty * TH;
+        ox0 = (rem - ty * tiles_x) * TW;
+    };
+
+    if (wave >= 8) {
+        // ================= DMA waves (as in the 4-wave kernel) ================================================
+        if (g_knob & 1) __builtin_amdgcn_s_setprio(3);
+        const int dw = wave - 8;
+        const demfi_piece& pc = d->pieces[0];
+        const char* const src = (const char*)pc.v.ptr;
+        const int64_t sx = pc.v.sx * 2, sy = pc.v.sy * 2, sb = pc.v.sb * 2;
+        const char* const zeros = (const char*)d->zero_page;
+        int off[P_NI], lyx[P_NI];
+#pragma unroll
+        for (int i = 0; i < P_NI; ++i) {
+            const int px = i * 8 + (lane >> 3);
+            const int ly = px / P_LW;
+            const int lxx = px - ly * P_LW;
+            const int v = (lane & 7) ^ ((lxx >> 1) & 7);
+            off[i] = (int)(ly * sy + lxx * sx) + v * 16;
+            lyx[i] = px < P_NP ? (ly | (lxx << 8)) : 0xffff;
+        }
+        auto issue_tile = [&](int t, int buf) {
+            int bimg, oy0, ox0;
+            tile_coords(t, bimg, oy0, ox0);
+            const char* base = src + (int64_t)bimg * sb + (int64_t)(oy0 - 1) * sy + (int64_t)(ox0 - 1) * sx;
+            char* dst = tbuf + buf * P_TILE_BYTES;
+            const bool interior = oy0 >= 1 && oy0 + TH + 1 <= H && ox0 >= 1 && ox0 + TW + 1 <= W;
+            if (interior) {
+#pragma unroll
+                for (int i = 0; i < P_NI; ++i) {
+                    if ((i % PR_NDMA) != dw) continue;
+                    const char* g = (i == P_NI - 1 && lyx[i] == 0xffff) ? zeros : base + off[i];
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                                     (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < P_NI; ++i) {
+                    if ((i % PR_NDMA) != dw) continue;
+                    const int iy = oy0 - 1 + (lyx[i] & 255), ix = ox0 - 1 + (lyx[i] >> 8);
+                    const char* g = (lyx[i] != 0xffff && iy >= 0 && iy < H && ix >= 0 && ix < W) ? base + off[i] : zeros;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                                     (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+                }
+            }
+        };
+        const uint4* wsrc = (const uint4*)d->wpack;
+        for (int i = dw; i < NTAPS * NKS * NCO; i += PR_NDMA)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + i * 64 + lane),
+                                             (__attribute__((address_space(3))) void*)(wlds + i * 1024), 16, 0, 0);
+        issue_tile(t_first, 0);
+        int buf = 0;
+        for (int t = t_first; t < t_end; t += t_step, buf ^= 1) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (t + t_step < t_end) issue_tile(t + t_step, buf ^ 1);
+        }
+        return;
+    }
+
+    // ================= MFMA waves: row pair wr, cout half ch ==================================================
+    const int ch = wave >> 2, wr = wave & 3;
+    const int hi = lane >> 5;
+    const int lx = lane & 31;
+    const demfi_seg& sg0 = d->segs[d->sub_seg[0]];
+    half_t* const dstp = (half_t*)sg0.dst.ptr;
+    const half_t* const resp = (const half_t*)sg0.res.ptr;
+    const int64_t d_sx = sg0.dst.sx, d_sy = sg0.dst.sy, d_sb = sg0.dst.sb;
+    const int64_t r_sx = sg0.res.sx, r_sy = sg0.res.sy, r_sb = sg0.res.sb;
+    const float act_floor = sg0.act == DEMFI_ACT_RELU ? 0.0f : -__builtin_huge_valf();
+    h8_t act_floor8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) act_floor8[j] = (half_t)act_floor;
+    const int ch0 = d->oct_ch[0] + ch * 32;                     // first output channel of this wave's subtile
+    float* const bias_lds = (float*)(tbuf + 2 * P_TILE_BYTES);
+    if (tid < NCO * 32) bias_lds[tid] = d->bias[tid];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    int boff[12];
+#pragma unroll
+    for (int g = 0; g < 12; ++g) {
+        const int col = lx + (g >> 2);
+        boff[g] = col * 128 + ((((g & 3) * 2 + hi) ^ ((col >> 1) & 7)) << 4);
+    }
+    const char* const wl = wlds + ch * 1024 + lane * 16;        // fragment (tap, ks, subtile ch)
+    const float* const bias_w = bias_lds + ch * 32;
+
+    struct RowFrag1 { uint4 a[3]; uint4 b[4]; };
+    const int knob = g_knob;
+    auto mfma_phase = [&](const char* tb, f16x_t (&acc)[2]) {
+        if (knob & 2) __builtin_amdgcn_s_setprio(0);
+        if (knob & 4) __builtin_amdgcn_s_setprio(2);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { acc[0][i] = 0.0f; acc[1][i] = 0.0f; }
+        auto load_g = [&](RowFrag1& f, int g) {                 // g = kx*4 + ks
+            const int kx = g >> 2, ks = g & 3;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) f.a[ky] = *(const uint4*)(wl + (((ky * 3 + kx) * NKS + ks) * NCO) * 1024);
+            const char* p0 = tb + boff[kx * 4 + ks];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) f.b[r] = *(const uint4*)(p0 + r * (P_LW * 128));
+        };
+        auto mma_g = [&](const RowFrag1& f) {
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                Mma<half_t>::run(acc[0], f.a[ky], f.b[ky]);
+                Mma<half_t>::run(acc[1], f.a[ky], f.b[ky + 1]);
+            }
+        };
+        auto groups = [&](bool loads) {                         // 6 MFMAs with the 7 ds_reads of the next group between them
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (loads) {
+                    if (q == 0) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    else        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        RowFrag1 f0, f1;
+        load_g(f0, 0);
+        static_for<0, 6>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            load_g(f1, 2 * i + 1);
+            mma_g(f0);
+            groups(true);
+            if constexpr (i < 5) load_g(f0, 2 * i + 2);
+            mma_g(f1);
+            groups(i < 5);
+        });
+    };
+    auto load_res = [&](u4_t (&rreg)[2][2], int bimg, int oy0, int ox0) {
+        if constexpr (RES) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int oy = min(oy0 + wr * 2 + p, H - 1), oxx = min(ox0 + lx, W - 1);
+                const half_t* rp = resp + bimg * r_sb + oy * r_sy + oxx * r_sx + ch0 + hi * 8;
+#pragma unroll
+                for (int m2 = 0; m2 < 2; ++m2) rreg[p][m2] = *gcp<u4_t>(rp + m2 * 16);
+            }
+        }
+    };
+    auto epilogue = [&](f16x_t (&acc)[2], u4_t (&rreg)[2][2], int bimg, int oy0, int ox0) {
+        if (knob & 2) __builtin_amdgcn_s_setprio(2);
+        if (knob & 4) __builtin_amdgcn_s_setprio(0);
+        if constexpr (RES) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(rreg[q >> 1][q & 1]));
+        }
+#pragma unroll
+        for (int m2 = 0; m2 < 2; ++m2) {
+            const f4_t b0 = *(const f4_t*)(bias_w + (2 * m2) * 8 + hi * 4);
+            const f4_t b1 = *(const f4_t*)(bias_w + (2 * m2 + 1) * 8 + hi * 4);
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    v[j] = acc[p][(2 * m2) * 4 + j] + b0[j];
+                    v[4 + j] = acc[p][(2 * m2 + 1) * 4 + j] + b1[j];
+                }
+                if constexpr (RES) {
+                    const h8_t r = __builtin_bit_cast(h8_t, rreg[p][m2]);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] += (float)r[j];
+                }
+                h8_t o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = (half_t)v[j];
+                o = __builtin_elementwise_max(o, act_floor8);
+                const int oy = oy0 + wr * 2 + p, oxx = ox0 + lx;
+                if (oy < H && oxx < W)
+                    *gp<u4_t>(dstp + bimg * d_sb + oy * d_sy + oxx * d_sx + ch0 + m2 * 16 + hi * 8) = __builtin_bit_cast(u4_t, o);
+            }
+        }
+    };
+
+    f16x_t acc[2];
+    u4_t rreg[2][2];
+    if (!SKEW || ch == 0) {
+        int buf = 0;
+        for (int t = t_first; t < t_end; t += t_step, buf ^= 1) {
+            int bimg, oy0, ox0;
+            tile_coords(t, bimg, oy0, ox0);
+            load_res(rreg, bimg, oy0, ox0);
+            asm volatile("s_barrier" ::: "memory");
+            mfma_phase(tbuf + buf * P_TILE_BYTES + (wr * 2) * (P_LW * 128), acc);
+            epilogue(acc, rreg, bimg, oy0, ox0);
+        }
+    } else {
+        int buf = 0;
+        int pb = 0, py = 0, px = 0;
+        bool have = false;
+        for (int t = t_first; t < t_end; t += t_step, buf ^= 1) {
+            int bimg, oy0, ox0;
+            tile_coords(t, bimg, oy0, ox0);
+            asm volatile("s_barrier" ::: "memory");
+            if (have) epilogue(acc, rreg, pb, py, px);          // tile k-1, under the other half's MFMAs of tile k
+            load_res(rreg, bimg, oy0, ox0);
+            mfma_phase(tbuf + buf * P_TILE_BYTES + (wr * 2) * (P_LW * 128), acc);
+            pb = bimg; py = oy0; px = ox0;
+            have = true;
+        }
+        epilogue(acc, rreg, pb, py, px);
+    }
+}
+
+static int launch_pair(const demfi_conv* h, const demfi_conv* dev, hipStream_t st, bool skew)
+{
+    const size_t lds = 9 * 4 * 2 * 1024 + 2 * P_TILE_BYTES + 1024;
+    DEMFI_LDS_ATTR((conv3x3_c64_pair_kernel<true, true>));
+    DEMFI_LDS_ATTR((conv3x3_c64_pair_kernel<false, true>));
+    DEMFI_LDS_ATTR((conv3x3_c64_pair_kernel<true, false>));
+    DEMFI_LDS_ATTR((conv3x3_c64_pair_kernel<false, false>));
+    const int total = ((h->W + TW - 1) / TW) * ((h->H + TH - 1) / TH) * h->batch;
+    const int grid = total >= 256 ? 256 : total;
+    const bool res = h->segs[h->sub_seg[0]].res.ptr != nullptr;
+    if (res && skew)       hipLaunchKernelGGL((conv3x3_c64_pair_kernel<true, true>), dim3(grid), dim3(PR_NT), lds, st, dev);
+    else if (res)          hipLaunchKernelGGL((conv3x3_c64_pair_kernel<true, false>), dim3(grid), dim3(PR_NT), lds, st, dev);
+    else if (skew)         hipLaunchKernelGGL((conv3x3_c64_pair_kernel<false, true>), dim3(grid), dim3(PR_NT), lds, st, dev);
+    else                   hipLaunchKernelGGL((conv3x3_c64_pair_kernel<false, false>), dim3(grid), dim3(PR_NT), lds, st, dev);
+    DEMFI_HIP_CHECK(hipGetLastError());
+    return DEMFI_OK;
+}
+
+
+// ======================================================================================================
 // Persistent 3x3 kernel for the NARROW layers (fp16, stride 1): K = 16, 32 or 64 input channels in ONE chunk made of
 // up to two NHWC pieces (+ zero padding), <= 64 output channels -- Mixer conv_delta1/2, conv_blend1/2
 // (DeMFInet.py:800-836) and every other layer of that shape.  These layers are HBM-bound (2-35 GFLOP on 75-180 MB), and
@@ -1044,6 +1331,7 @@ __global__ __launch_bounds__(NT + 64 * NDMA, 1) void conv3x3_narrow_persist_kern
 
     if (wave >= 4) {
         // ================= DMA wave(s) =======================================================================
+        if (g_knob & 1) __builtin_amdgcn_s_setprio(3);
         const int dw = wave - 4;                                 // this wave issues instructions i with i % NDMA == dw
         constexpr int NIW = NI / NDMA;                           // instructions per tile and wave, rounded DOWN (vmcnt waits err on the safe side)
         // the (at most two) real pieces of the chunk; everything else of the record is zero padding
@@ -1601,6 +1889,7 @@ __global__ __launch_bounds__(NT + 64 * S_NDMA, 1) void conv_sep5_c128_persist_ke
 
     if (wave >= 4) {
         // ================= DMA waves (instruction i of a unit belongs to wave i % S_NDMA) ======================
+        if (g_knob & 1) __builtin_amdgcn_s_setprio(3);
         const int dw = wave - 4;
         const demfi_piece& p0 = d->pieces[d->chunks[0].first_piece];
         const demfi_piece& p1 = d->pieces[d->chunks[1].first_piece];
@@ -1902,6 +2191,14 @@ extern "C" int demfi_conv2d(const demfi_conv* h, const demfi_conv* dev, void* st
         if (!ok) return demfi_set_error(DEMFI_ERR_ARG, "demfi_conv2d: subtile %d is not eligible for the staged epilogue", sb);
     }
     hipStream_t st = (hipStream_t)stream;
+    {
+        static const int knob_set = [] {
+            const int k = getenv("DEMFI_KNOB") ? atoi(getenv("DEMFI_KNOB")) : 0;
+            if (k) (void)hipMemcpyToSymbol(HIP_SYMBOL(g_knob), &k, sizeof(k));
+            return k;
+        }();
+        (void)knob_set;
+    }
     if ((h->cout_perm != 0) != demfi_persist_eligible(h))
         return demfi_set_error(DEMFI_ERR_ARG, h->cout_perm ? "demfi_conv2d: descriptor packed for a persistent kernel (cout_perm) but not eligible for one (zero_page missing?)"
                                                            : "demfi_conv2d: persistent-kernel layer without cout_perm (build the descriptor with demfi_conv_build)");
@@ -1943,6 +2240,8 @@ extern "C" int demfi_conv2d(const demfi_conv* h, const demfi_conv* dev, void* st
             if (var == 10) return launch_regw(h, dev, st);
             if (var == 6) return launch_persist<2, 0, true>(h, dev, st);
 #endif
+            static const int pair = getenv("DEMFI_PAIR") ? atoi(getenv("DEMFI_PAIR")) : 0;    // A/B switch: 1 skewed pair kernel, 2 unskewed
+            if (pair) return launch_pair(h, dev, st, pair == 1);
             return launch_persist<2>(h, dev, st);
         }
         return launch_persist<1>(h, dev, st);

@@ -8,12 +8,17 @@
 //           heuristic (libpng's default strategy) or a fixed filter; lossless, so the decoded pixels are what cv2 would write.
 #include "common.h"
 #include <string.h>
+#include <exception>
 #include <vector>
 #include <zlib.h>
 
 namespace {
 
 const uint8_t PNG_SIG[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+// limits of both directions of the codec: 32k x 32k covers any video frame, 2^28 pixels keeps every intermediate buffer (<= 8 bytes
+// per pixel + one filter byte per row) below 4 GiB, the range zlib's one-shot uInt / uLong interfaces are used in
+const int PNG_MAX_DIM = 32768;
+const int64_t PNG_MAX_PIXELS = (int64_t)1 << 28;
 
 inline uint32_t be32(const uint8_t* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
 inline void put32(uint8_t* p, uint32_t v) { p[0] = v >> 24; p[1] = v >> 16; p[2] = v >> 8; p[3] = v; }
@@ -59,7 +64,7 @@ void write_chunk(std::vector<uint8_t>& o, const char* type, const uint8_t* data,
 
 extern "C" int64_t demfi_png_encode_bound(int h, int w)
 {
-    if (h <= 0 || w <= 0) return 0;
+    if (h <= 0 || w <= 0 || h > PNG_MAX_DIM || w > PNG_MAX_DIM || (int64_t)h * w > PNG_MAX_PIXELS) return 0;
     const uLong raw = (uLong)h * ((uLong)w * 3 + 1);
     return (int64_t)compressBound(raw) + 4096;
 }
@@ -67,9 +72,11 @@ extern "C" int64_t demfi_png_encode_bound(int h, int w)
 // bgr: uint8 [h,w,3] with row stride `stride` bytes.  level: zlib 0..9; filter: -1 = adaptive (min-sum heuristic over the 5
 // filters, libpng's default), 0..4 = fixed (1 = Sub is what OpenCV's writer sets); strategy: -1 = Z_RLE for level <= 3 (OpenCV's
 // default), else a zlib strategy constant.  level 1 / Sub / RLE: ~15 ms per 720p frame and core.
-extern "C" int demfi_png_encode(const uint8_t* bgr, int h, int w, int64_t stride, int level, int filter, int strategy, uint8_t* out,
-                                int64_t out_cap, int64_t* out_bytes)
+static int png_encode_impl(const uint8_t* bgr, int h, int w, int64_t stride, int level, int filter, int strategy, uint8_t* out,
+                           int64_t out_cap, int64_t* out_bytes)
 {
+    if (h > PNG_MAX_DIM || w > PNG_MAX_DIM || (int64_t)h * w > PNG_MAX_PIXELS)
+        return demfi_set_error(DEMFI_ERR_ARG, "demfi_png_encode: %d x %d is outside the supported range", h, w);
     if (!bgr || !out || !out_bytes || h <= 0 || w <= 0 || stride < (int64_t)w * 3 || level < 0 || level > 9 || filter < -1 || filter > 4 ||
         strategy > 4)
         return demfi_set_error(DEMFI_ERR_ARG, "demfi_png_encode: bad arguments");
@@ -140,12 +147,17 @@ extern "C" int demfi_png_info(const uint8_t* data, int64_t n, int* h, int* w)
 {
     if (!data || n < 33 || memcmp(data, PNG_SIG, 8) != 0 || memcmp(data + 12, "IHDR", 4) != 0)
         return demfi_set_error(DEMFI_ERR_ARG, "demfi_png_info: not a PNG");
-    if (w) *w = (int)be32(data + 16);
-    if (h) *h = (int)be32(data + 20);
+    // the header is untrusted input: a crafted IHDR must come back as an error, not as an allocation the size of the address space
+    const uint32_t uw = be32(data + 16), uh = be32(data + 20);
+    if (uw == 0 || uh == 0 || uw > (uint32_t)PNG_MAX_DIM || uh > (uint32_t)PNG_MAX_DIM || (int64_t)uw * uh > PNG_MAX_PIXELS)
+        return demfi_set_error(DEMFI_ERR_ARG, "demfi_png_info: image of %u x %u pixels is outside the supported range (<= %d per side, <= %lld pixels)",
+                               uw, uh, PNG_MAX_DIM, (long long)PNG_MAX_PIXELS);
+    if (w) *w = (int)uw;
+    if (h) *h = (int)uh;
     return DEMFI_OK;
 }
 
-extern "C" int demfi_png_decode(const uint8_t* data, int64_t n, uint8_t* bgr, int64_t stride, int h_expect, int w_expect)
+static int png_decode_impl(const uint8_t* data, int64_t n, uint8_t* bgr, int64_t stride, int h_expect, int w_expect)
 {
     int h = 0, w = 0;
     int st = demfi_png_info(data, n, &h, &w);
@@ -209,4 +221,29 @@ extern "C" int demfi_png_decode(const uint8_t* data, int64_t n, uint8_t* bgr, in
         }
     }
     return DEMFI_OK;
+}
+
+// The C ABI never lets a C++ exception out (std::bad_alloc / std::length_error of the std::vectors above would otherwise reach
+// std::terminate through the extern "C" frame and kill the host process).
+extern "C" int demfi_png_encode(const uint8_t* bgr, int h, int w, int64_t stride, int level, int filter, int strategy, uint8_t* out,
+                                int64_t out_cap, int64_t* out_bytes)
+{
+    try {
+        return png_encode_impl(bgr, h, w, stride, level, filter, strategy, out, out_cap, out_bytes);
+    } catch (const std::exception& e) {
+        return demfi_set_error(DEMFI_ERR_ARG, "demfi_png_encode: %s", e.what());
+    } catch (...) {
+        return demfi_set_error(DEMFI_ERR_ARG, "demfi_png_encode: unknown exception");
+    }
+}
+
+extern "C" int demfi_png_decode(const uint8_t* data, int64_t n, uint8_t* bgr, int64_t stride, int h_expect, int w_expect)
+{
+    try {
+        return png_decode_impl(data, n, bgr, stride, h_expect, w_expect);
+    } catch (const std::exception& e) {
+        return demfi_set_error(DEMFI_ERR_ARG, "demfi_png_decode: %s", e.what());
+    } catch (...) {
+        return demfi_set_error(DEMFI_ERR_ARG, "demfi_png_decode: unknown exception");
+    }
 }

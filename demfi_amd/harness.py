@@ -36,3 +36,30 @@ def t_schedule(multiple_mfi):
     """t values of one x M window (utils.py:558): linspace(1/M, 1-1/M, M-1), float32."""
     import numpy as np
     return np.linspace(1 / multiple_mfi, 1 - 1 / multiple_mfi, multiple_mfi - 1).astype(np.float32)
+
+
+def module_window_u8(model, frames_u8, num_update, mfi):
+    """The uint8 frames of one x M window computed the REFERENCE way: one full ``DeMFInet.forward`` per time instant through
+    ``pad_forward_crop`` (utils.py:1339-1477), the loader's normalisation in front (utils.py:232-236) and the writer's
+    ``denorm255_np`` + ``astype(uint8)`` behind (utils.py:718-721, main.py:1165-1178), each as its own kernel.
+    frames_u8: 4 uint8 [h,w,3] tensors (B0, B1, B-1, B2; host or GPU).  Returns (St uint8 [M-1,h,w,3], S0S1 uint8 [2,h,w,3]) on
+    the GPU -- what ``bench.py`` and the 720p test compare the scheduler's sunk bytes against, byte for byte (S0 / S1 from the
+    first time instant, like main.py:1165-1172)."""
+    from .metrics import u8_frame_to_tensor
+    dev = model.device
+    fr = [f.to(dev) for f in frames_u8]
+    h, w = fr[0].shape[:2]
+    x = torch.stack([u8_frame_to_tensor(f) for f in fr], 1).unsqueeze(0)          # [1,3,4,h,w]
+    lib = L.load()
+    st = torch.zeros((mfi - 1, h, w, 3), dtype=torch.uint8, device=dev)
+    s01 = torch.zeros((2, h, w, 3), dtype=torch.uint8, device=dev)
+    sh = torch.cuda.current_stream(dev).cuda_stream
+    for j, t in enumerate(t_schedule(mfi)):
+        fin = pad_forward_crop(model, x, torch.tensor([[float(t)]], device=dev), num_update)[1][num_update - 1]
+        planes = [f[0].contiguous() for f in fin]                                  # S0, S1, St: [3,h,w] fp32
+        L.check(lib.demfi_frame_to_u8(planes[2].data_ptr(), st[j].data_ptr(), h, w, h, w, sh), 'to_u8')
+        if j == 0:
+            for i in range(2):
+                L.check(lib.demfi_frame_to_u8(planes[i].data_ptr(), s01[i].data_ptr(), h, w, h, w, sh), 'to_u8')
+    torch.cuda.synchronize(dev)
+    return st, s01

@@ -22,38 +22,58 @@ from .harness import t_schedule
 
 
 class WindowRunner:
-    def __init__(self, model, height, width, n_tst=3, mfi=8, use_graph=True, final_only=False):
+    def __init__(self, model, height, width, n_tst=3, mfi=8, use_graph=True, final_only=False, n_ctx=None, n_trunk=None):
         """final_only: produce the frames of the LAST recursion only (what test / test_custom consume, utils.py:1430-1434):
         the warp + D2 tail of the earlier recursions feeds nothing else and is skipped (batched plan only); the delivered
-        frames are bit-identical."""
+        frames are bit-identical.
+        n_ctx / n_trunk: per-t contexts batched into one launch sequence / trunk buffer sets pipelined over windows.  Explicit
+        values are taken as given (n_ctx must divide M-1 for the batched plan; the workspace must fit or engine creation
+        fails loudly).  None = default: env DEMFI_NCTX / DEMFI_NTRUNK, else the configuration of an engine the model
+        already holds for this frame size, else a probe of the free memory -- throughput then depends on co-tenants, so
+        the chosen values are exposed as ``self.n_ctx`` / ``self.n_trunk`` / ``self.config`` and printed by bench.py."""
         self.final_only = bool(final_only)
         self.h, self.w = height, width
         H = (height + 31) // 32 * 32
         W = (width + 31) // 32 * 32
-        self.n_trunk = int(os.environ.get('DEMFI_NTRUNK', 2)) if use_graph else 1
+        env_trunk = os.environ.get('DEMFI_NTRUNK')
+        env_ctx = os.environ.get('DEMFI_NCTX')
+        cached = getattr(model, '_engines', {}).get((H, W, model.path_dtype)) if use_graph else None
+        if cached is not None and cached.n_ctx <= 1:     # a plain forward()'s engine says nothing about a runner's configuration
+            cached = None
+        how = 'explicit'
+        if n_trunk is None:
+            n_trunk = int(env_trunk) if env_trunk else (cached.n_trunk if cached is not None else None)
+        self.n_trunk = (n_trunk or 2) if use_graph else 1
         # batched mode (default): the time instants of a window run as ONE launch sequence whose convolutions are batched
-        # over n_ctx per-t contexts (demfi_forward_tb); n_ctx = the largest divisor of M-1 (<= DEMFI_NCTX, default 8) whose
-        # workspace fits the GPU.  DEMFI_TB=0: one graph per time instant on n_ctx streams (round-2a scheduling).
+        # over n_ctx per-t contexts (demfi_forward_tb).  DEMFI_TB=0: one graph per time instant on n_ctx streams (round-2a).
         self.tb = bool(use_graph and mfi > 2 and os.environ.get('DEMFI_TB', '1') != '0')
         if self.tb:
-            cap = int(os.environ.get('DEMFI_NCTX', 8))
-            free = torch.cuda.mem_get_info(model.device)[0]
             lib = L.load()
             dt = L.F32 if model.path_dtype == torch.float32 else L.F16
-            self.n_ctx = 1
-            for d in range(min(cap, mfi - 1), 1, -1):
-                if (mfi - 1) % d == 0 and 0 < lib.demfi_workspace_bytes(H, W, max(n_tst, 3), dt, self.n_trunk, d) < 0.85 * free:
-                    self.n_ctx = d
-                    break
+            if n_ctx is None and cached is not None and cached.n_ctx > 1 and (mfi - 1) % cached.n_ctx == 0 and not env_ctx:
+                n_ctx, how = cached.n_ctx, 'cached engine'
+            if n_ctx is None:
+                # the largest divisor of M-1 (<= DEMFI_NCTX, default 8) whose workspace fits the free memory
+                how = 'env' if env_ctx else 'memory probe'
+                cap = int(env_ctx or 8)
+                free = torch.cuda.mem_get_info(model.device)[0]
+                n_ctx = 1
+                for d in range(min(cap, mfi - 1), 1, -1):
+                    if (mfi - 1) % d == 0 and 0 < lib.demfi_workspace_bytes(H, W, max(n_tst, 3), dt, self.n_trunk, d) < 0.85 * free:
+                        n_ctx = d
+                        break
+                # a third trunk set (its own per-t sets and stream) lets three consecutive windows overlap: +0.7 % at 720p for
+                # 40 GB; taken only when nothing was specified and it leaves half of the GPU's memory free
+                if n_ctx > 1 and n_trunk is None and 0 < lib.demfi_workspace_bytes(H, W, max(n_tst, 3), dt, 3, n_ctx) < 0.5 * free:
+                    self.n_trunk = 3
+            elif n_ctx > 1 and (mfi - 1) % n_ctx:
+                raise ValueError('WindowRunner: n_ctx=%d must divide M-1=%d for the batched per-t plan' % (n_ctx, mfi - 1))
+            self.n_ctx = int(n_ctx)
             self.tb = self.n_ctx > 1
-            # a third trunk set (its own per-t sets and stream) lets three consecutive windows overlap: +0.7 % at 720p for 40 GB;
-            # taken only when it leaves half of the GPU's memory free
-            if self.tb and 'DEMFI_NTRUNK' not in os.environ and \
-                    0 < lib.demfi_workspace_bytes(H, W, max(n_tst, 3), dt, 3, self.n_ctx) < 0.5 * free:
-                self.n_trunk = 3
         if not self.tb:
-            self.n_ctx = min(int(os.environ.get('DEMFI_NCTX', 5)), max(1, mfi - 1)) if (use_graph and mfi > 2) else 1
+            self.n_ctx = (int(n_ctx) if n_ctx else min(int(env_ctx or 5), max(1, mfi - 1))) if (use_graph and mfi > 2) else 1
             self.final_only = False                  # a mode of the batched plan
+        self.config = {'n_ctx': self.n_ctx, 'n_trunk': self.n_trunk, 'batched': self.tb, 'final_only': self.final_only, 'chosen_by': how}
         self.model = model
         self._HW = (H, W)
         self.engine = model.engine(H, W, n_tst, n_ctx=self.n_ctx, n_trunk=self.n_trunk, exact_ctx=self.tb)
@@ -132,7 +152,7 @@ class WindowRunner:
             s.synchronize()
         e.use_ctx(0, trunk=0)
 
-    def _window(self, load, emit, body_only=False, pre=None):
+    def _window(self, load, emit, body_only=False, pre=None, emit_ctx=False):
         """One window: load(engine, stream_handle) fills the bound trunk context's input on the trunk stream;
         emit(j, finals, stream_handle) copies the outputs of time instant j out of a per-t context on that context's stream.
         body_only: load() already did the trunk's prologue (fused uint8 ingest).  pre(j, ctx): runs on the per-t stream before
@@ -171,7 +191,10 @@ class WindowRunner:
                         e._tb[k]['sink_all'].zero_()  # float path: a sink left by an earlier uint8 run must not fire
                     L.check(self.lib.demfi_graph_launch(self._g_tb[k], st.cuda_stream), 'graph_launch')
                     for c in range(self.n_ctx):
-                        emit(j0 + c, e._ctxs[k][c]['finals'][self.n_tst - 1], st.cuda_stream)
+                        if emit_ctx:
+                            emit(j0 + c, e._ctxs[k][c]['finals'][self.n_tst - 1], st.cuda_stream, e._ctxs[k][c])
+                        else:
+                            emit(j0 + c, e._ctxs[k][c]['finals'][self.n_tst - 1], st.cuda_stream)
                 ev = torch.cuda.Event()
                 ev.record(st)
             self._t_done[k] = [ev]
@@ -196,7 +219,10 @@ class WindowRunner:
                 else:
                     e.use_ctx(c)
                     e.run_t(st.cuda_stream, self.n_tst)
-                emit(j, ctx['finals'][self.n_tst - 1], st.cuda_stream)
+                if emit_ctx:
+                    emit(j, ctx['finals'][self.n_tst - 1], st.cuda_stream, ctx)
+                else:
+                    emit(j, ctx['finals'][self.n_tst - 1], st.cuda_stream)
         evs = []
         for c in used:
             ev = torch.cuda.Event()
@@ -251,18 +277,30 @@ class WindowRunner:
         return load
 
     # ---------------------------------------------------------------------------------------------------------
-    def run_window(self, x):
-        """x: [1,3,4,h,w] fp32 on the GPU.  Returns (St [M-1,3,h,w], S0S1 [2,3,h,w]) -- views of reused buffers."""
+    def run_window(self, x, with_d1=False):
+        """x: [1,3,4,h,w] fp32 on the GPU.  Returns (St [M-1,3,h,w], S0S1 [2,3,h,w]) -- views of reused buffers.
+        with_d1: also the Stage-I frames ``Sharps_prime`` (DeMFInet.py:95-103): (St, S0S1, St' [M-1,3,h,w], S0'S1' [2,3,h,w])."""
         load = self._loader(x)
         cur = self._begin()
+        if with_d1 and getattr(self, 'out_d1', None) is None:
+            self.out_d1 = torch.zeros_like(self.out)
+            self.s01_d1 = torch.zeros_like(self.s01)
 
-        def emit(j, fin, sh):
+        def emit(j, fin, sh, ctx=None):
             self.out[j].copy_(fin[2, :, :self.h, :self.w], non_blocking=True)
             if j == 0:
                 self.s01[0].copy_(fin[0, :, :self.h, :self.w], non_blocking=True)
                 self.s01[1].copy_(fin[1, :, :self.h, :self.w], non_blocking=True)
-        self._window(load, emit)
+            if with_d1:
+                d1 = ctx['sharp1']                   # [9,H,W]: S0', S1', St'
+                self.out_d1[j].copy_(d1[6:9, :self.h, :self.w], non_blocking=True)
+                if j == 0:
+                    self.s01_d1[0].copy_(d1[0:3, :self.h, :self.w], non_blocking=True)
+                    self.s01_d1[1].copy_(d1[3:6, :self.h, :self.w], non_blocking=True)
+        self._window(load, emit, emit_ctx=with_d1)
         self._end(cur)
+        if with_d1:
+            return self.out, self.s01, self.out_d1, self.s01_d1
         return self.out, self.s01
 
     def run_windows(self, xs, out=None, s01=None):

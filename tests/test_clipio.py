@@ -93,3 +93,113 @@ def test_eval_table_per_index_per_scene():
     assert abs(s['per_index'][0][0] - 35.75) < 1e-12 and abs(s['per_index'][2][1] - 0.92) < 1e-12
     assert s['samples'] == 15 and abs(s['total'][0] - np.mean([30 + j + w for w in range(2) for j in range(3)] +
                                                              [40 + j + w for w in range(3) for j in range(3)])) < 1e-12
+
+
+def test_deblurred_frames_are_written_once_like_the_sequential_reference_loop():
+    """main.py:1165-1172 writes S0 under B0's name and S1 under B1's name for every window, in window order: window k+1's S0
+    lands on window k's S1 file.  What survives = what deblurred_writes says, so no file has two writers."""
+    from demfi_amd.clip import deblurred_writes
+    for n_frames in (4, 5, 9):
+        wins = window_list(n_frames)
+        survivor = {}
+        for k, (b0, b1, _, _) in enumerate(wins):          # the reference's sequential loop
+            survivor[b0] = ('S0', k)
+            survivor[b1] = ('S1', k)
+        ours = {}
+        for k, (b0, b1, _, _) in enumerate(wins):
+            w0, w1 = deblurred_writes(k, len(wins))
+            if w0:
+                assert b0 not in ours
+                ours[b0] = ('S0', k)
+            if w1:
+                assert b1 not in ours
+                ours[b1] = ('S1', k)
+        assert ours == survivor
+    # every rank decides from the GLOBAL window index: shards never write the same file
+    from demfi_amd.dist import shard_windows
+    n = 7
+    files = []
+    for rank in range(3):
+        lo, hi = shard_windows(n, 3, rank)
+        for k in range(lo, hi):
+            w0, w1 = deblurred_writes(k, n)
+            files += [k + 1] * int(w0) + [k + 2] * int(w1)
+    assert sorted(files) == list(range(1, n + 2))
+
+
+def test_gt_names_follow_make_2D_dataset_Test():
+    """utils.py:446-455: sharp name = zfill(int(number of B0 + (t_step_size / multiple) * (mul + 1)))."""
+    from demfi_amd.clip import gt_names
+    names = ['/d/test_blur/s/%05d.png' % i for i in (9, 17, 25, 33, 41)]
+    g = gt_names(names, 8, 8)
+    assert len(g) == 2
+    assert g[0][0] == ['%05d.png' % i for i in range(18, 25)] and g[0][1] == '00017.png' and g[0][2] == '00025.png'
+    assert g[1][0][0] == '00026.png' and g[1][0][-1] == '00032.png'
+    g2 = gt_names(['/x/%06d.png' % i for i in (1, 9, 17, 25)], 2, 8)      # x2: the centre frame only
+    assert g2 == [(['000013.png'], '000009.png', '000017.png')]
+
+
+def test_eval_table_reduction_vector_is_rank_consistent():
+    """Ranks own different windows / scenes: the reduction vector must have the same layout everywhere (round 2 sorted each
+    rank's OWN keys).  Simulated all-reduce = element-wise sum of the two ranks' vectors."""
+    scenes = ['a', 'b', 'c']
+    t0, t1, ref = EvalTable(4), EvalTable(4), EvalTable(4)
+    for (tab, scene, j, p) in ((t0, 'a', 0, 30.0), (t0, 'a', 1, 31.0), (t1, 'a', 0, 32.0), (t1, 'c', 2, 40.0), (t1, 'c', 4, 20.0), (t0, 'b', 3, 25.0)):
+        tab.update(scene, j, p, p / 100)
+        ref.update(scene, j, p, p / 100)
+    v0, v1 = t0.merge_vector(scenes), t1.merge_vector(scenes)
+    assert len(v0) == len(v1) == 3 * len(scenes) * (3 + 2)
+    t0.merge_from(scenes, [a + b for a, b in zip(v0, v1)])
+    assert t0.acc == ref.acc and t0.summary() == ref.summary()
+    assert t0.summary()['deblur']['S1'][0] == 20.0
+    with pytest.raises(ValueError):
+        t1.merge_vector(['a'])                                  # a scene this rank updated is missing from the common list
+
+
+def test_streamed_decoder_is_bounded_and_in_order(tmp_path):
+    from demfi_amd.clip import _StreamedFrames
+    rng = np.random.default_rng(1)
+    n = 30
+    names = []
+    for i in range(n):
+        names.append(str(tmp_path / ('%05d_12x16.bgr' % i)))
+        clipio.write_frame(names[-1], rng.integers(0, 256, (12, 16, 3), dtype=np.uint8))
+    pool = clipio.FramePool(3)
+    sf = _StreamedFrames(names, range(n), pool, ahead=5)
+    for k, win in enumerate(window_list(n)):                    # the runner asks for a window's frames in (B0,B1,B-1,B2) order
+        for i in win:
+            if i >= k + 2 or k == 0:                            # each frame once, when its first window is uploaded
+                f = sf[i]
+                assert np.array_equal(f.numpy(), clipio.read_frame(names[i]))
+    assert sf.peak <= 5 + 4 + 2 and sf.pos == n                 # O(ahead) frames alive, never the whole clip
+    pool.close()
+
+
+def test_frame_pool_write_queue_is_bounded(tmp_path):
+    pool = clipio.FramePool(2, max_pending=3)
+    img = np.zeros((64, 64, 3), np.uint8)
+    for i in range(20):
+        pool.submit_write(str(tmp_path / ('%03d.png' % i)), img)
+        assert len(pool._pending) <= 3
+    pool.wait()
+    assert len(os.listdir(tmp_path)) == 20
+    pool.close()
+
+
+def test_png_codec_rejects_crafted_headers():
+    """ADVICE r2: IHDR is untrusted -- huge dimensions must come back as an error, not as std::terminate."""
+    import ctypes as C
+    import struct
+    from demfi_amd import _lib as L
+    lib = L.load()
+    data = bytearray(clipio.png_encode(np.zeros((4, 4, 3), np.uint8)))
+    for wv, hv in ((0x7fffffff, 0x7fffffff), (0, 4), (4, 0), (40000, 4), (20000, 20000)):
+        bad = bytearray(data)
+        bad[16:20] = struct.pack('>I', wv)
+        bad[20:24] = struct.pack('>I', hv)
+        buf = np.frombuffer(bytes(bad), np.uint8)
+        h, w = C.c_int(0), C.c_int(0)
+        assert lib.demfi_png_info(buf.ctypes.data, buf.size, C.byref(h), C.byref(w)) < 0
+        with pytest.raises(RuntimeError):
+            clipio.png_decode(bytes(bad))
+    assert lib.demfi_png_encode_bound(0x7fffffff, 0x7fffffff) == 0

@@ -146,3 +146,45 @@ def test_two_process_gloo_state_dict_broadcast_and_sharded_clip():
     for k, w in enumerate(window_list(6)):
         sim.forward(th.stack([frames[i] for i in w], 1)[None], 0.5, 1)
         assert abs(float(eng.finals[0, 2].double().sum()) - r0[4][k]) < 2e-3       # MKLDNN sums differ with the thread count
+
+
+def _table_worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from demfi_amd import dist as DD
+    from demfi_amd.clip import EvalTable
+    assert DD.init(world, rank, 0, backend='gloo')
+    scenes = ['s0', 's1', 's2']                                  # the common scene list; ranks own different windows / scenes
+    t = EvalTable(4)
+    if rank == 0:
+        t.update('s0', 0, 30.0, 0.90)
+        t.update('s0', 1, 31.0, 0.91)
+    else:
+        t.update('s0', 0, 32.0, 0.92)
+        t.update('s2', 2, 40.0, 0.95)
+        t.update('s2', 3, 25.0, 0.80)                            # a deblur column
+    t.all_reduce(scenes, 'cpu')
+    q.put((rank, t.summary()))
+    DD.finalize()
+
+
+def test_two_process_gloo_eval_table_all_reduce():
+    """ranks hold different key sets; the reduced table must be the same, complete table on every rank."""
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_table_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    s0, s1 = res[0][1], res[1][1]
+    assert s0['samples'] == s1['samples'] == 4
+    assert s0['per_index'][0] == s1['per_index'][0] == (31.0, 0.91)        # scene s0: mean(30, 32); only scene with column 0
+    assert s0['per_index'][2] == (40.0, 0.95) and s0['deblur']['S0'] == s1['deblur']['S0'] == (25.0, 0.80)
+    assert abs(s0['total'][0] - (30 + 31 + 32 + 40) / 4) < 1e-12

@@ -67,7 +67,8 @@ def test_folder_run_png_in_png_out_and_sharding(model16, tmp_path):
     cr = ClipRunner(model16, h, w, n_tst=N, mfi=M, batch=2)
     out1 = str(tmp_path / 'out1')
     nwin, nfr = cr.run_folder(str(scene), out1)
-    assert nwin == 4 and nfr == 4 * (M - 1 + 2)
+    assert nwin == 4 and nfr == 4 * (M - 1) + 4 + 1            # St of every window, S0 of every window, S1 of the last one only
+    assert cr.last_decode_peak <= 2 * 2 + 3 + 4 + 2            # streamed decode: O(ahead) frames alive, not the clip
     exp_files = set()
     for st_names, s0, s1 in output_names(names, M):
         exp_files.update(st_names + [s0, s1])
@@ -75,9 +76,14 @@ def test_folder_run_png_in_png_out_and_sharding(model16, tmp_path):
     # frames written == frames the runner returns for the same windows
     got = {}
     cr.run_frames(frames, lambda k, st, s01: got.__setitem__(k, (st.numpy().copy(), s01.numpy().copy())))
-    for k, (st_names, s0, s1) in enumerate(output_names(names, M)):
+    onames = output_names(names, M)
+    for k, (st_names, s0, s1) in enumerate(onames):
         for j, nm in enumerate(st_names):
             assert np.array_equal(clipio.read_frame(os.path.join(out1, nm)), got[k][0][j])
+        # deblurred frames: the file named after B0 holds THIS window's S0 (what the reference's sequential loop leaves), the
+        # clip's last B1 file the last window's S1 -- deterministic, one writer per file
+        assert np.array_equal(clipio.read_frame(os.path.join(out1, s0)), got[k][1][0])
+    assert np.array_equal(clipio.read_frame(os.path.join(out1, onames[-1][2])), got[len(onames) - 1][1][1])
     # two ranks (run one after the other on this GPU): disjoint windows, same files in the end
     out2 = str(tmp_path / 'out2')
     tot = 0
@@ -86,9 +92,8 @@ def test_folder_run_png_in_png_out_and_sharding(model16, tmp_path):
         nw, _ = crr.run_folder(str(scene), out2)
         tot += nw
     assert tot == 4 and set(os.listdir(out2)) == exp_files
-    for nm in exp_files:
-        if '_' in nm:                                                   # St frames: written exactly once
-            assert np.array_equal(clipio.read_frame(os.path.join(out2, nm)), clipio.read_frame(os.path.join(out1, nm)))
+    for nm in exp_files:                                                # every file (St AND deblurred) has exactly one writer
+        assert np.array_equal(clipio.read_frame(os.path.join(out2, nm)), clipio.read_frame(os.path.join(out1, nm)))
 
 
 def test_gpu_psnr_ssim_match_reference_fixture_and_oracle(golden_dir):
@@ -124,3 +129,60 @@ def test_gpu_eval_on_uint8_targets_full_size():
     p, s = FrameEvaluator(h, w, DEV)(pred, gt)
     po, so = O.eval_frame(pred.cpu().numpy(), gt.cpu().numpy())
     assert abs(p - po) < 1e-9 and abs(s - so) < 1e-9
+
+
+def test_evaluate_scene_against_ground_truth_matches_oracle_metrics(model16, tmp_path):
+    """ClipRunner.evaluate = the metric half of test() (main.py:756-838): blur folder + sharp folder in the layout of
+    make_2D_dataset_Test, D1 and D2 frames of every (window, t) against the GT, averaged per time index.  Checked against the
+    oracle's eval_frame on the frames the runner delivers, on a 3-window clip; two ranks reduce to the same table."""
+    from demfi_amd.clip import EvalTable, gt_names
+    from demfi_amd.runner import WindowRunner
+    h, w, N, M, step = 40, 72, 2, 4, 8
+    blur, sharp = tmp_path / 'test_blur' / 's0', tmp_path / 'test' / 's0'
+    blur.mkdir(parents=True)
+    sharp.mkdir(parents=True)
+    nums = [1 + step * i for i in range(6)]                              # 6 blurry frames -> 3 windows
+    bframes = _clip(h, w, 6, 5)
+    names = []
+    for n, f in zip(nums, bframes):
+        names.append(str(blur / ('%05d.png' % n)))
+        clipio.write_frame(names[-1], f)
+    sframes = _clip(h, w, nums[-1] + 1, 6)
+    for n in range(nums[-1] + 1):
+        clipio.write_frame(str(sharp / ('%05d.png' % n)), sframes[n])
+    cr = ClipRunner(model16, h, w, n_tst=N, mfi=M, batch=2)
+    tabs, nwin = cr.evaluate(str(blur), str(sharp), t_step_size=step)
+    assert nwin == 3
+    # reference: the same windows through the runner, metrics by the oracle (numpy fp64 restatement of utils.py:652-705)
+    runner = WindowRunner(model16, h, w, n_tst=N, mfi=M)
+    exp = {'D1': EvalTable(M), 'D2': EvalTable(M)}
+    gts = gt_names(names, M, step)
+    to_t = lambda f: u8_frame_to_tensor(torch.from_numpy(f).to(DEV))
+    for k, win in enumerate(window_list(6)):
+        x = torch.stack([to_t(bframes[i]) for i in win], 1).unsqueeze(0)
+        st, s01, st1, s011 = [t.cpu().numpy().copy() for t in runner.run_window(x, with_d1=True)]
+        for j in range(M - 1):
+            g = to_t(clipio.read_frame(str(sharp / gts[k][0][j]))).cpu().numpy()
+            exp['D1'].update('s0', j, *O.eval_frame(st1[j], g))
+            exp['D2'].update('s0', j, *O.eval_frame(st[j], g))
+        for i in range(2):
+            g = to_t(clipio.read_frame(str(sharp / gts[k][1 + i]))).cpu().numpy()
+            exp['D1'].update('s0', M - 1 + i, *O.eval_frame(s011[i], g))
+            exp['D2'].update('s0', M - 1 + i, *O.eval_frame(s01[i], g))
+    for key in ('D1', 'D2'):
+        a, b = tabs[key].summary(), exp[key].summary()
+        assert a['samples'] == b['samples'] == 3 * (M - 1)
+        assert np.allclose(a['per_index'], b['per_index'], rtol=0, atol=1e-8) and np.allclose(a['total'], b['total'], rtol=0, atol=1e-8)
+        assert np.allclose([a['deblur']['S0'], a['deblur']['S1']], [b['deblur']['S0'], b['deblur']['S1']], rtol=0, atol=1e-8)
+    assert tabs['D2'].summary()['total'][0] != tabs['D1'].summary()['total'][0]      # the two stages are different frames
+    # two ranks (one after the other on this GPU) + the reduction vector = the single-rank table
+    merged = {'D1': None, 'D2': None}
+    for rank in range(2):
+        t2, _ = ClipRunner(model16, h, w, n_tst=N, mfi=M, batch=2, world=2, rank=rank).evaluate(str(blur), str(sharp), t_step_size=step)
+        for key in merged:
+            v = t2[key].merge_vector(['s0'])
+            merged[key] = v if merged[key] is None else [x + y for x, y in zip(merged[key], v)]
+    for key in merged:
+        t = EvalTable(M)
+        t.merge_from(['s0'], merged[key])
+        assert np.allclose(t.summary()['per_index'], tabs[key].summary()['per_index'], rtol=0, atol=1e-9)
