@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -I../../include -Wno-unused-result -Wno-pass-failed"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -I../../include -Wno-unused-result -Wno-pass-failed $DEMFI_EXTRA_FLAGS"
 SRCS_HIP="conv.hip pointwise.hip"
 SRCS_CPP="abi.cpp"
 [ -f metrics.hip ] && SRCS_HIP="$SRCS_HIP metrics.hip"
@@ -14,9 +14,13 @@ SRCS_CPP="abi.cpp"
 rm -f ./*.o libdemfi_hip.so
 pids=()
 objs=()
+# conv.hip: no SLP vectorisation -- the auto-packed v_pk_add_f32 of the epilogues need v_mov shuffles around the accumulator
+# registers (250 instead of 128 VALU in the 64->64 epilogue) and packed f32 VALU is slow beside MFMAs (MI355X_MICROARCH.md)
+CONV_FLAGS="-fno-slp-vectorize"
 for s in $SRCS_HIP; do
   o="${s%.hip}.o"; objs+=("$o")
-  $HIPCC $FLAGS -c "$s" -o "$o" & pids+=($!)
+  xf=""; [ "$s" = conv.hip ] && xf="$CONV_FLAGS"
+  $HIPCC $FLAGS $xf -c "$s" -o "$o" & pids+=($!)
 done
 for s in $SRCS_CPP; do
   o="${s%.cpp}.o"; objs+=("$o")
@@ -27,8 +31,16 @@ $HIPCC --offload-arch=gfx950 -shared -fPIC "${objs[@]}" -o libdemfi_hip.so -lz -
 echo "built $(pwd)/libdemfi_hip.so"
 # --ablation: second library with the ablation variants / experimental kernels (DEMFI_PERSIST_VARIANT, DEMFI_SEP_VARIANT,
 # DEMFI_CONV_Z, ...); use it with DEMFI_HIP_LIB=$(pwd)/libdemfi_hip_abl.so.  Never loaded by default.
+# --trace: third library whose persistent 64->64 kernels stamp s_memtime at their phase boundaries (tools/phase_trace.py)
+if [ "$1" = "--trace" ]; then
+  $HIPCC $FLAGS $CONV_FLAGS -DDEMFI_TRACE -c conv.hip -o conv_trace.o
+  trc=()
+  for o in "${objs[@]}"; do [ "$o" = conv.o ] && trc+=(conv_trace.o) || trc+=("$o"); done
+  $HIPCC --offload-arch=gfx950 -shared -fPIC "${trc[@]}" -o libdemfi_hip_trace.so -lz -lpthread
+  echo "built $(pwd)/libdemfi_hip_trace.so"
+fi
 if [ "$1" = "--ablation" ]; then
-  $HIPCC $FLAGS -DDEMFI_ABLATION -c conv.hip -o conv_abl.o
+  $HIPCC $FLAGS $CONV_FLAGS -DDEMFI_ABLATION -c conv.hip -o conv_abl.o
   abl=()
   for o in "${objs[@]}"; do [ "$o" = conv.o ] && abl+=(conv_abl.o) || abl+=("$o"); done
   $HIPCC --offload-arch=gfx950 -shared -fPIC "${abl[@]}" -o libdemfi_hip_abl.so -lz -lpthread

@@ -32,6 +32,21 @@ namespace {
 // phase at 0;  bit 2 (pair kernel): MFMA phase at priority 2, epilogue at 0.
 __device__ int g_knob = 0;
 
+// In-kernel phase trace (libdemfi_hip_trace.so, build.sh --trace; never in the product): s_memtime stamps of the first
+// TR_TILES tiles of workgroups 0..TR_WGS-1, [wg][wave][tile][stamp].  MFMA waves: 0 = arrived at barrier A, 1 = released,
+// 2 = MFMA phase done, 3 = epilogue issued.  DMA waves: 0 = tile landed (vmcnt 0), 1 = released, 2 = next tile issued.
+#ifdef DEMFI_TRACE
+constexpr int TR_WGS = 32, TR_WAVES = 10, TR_TILES = 24, TR_STAMPS = 6;
+__device__ unsigned long long g_trace[TR_WGS * TR_WAVES * TR_TILES * TR_STAMPS];
+#define TRACE_STAMP(wave_, k_, i_)                                                                                  \
+    do {                                                                                                              \
+        if (blockIdx.x < TR_WGS && (k_) < TR_TILES && (threadIdx.x & 63) == 0)                                      \
+            g_trace[((blockIdx.x * TR_WAVES + (wave_)) * TR_TILES + (k_)) * TR_STAMPS + (i_)] = __builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define TRACE_STAMP(wave_, k_, i_) do { } while (0)
+#endif
+
 constexpr int TH = 8;
 constexpr int TW = 32;
 constexpr int NT = 256;
@@ -44,6 +59,17 @@ template <> struct Mma<half_t> {
     {
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8_t, a), __builtin_bit_cast(h8_t, b),
                                                      acc, 0, 0, 0);
+    }
+    // first MFMA of an accumulator with an explicit C operand (the bias rows: saves the epilogue's bias adds)
+    static __device__ __forceinline__ void initc(f16x_t& acc, const uint4& a, const uint4& b, const f16x_t& c)
+    {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8_t, a), __builtin_bit_cast(h8_t, b), c, 0, 0, 0);
+    }
+    // first MFMA of an accumulator: C = inline constant 0 instead of 16 v_mov per accumulator before the loop
+    static __device__ __forceinline__ void init(f16x_t& acc, const uint4& a, const uint4& b)
+    {
+        const f16x_t z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8_t, a), __builtin_bit_cast(h8_t, b), z, 0, 0, 0);
     }
 };
 template <> struct Mma<float> {
@@ -457,11 +483,6 @@ constexpr int P_NT = NT + 64;                                   // 4 MFMA waves 
 // One k-step pair of fragments: 2 k-steps x (NCO A fragments + 2 B fragments)
 template <int NCO> struct FragSet { uint4 a[2][NCO]; uint4 b[2][2]; };
 
-// PIPE (NCO == 2 only; EXPERIMENT, instantiated only in -DDEMFI_ABLATION builds with DEMFI_PERSIST_VARIANT=6): the two
-// 32-cout subtiles are computed in two half-phases per tile and the register epilogue of one subtile is interleaved,
-// a few instructions at a time, between the MFMAs of the other.  Measured 0.30 ms vs 0.28 ms for the plain version (both with raw barriers; residual loads issued through inline asm with one manual vmcnt wait per half-phase)
-// (3x3 64->64, 736x1280, batch 3): halving the A-fragment reuse (3 ds_reads per 2 MFMAs) costs more than the hidden
-// epilogue gains.
 #ifndef DEMFI_P_NDMA
 #define DEMFI_P_NDMA 2
 #endif
@@ -469,7 +490,7 @@ template <int NCO> struct FragSet { uint4 a[2][NCO]; uint4 b[2][2]; };
 #define DEMFI_P_KYREUSE 1        // 0: one (tap, k-step pair) at a time, 12 ds_reads per 12 MFMAs (A/B builds)
 #endif
 constexpr int P_NDMA = DEMFI_P_NDMA;                            // waves issuing the tile DMA (instruction i -> wave i % P_NDMA)
-template <int NCO, int VAR, bool PIPE = false, bool RES = true>   // RES: the segment has a residual input (compile time: keeps the loads free of phis).  VAR: 0 = product; 1 no epilogue, 2 no MFMA phase, 3 no tile DMA, 4 epilogue only (ablation builds)
+template <int NCO, int VAR, bool RES = true>   // RES: the segment has a residual input (compile time: keeps the loads free of phis).  VAR: 0 = product; 1 no epilogue, 2 no MFMA phase, 3 no tile DMA, 4 epilogue only (ablation builds)
 __global__ __launch_bounds__(NT + 64 * P_NDMA, 1) void conv3x3_c64_persist_kernel(const demfi_conv* __restrict__ d)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -563,10 +584,15 @@ __global__ __launch_bounds__(NT + 64 * P_NDMA, 1) void conv3x3_c64_persist_kerne
                                              (__attribute__((address_space(3))) void*)(wlds + i * 1024), 16, 0, 0);
         issue_tile(t_first, 0);
         int buf = 0;
+        [[maybe_unused]] int trk = 0;
         for (int t = t_first; t < t_end; t += t_step, buf ^= 1) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tile t (and the weights) have landed in LDS
+            TRACE_STAMP(wave, trk, 0);
             __syncthreads();                                    // A: hand tile t to the MFMA waves
+            TRACE_STAMP(wave, trk, 1);
             if (VAR != 3 && VAR != 4 && VAR != 10 && t + t_step < t_end) issue_tile(t + t_step, buf ^ 1);   // streams in under the MFMAs
+            TRACE_STAMP(wave, trk, 2);
+            ++trk;
         }
         return;
     }
@@ -599,123 +625,12 @@ __global__ __launch_bounds__(NT + 64 * P_NDMA, 1) void conv3x3_c64_persist_kerne
         boff[g] = col * 128 + ((((g & 3) * 2 + hi) ^ ((col >> 1) & 7)) << 4);
     }
     const char* const wl = wlds + lane * 16;
-    if constexpr (PIPE && NCO == 2) {
-        f16x_t acc[2][2];
-        u4_t rr[2][2][2];                                       // residual of subtile s: [s][p][m2], loaded one half-phase early
-        int cb[2], cy[2], cx[2];                                // tile coordinates the accumulators of subtile s belong to
-        float v[8];                                             // values of the epilogue unit in flight
-        // one epilogue unit = (m2, p) of subtile S: 8 consecutive couts of pixel (row p, column lx); 5 chunks of ~6-10
-        // instructions each, issued one chunk per k-step between the MFMAs of the OTHER subtile
-        auto epi_chunk = [&](auto S_, auto STEP_) {
-            constexpr int S = decltype(S_)::value, STEP = decltype(STEP_)::value;
-            constexpr int unit = STEP / 5, chunk = STEP % 5, m2 = unit >> 1, p = unit & 1;
-            if constexpr (chunk == 0) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float qa = acc[S][p][(2 * m2) * 4 + j];
-                    float qb = acc[S][p][(2 * m2 + 1) * 4 + j];
-#if defined(__HIP_DEVICE_COMPILE__)
-                    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(qa), "+v"(qb));
-#endif
-                    v[j] = qa;
-                    v[4 + j] = qb;
-                }
-            } else if constexpr (chunk == 1) {
-                const f4_t b0 = *(const f4_t*)(bias_lds + S * 32 + m2 * 16 + hi * 8);
-                const f4_t b1 = *(const f4_t*)(bias_lds + S * 32 + m2 * 16 + hi * 8 + 4);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { v[j] += b0[j]; v[4 + j] += b1[j]; }
-            } else if constexpr (chunk == 2) {
-                if constexpr (RES) {
-                    // in flight at most: the 4 loads of the other subtile issued at the start of this half-phase; the "+v"
-                    // operands tie every consumer of rr[S] to this wait
-                    auto& rs = rr[S];
-                    if constexpr (unit == 0)
-                        asm volatile("s_waitcnt vmcnt(4)" : "+v"(rs[0][0]), "+v"(rs[0][1]), "+v"(rs[1][0]), "+v"(rs[1][1])::"memory");
-                    const h8_t r = __builtin_bit_cast(h8_t, rr[S][p][m2]);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] += (float)r[j];
-                }
-            } else if constexpr (chunk == 3) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], act_floor);
-            } else {
-                const int oy = cy[S] + wave * 2 + p, oxx = cx[S] + lx;
-                if (oy < H && oxx < W)
-                    store8<half_t>(dstp + cb[S] * d_sb + oy * d_sy + oxx * d_sx + ch0 + S * 32 + m2 * 16 + hi * 8, v);
-            }
-        };
-        // Residual loads are issued through inline asm: the compiler then inserts NO vmcnt waits of its own (its in-order
-        // bookkeeping would make an epilogue unit wait for the stores of the units before it); one manual
-        // s_waitcnt vmcnt(4) per half-phase retires them (the 4 loads of the next subtile may stay in flight).
-        auto load_res = [&](auto S_, int bimg, int oy0, int ox0) {
-            constexpr int S = decltype(S_)::value;
-            if constexpr (!RES) return;
-            auto& rs = rr[S];                                   // (an asm operand alone does not capture 'rr' in a generic lambda)
-#pragma unroll
-            for (int p = 0; p < 2; ++p) {
-#pragma unroll
-                for (int m2 = 0; m2 < 2; ++m2) {
-                    const int oy = min(oy0 + wave * 2 + p, H - 1), oxx = min(ox0 + lx, W - 1);
-                    const half_t* g = resp + bimg * r_sb + oy * r_sy + oxx * r_sx + ch0 + S * 32 + m2 * 16 + hi * 8;
-#if defined(__HIP_DEVICE_COMPILE__)
-                    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rs[p][m2]) : "v"(g) : "memory");
-#endif
-                }
-            }
-        };
-        struct Frag1 { uint4 a, b0, b1; };
-        // half-phase of subtile S on the tile in 'tb'; EPI: interleave the epilogue of the other subtile
-        auto half_phase = [&](auto S_, const char* tb, bool epi) {
-            constexpr int S = decltype(S_)::value;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) { acc[S][0][i] = 0.0f; acc[S][1][i] = 0.0f; }
-            auto load_step = [&](Frag1& f, int st) {                  // st = tap*4 + ks
-                const int tap = st >> 2, ks = st & 3;
-                const int ky = tap / 3, kx = tap % 3;
-                f.a = *(const uint4*)(wl + ((tap * NKS + ks) * 2 + S) * 1024);
-                const char* p0 = tb + boff[kx * 4 + ks];
-                f.b0 = *(const uint4*)(p0 + ky * (P_LW * 128));
-                f.b1 = *(const uint4*)(p0 + (ky + 1) * (P_LW * 128));
-            };
-            Frag1 f[3];                                                // fragments two k-steps ahead of the MFMAs
-            load_step(f[0], 0);
-            load_step(f[1], 1);
-            static_for<0, 36>([&](auto ST) {
-                constexpr int st = decltype(ST)::value;
-                if constexpr (st + 2 < 36) load_step(f[(st + 2) % 3], st + 2);
-                __builtin_amdgcn_sched_barrier(0);
-                Mma<half_t>::run(acc[S][0], f[st % 3].a, f[st % 3].b0);
-                Mma<half_t>::run(acc[S][1], f[st % 3].a, f[st % 3].b1);
-                if constexpr (st < 20) {
-                    if (epi) epi_chunk(std::integral_constant<int, 1 - S>{}, ST);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            });
-        };
-        int buf = 0;
-        bool have_prev = false;
-        for (int t = t_first; t < t_end; t += t_step, buf ^= 1) {
-            int bimg, oy0, ox0;
-            tile_coords(t, bimg, oy0, ox0);
-            asm volatile("s_barrier" ::: "memory");             // A: tile t is in LDS (raw: stores / residual loads stay in flight)
-            const char* tb = tbuf + buf * P_TILE_BYTES + (wave * 2) * (P_LW * 128);
-            load_res(std::integral_constant<int, 0>{}, bimg, oy0, ox0);
-            half_phase(std::integral_constant<int, 0>{}, tb, have_prev);          // + epilogue of subtile 1 of the previous tile
-            cb[0] = bimg; cy[0] = oy0; cx[0] = ox0;
-            load_res(std::integral_constant<int, 1>{}, bimg, oy0, ox0);
-            half_phase(std::integral_constant<int, 1>{}, tb, true);               // + epilogue of subtile 0 of this tile
-            cb[1] = bimg; cy[1] = oy0; cx[1] = ox0;
-            have_prev = true;
-        }
-        // drain: subtile 1 of the last tile
-        static_for<0, 20>([&](auto ST) { epi_chunk(std::integral_constant<int, 1>{}, ST); });
-        return;
-    }
     int buf = 0;
+    [[maybe_unused]] int trk = -1;
     for (int t = t_first; t < t_end; t += t_step, buf ^= 1) {
         int bimg, oy0, ox0;
         tile_coords(t, bimg, oy0, ox0);
+        ++trk;
         // Residual of this tile: issued before the MFMA phase, consumed in the epilogue.  The loads are unconditional
         // (clamped address, no per-lane branch) and barrier A is a RAW s_barrier: a lane-divergent load leaves register
         // copies behind and __syncthreads() carries a fence -- either one makes the compiler put s_waitcnt vmcnt(0)
@@ -735,7 +650,9 @@ __global__ __launch_bounds__(NT + 64 * P_NDMA, 1) void conv3x3_c64_persist_kerne
         }
         // A: tile t is in LDS (the DMA wave waited for it).  These waves wrote no LDS and consumed every ds_read of the
         // previous tile, so no counter has to drain here; "memory" keeps the compiler from moving LDS reads above it.
+        TRACE_STAMP(wave, trk, 0);
         asm volatile("s_barrier" ::: "memory");
+        TRACE_STAMP(wave, trk, 1);
         f16x_t acc[NCO][2];
 #pragma unroll
         for (int s = 0; s < NCO; ++s) {
@@ -769,7 +686,7 @@ __global__ __launch_bounds__(NT + 64 * P_NDMA, 1) void conv3x3_c64_persist_kerne
                     }
                 }
             };
-            if constexpr (VAR == 0 && !PIPE && DEMFI_P_KYREUSE != 0) {
+            if constexpr (VAR == 0 && DEMFI_P_KYREUSE != 0) {
                 // Input-row reuse across ky: for one (kx, k-step) the taps ky = 0..2 of output rows p = 0, 1 read input rows
                 // p + ky = 0..3 at the same column offset -- 4 distinct B fragments feed 6 (ky, p) combinations.  One group =
                 // 4 row fragments + 3*NCO weight fragments -> 6*NCO MFMAs: 10 ds_reads per 12 MFMAs instead of 12 (NCO = 2).
@@ -901,6 +818,11 @@ __global__ __launch_bounds__(NT + 64 * P_NDMA, 1) void conv3x3_c64_persist_kerne
             continue;
         }
         // ---- epilogue straight from the accumulators (the tile buffer is not reused: barrier B only orders the DMA) ----
+#if defined(DEMFI_TRACE) && defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+        for (int s = 0; s < NCO; ++s) { asm volatile("" ::"v"(acc[s][0])); asm volatile("" ::"v"(acc[s][1])); }
+        TRACE_STAMP(wave, trk, 2);
+#endif
         if constexpr (RES) {
             // Retire the residual loads HERE (they landed during the MFMA phase): otherwise the compiler's in-order
             // vmcnt bookkeeping makes the later units wait for this epilogue's own stores to be acknowledged.
@@ -942,47 +864,67 @@ __global__ __launch_bounds__(NT + 64 * P_NDMA, 1) void conv3x3_c64_persist_kerne
                 }
             }
         }
+        TRACE_STAMP(wave, trk, 3);
     }
 }
 
-template <int NCO, int VAR = 0, bool PIPE = false>
+template <int NCO, int VAR = 0>
 int launch_persist(const demfi_conv* h, const demfi_conv* dev, hipStream_t st)
 {
     const size_t lds = 9 * 4 * NCO * 1024 + 2 * P_TILE_BYTES + 1024;      // weights + 2 tiles + bias
-    DEMFI_LDS_ATTR((conv3x3_c64_persist_kernel<NCO, VAR, PIPE, true>));
-    DEMFI_LDS_ATTR((conv3x3_c64_persist_kernel<NCO, VAR, PIPE, false>));
+    DEMFI_LDS_ATTR((conv3x3_c64_persist_kernel<NCO, VAR, true>));
+    DEMFI_LDS_ATTR((conv3x3_c64_persist_kernel<NCO, VAR, false>));
     const int total = ((h->W + TW - 1) / TW) * ((h->H + TH - 1) / TH) * h->batch;
     const int grid = total >= 256 ? 256 : total;
     if (h->segs[h->sub_seg[0]].res.ptr != nullptr)
-        hipLaunchKernelGGL((conv3x3_c64_persist_kernel<NCO, VAR, PIPE, true>), dim3(grid), dim3(NT + 64 * P_NDMA), lds, st, dev);
+        hipLaunchKernelGGL((conv3x3_c64_persist_kernel<NCO, VAR, true>), dim3(grid), dim3(NT + 64 * P_NDMA), lds, st, dev);
     else
-        hipLaunchKernelGGL((conv3x3_c64_persist_kernel<NCO, VAR, PIPE, false>), dim3(grid), dim3(NT + 64 * P_NDMA), lds, st, dev);
+        hipLaunchKernelGGL((conv3x3_c64_persist_kernel<NCO, VAR, false>), dim3(grid), dim3(NT + 64 * P_NDMA), lds, st, dev);
     DEMFI_HIP_CHECK(hipGetLastError());
     return DEMFI_OK;
 }
 
 
 // ======================================================================================================
-// PAIR variant of the 64 -> 64 kernel: TWO MFMA waves per SIMD in complementary phases.
-// The 4-wave kernel above runs one MFMA wave per SIMD, so the phases of a tile ADD (MFMA 4 608 + LDS-read waits +
-// hand-over + epilogue VALU + stores = 10 700 cycles per tile, profiles/r02_notes.md).  Here the workgroup has eight
-// MFMA waves: wave w owns row pair (w & 3) of the tile -- as before -- but only ONE 32-cout subtile (w >> 2), so the two
-// waves of a SIMD share their input rows and split the couts.  The halves run SKEWED by half a period:
-//     half 0:  barrier(k)  MFMA(k)         epilogue(k)
-//     half 1:  barrier(k)  epilogue(k-1)   MFMA(k)
-// so on every SIMD one wave's epilogue (VALU + stores) runs under the other wave's MFMAs, and where both are in their
-// MFMA phase they fill each other's issue gaps (the matrix pipe is per SIMD and serves both).  Same LDS image, same
-// DMA waves, same weight blob (cout_perm) and the same one raw barrier per tile as the 4-wave kernel: tile k's buffer
-// is read in period k by both halves, the DMA of tile k+1 fills the other buffer during period k.
-// Price: a wave reuses a B (input) fragment for 32 couts only: 7 ds_read_b128 per 6 MFMAs instead of 10 per 12.
+// STAGED-STORE variant of the 64 -> 64 kernel (NCO == 2).
+// What the in-kernel phase trace says about the 4-wave kernel above (profiles/r03_phase_trace.md; cycles at the ~1.7 GHz the part
+// sustains under this load): a tile period of 7 700 cycles = MFMA phase 5 200 (144 MFMAs = 4 608 pipe cycles) + epilogue 2 200 +
+// barrier ~300, and the epilogue is the CU's store path: 32 KiB per tile at ~16 B/clk/CU (tools/microbench/store_path_per_cu.hip)
+// = 2 048 cycles during which the matrix pipe of all four SIMDs idles.  tools/microbench/overlap_matrix.hip says which waves may
+// share a SIMD: an OLDER k-loop-like MFMA wave is not slowed by a YOUNGER wave that issues global stores (687 vs 683 cycles per
+// 16 MFMAs, stores at full rate), while an older storing wave starves a younger MFMA wave completely -- so the roles are fixed by
+// age: MFMA waves 0-3 never touch global memory for their outputs; after the MFMA phase they apply bias / residual / ReLU in
+// registers, ds_write the packed fp16 tile into the tile buffer they have just finished reading (barrier B) and go on to the next
+// tile.  The four helper waves (4-7, one per SIMD, younger) read the staged tile back 8 lanes per pixel, issue the global stores
+// as whole 128-byte lines while the next tile is on the matrix cores, and then issue the LDS-DMA of tile k+2 into the same buffer
+// (helper w drains exactly the 1-KiB chunks its own DMA instructions overwrite, so nothing else has to be synchronised).
+// Round 2 built this once on the 2-DMA-wave kernel and measured nothing (profiles/r02_notes.md); the trace shows why: there the
+// helper path (stores, then 3 300 cycles of DMA issue starved by the MFMA waves, then the landing) was as long as the period.
 // ======================================================================================================
-#ifndef DEMFI_PAIR_NDMA
-#define DEMFI_PAIR_NDMA 2
+// (fp16 half of a packed pair) * 1.0 + c in one VALU op: the residual add of the epilogue
+__device__ __forceinline__ float res_mix_lo(unsigned a, float c)
+{
+    float d = 0.0f;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(a), "v"(c));
 #endif
-constexpr int PR_NDMA = DEMFI_PAIR_NDMA;
-constexpr int PR_NT = 8 * 64 + 64 * PR_NDMA;
-template <bool RES, bool SKEW>
-__global__ __launch_bounds__(PR_NT, 1) void conv3x3_c64_pair_kernel(const demfi_conv* __restrict__ d)
+    return d;
+}
+__device__ __forceinline__ float res_mix_hi(unsigned a, float c)
+{
+    float d = 0.0f;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(a), "v"(c));
+#endif
+    return d;
+}
+#ifndef DEMFI_STG_RES_AT
+#define DEMFI_STG_RES_AT 2                                       // k-loop third after which the residual loads are issued (-1: before barrier A)
+#endif
+constexpr int SG_NH = 4;                                         // helper waves
+constexpr int SG_NT = NT + 64 * SG_NH;
+template <bool RES>
+__global__ __launch_bounds__(SG_NT, 1) void conv3x3_c64_stg_kernel(const demfi_conv* __restrict__ d)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NTAPS = 9, NKS = 4, NCO = 2;
@@ -1019,225 +961,299 @@ __global__ __launch_bounds__(PR_NT, 1) void conv3x3_c64_pair_kernel(const demfi_
         oy0 = ty * TH;
         ox0 = (rem - ty * tiles_x) * TW;
     };
+    const demfi_seg& sg0 = d->segs[d->sub_seg[0]];
+    const int64_t d_sx = sg0.dst.sx, d_sy = sg0.dst.sy, d_sb = sg0.dst.sb;
+    [[maybe_unused]] int trk = 0;
 
-    if (wave >= 8) {
-        // ================= DMA waves (as in the 4-wave kernel) ================================================
-        if (g_knob & 1) __builtin_amdgcn_s_setprio(3);
-        const int dw = wave - 8;
+    if (wave >= 4) {
+        // ================= helper waves: tile DMA + the global stores of the staged outputs ==========================
+        if (g_knob & 1) __builtin_amdgcn_s_setprio(2);
+        const int dw = wave - 4;
+        constexpr int NIW = (P_NI + SG_NH - 1) / SG_NH;          // DMA instructions per helper (11; the last one may not exist)
         const demfi_piece& pc = d->pieces[0];
         const char* const src = (const char*)pc.v.ptr;
         const int64_t sx = pc.v.sx * 2, sy = pc.v.sy * 2, sb = pc.v.sb * 2;
         const char* const zeros = (const char*)d->zero_page;
-        int off[P_NI], lyx[P_NI];
+        unsigned off[NIW];                                       // unsigned: uniform base + zero-extended 32-bit lane offset = the saddr form (no VALU per instruction)
+        int lyx[NIW];
 #pragma unroll
-        for (int i = 0; i < P_NI; ++i) {
+        for (int k = 0; k < NIW; ++k) {
+            const int i = dw + SG_NH * k;
             const int px = i * 8 + (lane >> 3);
-            const int ly = px / P_LW;
-            const int lxx = px - ly * P_LW;
+            const int pxc = min(px, P_NP - 1);                   // lanes past the tile (last instruction only) re-read its last pixel: never consumed
+            const int ly = pxc / P_LW;
+            const int lxx = pxc - ly * P_LW;
             const int v = (lane & 7) ^ ((lxx >> 1) & 7);
-            off[i] = (int)(ly * sy + lxx * sx) + v * 16;
-            lyx[i] = px < P_NP ? (ly | (lxx << 8)) : 0xffff;
+            off[k] = (unsigned)((ly + 1) * sy + (lxx + 1) * sx) + v * 16;      // relative to pixel (-2,-2) of the tile: never negative
+            lyx[k] = (i < P_NI && px < P_NP) ? (ly | (lxx << 8)) : 0xffff;
         }
         auto issue_tile = [&](int t, int buf) {
             int bimg, oy0, ox0;
             tile_coords(t, bimg, oy0, ox0);
-            const char* base = src + (int64_t)bimg * sb + (int64_t)(oy0 - 1) * sy + (int64_t)(ox0 - 1) * sx;
+            const char* base = src + (int64_t)bimg * sb + (int64_t)(oy0 - 2) * sy + (int64_t)(ox0 - 2) * sx;
             char* dst = tbuf + buf * P_TILE_BYTES;
             const bool interior = oy0 >= 1 && oy0 + TH + 1 <= H && ox0 >= 1 && ox0 + TW + 1 <= W;
-            if (interior) {
+            if (interior) {                                      // uniform base + precomputed 32-bit lane offset: ~2 VALU per instruction
 #pragma unroll
-                for (int i = 0; i < P_NI; ++i) {
-                    if ((i % PR_NDMA) != dw) continue;
-                    const char* g = (i == P_NI - 1 && lyx[i] == 0xffff) ? zeros : base + off[i];
+                for (int k = 0; k < NIW; ++k) {
+                    const int i = dw + SG_NH * k;
+                    if (i >= P_NI) continue;                     // wave-uniform
+                    const char* g = base + off[k];
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                                      (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
                 }
             } else {
 #pragma unroll
-                for (int i = 0; i < P_NI; ++i) {
-                    if ((i % PR_NDMA) != dw) continue;
-                    const int iy = oy0 - 1 + (lyx[i] & 255), ix = ox0 - 1 + (lyx[i] >> 8);
-                    const char* g = (lyx[i] != 0xffff && iy >= 0 && iy < H && ix >= 0 && ix < W) ? base + off[i] : zeros;
+                for (int k = 0; k < NIW; ++k) {
+                    const int i = dw + SG_NH * k;
+                    if (i >= P_NI) continue;
+                    const int iy = oy0 - 1 + (lyx[k] & 255), ix = ox0 - 1 + (lyx[k] >> 8);
+                    const char* g = (lyx[k] != 0xffff && iy >= 0 && iy < H && ix >= 0 && ix < W) ? base + off[k] : zeros;
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                                      (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
                 }
             }
         };
+        half_t* const dstp = (half_t*)sg0.dst.ptr + d->oct_ch[0];
+        constexpr int NCH = 32 / SG_NH;                          // 1-KiB chunks (8 pixels x 128 B) of the 32-KiB staging per helper
+        u4_t stage[NCH];
+        auto stage_read = [&](int b) {
+            const char* sbp = tbuf + b * P_TILE_BYTES + lane * 16;
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) stage[k] = *(const u4_t*)(sbp + (dw + SG_NH * k) * 1024);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // in registers before this wave's DMA may overwrite the chunks
+        };
+        // byte offset of this lane's 16-byte piece of chunk k relative to the tile's first output pixel (loop-invariant)
+        unsigned doff[NCH];
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const int j = dw + SG_NH * k;                        // chunk j: pixels 8j .. 8j+7 of the 8x32 tile; lane -> (pixel, physical slot)
+            const int oxl = (j & 3) * 8 + (lane >> 3);
+            const int q = (lane & 7) ^ ((oxl >> 1) & 7);         // logical 16-byte slot = channels 8q .. 8q+7
+            doff[k] = (unsigned)(((j >> 2) * d_sy + oxl * d_sx + q * 8) * 2);
+        }
+        auto stage_store = [&](int bimg, int oy0, int ox0) {
+            char* const obase = (char*)(dstp + bimg * d_sb + oy0 * d_sy + ox0 * d_sx);      // wave-uniform
+            if (oy0 + TH <= H && ox0 + TW <= W) {
+#pragma unroll
+                for (int k = 0; k < NCH; ++k) *gp<u4_t>(obase + doff[k]) = stage[k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < NCH; ++k) {
+                    const int j = dw + SG_NH * k;
+                    if (oy0 + (j >> 2) < H && ox0 + (j & 3) * 8 + (lane >> 3) < W) *gp<u4_t>(obase + doff[k]) = stage[k];
+                }
+            }
+        };
         const uint4* wsrc = (const uint4*)d->wpack;
-        for (int i = dw; i < NTAPS * NKS * NCO; i += PR_NDMA)
+        for (int i = dw; i < NTAPS * NKS * NCO; i += SG_NH)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + i * 64 + lane),
                                              (__attribute__((address_space(3))) void*)(wlds + i * 1024), 16, 0, 0);
         issue_tile(t_first, 0);
         int buf = 0;
+        int pb = 0, py = 0, px = 0;
+        bool have_prev = false;
         for (int t = t_first; t < t_end; t += t_step, buf ^= 1) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // tile t has landed (and this wave's stores of tile t-2 are out)
+            TRACE_STAMP(wave, trk, 0);
+            asm volatile("s_barrier" ::: "memory");             // A: tile t to the MFMA waves; their outputs of tile t-1 are staged in buffer buf^1
+            TRACE_STAMP(wave, trk, 1);
+            // stores first: the vmcnt(0) in front of the next barrier A then waits for the tile loads issued LAST, not for the
+            // acknowledgements of stores issued late in the phase
+            if (have_prev) { stage_read(buf ^ 1); stage_store(pb, py, px); }
             if (t + t_step < t_end) issue_tile(t + t_step, buf ^ 1);
+            TRACE_STAMP(wave, trk, 2);
+            tile_coords(t, pb, py, px);
+            have_prev = true;
+            asm volatile("s_barrier" ::: "memory");             // B: the MFMA waves have finished reading buffer buf and may stage into it
+            ++trk;
         }
+        asm volatile("s_barrier" ::: "memory");                 // F: the last tile is staged (in buffer buf^1: buf was toggled on exit)
+        stage_read(buf ^ 1);
+        stage_store(pb, py, px);
         return;
     }
 
-    // ================= MFMA waves: row pair wr, cout half ch ==================================================
-    const int ch = wave >> 2, wr = wave & 3;
+    // ================= MFMA waves ============================================================================
     const int hi = lane >> 5;
     const int lx = lane & 31;
-    const demfi_seg& sg0 = d->segs[d->sub_seg[0]];
-    half_t* const dstp = (half_t*)sg0.dst.ptr;
     const half_t* const resp = (const half_t*)sg0.res.ptr;
-    const int64_t d_sx = sg0.dst.sx, d_sy = sg0.dst.sy, d_sb = sg0.dst.sb;
     const int64_t r_sx = sg0.res.sx, r_sy = sg0.res.sy, r_sb = sg0.res.sb;
     const float act_floor = sg0.act == DEMFI_ACT_RELU ? 0.0f : -__builtin_huge_valf();
     h8_t act_floor8;
 #pragma unroll
     for (int j = 0; j < 8; ++j) act_floor8[j] = (half_t)act_floor;
-    const int ch0 = d->oct_ch[0] + ch * 32;                     // first output channel of this wave's subtile
-    float* const bias_lds = (float*)(tbuf + 2 * P_TILE_BYTES);
-    if (tid < NCO * 32) bias_lds[tid] = d->bias[tid];
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int ch0 = d->oct_ch[0];
+    // bias of this lane's 32 accumulator rows (MFMA-row order: element 4g + j = quad g, half hi, j), in registers for the whole
+    // launch and fed to the FIRST MFMA of every accumulator as its C operand: the accumulation starts at the bias, so the
+    // epilogue has no bias adds at all (the 4-wave kernel re-reads the bias from LDS per epilogue unit: 8 dependent LDS round
+    // trips, ~700 cycles per tile in the phase trace).  fp32 summation order differs from "sum, then + bias" by one rounding.
+    f16x_t bias16[NCO];
+#pragma unroll
+    for (int s = 0; s < NCO; ++s) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f4_t bq = *gcp<f4_t>(d->bias + s * 32 + g * 8 + hi * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bias16[s][g * 4 + j] = bq[j];
+        }
+    }
     int boff[12];
 #pragma unroll
     for (int g = 0; g < 12; ++g) {
         const int col = lx + (g >> 2);
         boff[g] = col * 128 + ((((g & 3) * 2 + hi) ^ ((col >> 1) & 7)) << 4);
     }
-    const char* const wl = wlds + ch * 1024 + lane * 16;        // fragment (tap, ks, subtile ch)
-    const float* const bias_w = bias_lds + ch * 32;
-
-    struct RowFrag1 { uint4 a[3]; uint4 b[4]; };
-    const int knob = g_knob;
-    auto mfma_phase = [&](const char* tb, f16x_t (&acc)[2]) {
-        if (knob & 2) __builtin_amdgcn_s_setprio(0);
-        if (knob & 4) __builtin_amdgcn_s_setprio(2);
+    const char* const wl = wlds + lane * 16;
+    // staging slot of this lane's (s, m2) piece: pixel record (row, lx) of a 32-pixel-per-row image, 16-byte slot
+    // q = 4s + 2m2 + hi XOR-swizzled by the column like the input tiles (conflict-free ds_write_b128 groups)
+    int soff[NCO][2];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { acc[0][i] = 0.0f; acc[1][i] = 0.0f; }
-        auto load_g = [&](RowFrag1& f, int g) {                 // g = kx*4 + ks
-            const int kx = g >> 2, ks = g & 3;
+    for (int s = 0; s < NCO; ++s) {
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky) f.a[ky] = *(const uint4*)(wl + (((ky * 3 + kx) * NKS + ks) * NCO) * 1024);
-            const char* p0 = tb + boff[kx * 4 + ks];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) f.b[r] = *(const uint4*)(p0 + r * (P_LW * 128));
-        };
-        auto mma_g = [&](const RowFrag1& f) {
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
-                Mma<half_t>::run(acc[0], f.a[ky], f.b[ky]);
-                Mma<half_t>::run(acc[1], f.a[ky], f.b[ky + 1]);
-            }
-        };
-        auto groups = [&](bool loads) {                         // 6 MFMAs with the 7 ds_reads of the next group between them
-#pragma unroll
-            for (int q = 0; q < 6; ++q) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                if (loads) {
-                    if (q == 0) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                    else        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        RowFrag1 f0, f1;
-        load_g(f0, 0);
-        static_for<0, 6>([&](auto I) {
-            constexpr int i = decltype(I)::value;
-            load_g(f1, 2 * i + 1);
-            mma_g(f0);
-            groups(true);
-            if constexpr (i < 5) load_g(f0, 2 * i + 2);
-            mma_g(f1);
-            groups(i < 5);
-        });
-    };
-    auto load_res = [&](u4_t (&rreg)[2][2], int bimg, int oy0, int ox0) {
-        if constexpr (RES) {
-#pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                const int oy = min(oy0 + wr * 2 + p, H - 1), oxx = min(ox0 + lx, W - 1);
-                const half_t* rp = resp + bimg * r_sb + oy * r_sy + oxx * r_sx + ch0 + hi * 8;
-#pragma unroll
-                for (int m2 = 0; m2 < 2; ++m2) rreg[p][m2] = *gcp<u4_t>(rp + m2 * 16);
-            }
-        }
-    };
-    auto epilogue = [&](f16x_t (&acc)[2], u4_t (&rreg)[2][2], int bimg, int oy0, int ox0) {
-        if (knob & 2) __builtin_amdgcn_s_setprio(2);
-        if (knob & 4) __builtin_amdgcn_s_setprio(0);
-        if constexpr (RES) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(rreg[q >> 1][q & 1]));
-        }
-#pragma unroll
-        for (int m2 = 0; m2 < 2; ++m2) {
-            const f4_t b0 = *(const f4_t*)(bias_w + (2 * m2) * 8 + hi * 4);
-            const f4_t b1 = *(const f4_t*)(bias_w + (2 * m2 + 1) * 8 + hi * 4);
-#pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                float v[8];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    v[j] = acc[p][(2 * m2) * 4 + j] + b0[j];
-                    v[4 + j] = acc[p][(2 * m2 + 1) * 4 + j] + b1[j];
-                }
-                if constexpr (RES) {
-                    const h8_t r = __builtin_bit_cast(h8_t, rreg[p][m2]);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] += (float)r[j];
-                }
-                h8_t o;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] = (half_t)v[j];
-                o = __builtin_elementwise_max(o, act_floor8);
-                const int oy = oy0 + wr * 2 + p, oxx = ox0 + lx;
-                if (oy < H && oxx < W)
-                    *gp<u4_t>(dstp + bimg * d_sb + oy * d_sy + oxx * d_sx + ch0 + m2 * 16 + hi * 8) = __builtin_bit_cast(u4_t, o);
-            }
-        }
-    };
-
-    f16x_t acc[2];
-    u4_t rreg[2][2];
-    if (!SKEW || ch == 0) {
-        int buf = 0;
-        for (int t = t_first; t < t_end; t += t_step, buf ^= 1) {
-            int bimg, oy0, ox0;
-            tile_coords(t, bimg, oy0, ox0);
-            load_res(rreg, bimg, oy0, ox0);
-            asm volatile("s_barrier" ::: "memory");
-            mfma_phase(tbuf + buf * P_TILE_BYTES + (wr * 2) * (P_LW * 128), acc);
-            epilogue(acc, rreg, bimg, oy0, ox0);
-        }
-    } else {
-        int buf = 0;
-        int pb = 0, py = 0, px = 0;
-        bool have = false;
-        for (int t = t_first; t < t_end; t += t_step, buf ^= 1) {
-            int bimg, oy0, ox0;
-            tile_coords(t, bimg, oy0, ox0);
-            asm volatile("s_barrier" ::: "memory");
-            if (have) epilogue(acc, rreg, pb, py, px);          // tile k-1, under the other half's MFMAs of tile k
-            load_res(rreg, bimg, oy0, ox0);
-            mfma_phase(tbuf + buf * P_TILE_BYTES + (wr * 2) * (P_LW * 128), acc);
-            pb = bimg; py = oy0; px = ox0;
-            have = true;
-        }
-        epilogue(acc, rreg, pb, py, px);
+        for (int m2 = 0; m2 < 2; ++m2) soff[s][m2] = lx * 128 + (((s * 4 + m2 * 2 + hi) ^ ((lx >> 1) & 7)) << 4);
     }
+    int buf = 0;
+    for (int t = t_first; t < t_end; t += t_step, buf ^= 1) {
+        int bimg, oy0, ox0;
+        tile_coords(t, bimg, oy0, ox0);
+        // Residual of this tile: issued in the MIDDLE of the MFMA phase (after a third of the k-loop).  At the head of the period the
+        // CU's memory pipe belongs to the helper waves' stores of the previous tile and to the DMA of the next one; loads issued
+        // here still have ~3 000 cycles to land before the epilogue, and do not queue in front of those.
+        u4_t rreg[NCO][2][2];
+        auto load_res = [&]() {
+            if constexpr (RES) {
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    const int oy = min(oy0 + wave * 2 + p, H - 1), oxx = min(ox0 + lx, W - 1);
+                    const half_t* rp = resp + bimg * r_sb + oy * r_sy + oxx * r_sx + ch0 + hi * 8;
+#pragma unroll
+                    for (int s = 0; s < NCO; ++s) {
+#pragma unroll
+                        for (int m2 = 0; m2 < 2; ++m2) rreg[s][p][m2] = *gcp<u4_t>(rp + s * 32 + m2 * 16);
+                    }
+                }
+            }
+        };
+        if constexpr (DEMFI_STG_RES_AT < 0) load_res();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the staged outputs of the previous tile are in LDS
+        TRACE_STAMP(wave, trk, 0);
+        asm volatile("s_barrier" ::: "memory");                 // A
+        TRACE_STAMP(wave, trk, 1);
+        f16x_t acc[NCO][2];
+        char* const tbase = tbuf + buf * P_TILE_BYTES;
+        const char* tb = tbase + (wave * 2) * (P_LW * 128);
+        {
+            struct RowFrag { uint4 a[3][NCO]; uint4 b[4]; };
+            auto load_g = [&](RowFrag& f, int g) {              // g = kx*4 + ks
+                const int kx = g >> 2, ks = g & 3;
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+                    for (int s = 0; s < NCO; ++s) f.a[ky][s] = *(const uint4*)(wl + (((ky * 3 + kx) * NKS + ks) * NCO + s) * 1024);
+                }
+                const char* p0 = tb + boff[kx * 4 + ks];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) f.b[r] = *(const uint4*)(p0 + r * (P_LW * 128));
+            };
+            auto mma_g = [&](const RowFrag& f, auto FIRST) {
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+                    for (int s = 0; s < NCO; ++s) {
+                        if (decltype(FIRST)::value && ky == 0) {
+                            Mma<half_t>::initc(acc[s][0], f.a[ky][s], f.b[ky], bias16[s]);
+                            Mma<half_t>::initc(acc[s][1], f.a[ky][s], f.b[ky + 1], bias16[s]);
+                        } else {
+                            Mma<half_t>::run(acc[s][0], f.a[ky][s], f.b[ky]);
+                            Mma<half_t>::run(acc[s][1], f.a[ky][s], f.b[ky + 1]);
+                        }
+                    }
+                }
+            };
+            auto groups = [&](bool loads) {
+#pragma unroll
+                for (int q = 0; q < 6 * NCO; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (loads && q < 3 * NCO + 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            RowFrag f0, f1;
+            load_g(f0, 0);
+            static_for<0, 6>([&](auto I) {
+                constexpr int i = decltype(I)::value;
+                load_g(f1, 2 * i + 1);
+                mma_g(f0, std::integral_constant<bool, i == 0>{});
+                groups(true);
+                if constexpr (i == DEMFI_STG_RES_AT) load_res();
+                if constexpr (i < 5) load_g(f0, 2 * i + 2);
+                mma_g(f1, std::false_type{});
+                groups(i < 5);
+            });
+        }
+#if defined(DEMFI_TRACE) && defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+        for (int s = 0; s < NCO; ++s) { asm volatile("" ::"v"(acc[s][0])); asm volatile("" ::"v"(acc[s][1])); }
+        TRACE_STAMP(wave, trk, 2);
+#endif
+        // B: every MFMA wave has consumed its reads of this tile buffer -> its first 32 KiB become the staging image of the outputs
+        asm volatile("s_barrier" ::: "memory");
+        TRACE_STAMP(wave, trk, 4);
+        if constexpr (RES) {
+#pragma unroll
+            for (int s = 0; s < NCO; ++s) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(rreg[s][q >> 1][q & 1]));
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < NCO; ++s) {
+#pragma unroll
+            for (int m2 = 0; m2 < 2; ++m2) {
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        v[j] = acc[s][p][(2 * m2) * 4 + j];
+                        v[4 + j] = acc[s][p][(2 * m2 + 1) * 4 + j];
+                    }
+                    if constexpr (RES) {
+                        // + residual: v_fma_mix_f32 (fp16 operand * 1.0 + fp32) = the conversion and the add in one instruction, same rounding
+                        const u4_t r = rreg[s][p][m2];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            v[2 * q] = res_mix_lo(r[q], v[2 * q]);
+                            v[2 * q + 1] = res_mix_hi(r[q], v[2 * q + 1]);
+                        }
+                    }
+                    h8_t o;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] = (half_t)v[j];
+                    o = __builtin_elementwise_max(o, act_floor8);
+                    *(u4_t*)(tbase + (wave * 2 + p) * 4096 + soff[s][m2]) = __builtin_bit_cast(u4_t, o);
+                }
+            }
+        }
+        TRACE_STAMP(wave, trk, 3);
+        ++trk;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the last tile is staged
+    asm volatile("s_barrier" ::: "memory");                     // F
 }
 
-static int launch_pair(const demfi_conv* h, const demfi_conv* dev, hipStream_t st, bool skew)
+static int launch_stg(const demfi_conv* h, const demfi_conv* dev, hipStream_t st)
 {
     const size_t lds = 9 * 4 * 2 * 1024 + 2 * P_TILE_BYTES + 1024;
-    DEMFI_LDS_ATTR((conv3x3_c64_pair_kernel<true, true>));
-    DEMFI_LDS_ATTR((conv3x3_c64_pair_kernel<false, true>));
-    DEMFI_LDS_ATTR((conv3x3_c64_pair_kernel<true, false>));
-    DEMFI_LDS_ATTR((conv3x3_c64_pair_kernel<false, false>));
+    DEMFI_LDS_ATTR((conv3x3_c64_stg_kernel<true>));
+    DEMFI_LDS_ATTR((conv3x3_c64_stg_kernel<false>));
     const int total = ((h->W + TW - 1) / TW) * ((h->H + TH - 1) / TH) * h->batch;
     const int grid = total >= 256 ? 256 : total;
-    const bool res = h->segs[h->sub_seg[0]].res.ptr != nullptr;
-    if (res && skew)       hipLaunchKernelGGL((conv3x3_c64_pair_kernel<true, true>), dim3(grid), dim3(PR_NT), lds, st, dev);
-    else if (res)          hipLaunchKernelGGL((conv3x3_c64_pair_kernel<true, false>), dim3(grid), dim3(PR_NT), lds, st, dev);
-    else if (skew)         hipLaunchKernelGGL((conv3x3_c64_pair_kernel<false, true>), dim3(grid), dim3(PR_NT), lds, st, dev);
-    else                   hipLaunchKernelGGL((conv3x3_c64_pair_kernel<false, false>), dim3(grid), dim3(PR_NT), lds, st, dev);
+    if (h->segs[h->sub_seg[0]].res.ptr != nullptr)
+        hipLaunchKernelGGL((conv3x3_c64_stg_kernel<true>), dim3(grid), dim3(SG_NT), lds, st, dev);
+    else
+        hipLaunchKernelGGL((conv3x3_c64_stg_kernel<false>), dim3(grid), dim3(SG_NT), lds, st, dev);
     DEMFI_HIP_CHECK(hipGetLastError());
     return DEMFI_OK;
 }
@@ -2238,11 +2254,16 @@ extern "C" int demfi_conv2d(const demfi_conv* h, const demfi_conv* dev, void* st
             if (var == 13) return launch_regw<3>(h, dev, st);
             if (var == 14) return launch_regw<4>(h, dev, st);
             if (var == 10) return launch_regw(h, dev, st);
-            if (var == 6) return launch_persist<2, 0, true>(h, dev, st);
+            if (var == 6) return launch_pipe(h, dev, st);
+            // DEMFI_PAIR: 1 skewed pair kernel, 2 unskewed (round-3 experiments), 4 the round-2 product (stores from the MFMA waves)
+            static const int pair = getenv("DEMFI_PAIR") ? atoi(getenv("DEMFI_PAIR")) : 0;
+            if (pair == 1 || pair == 2) return launch_pair(h, dev, st, pair == 1);
+            if (pair == 4) return launch_persist<2>(h, dev, st);
 #endif
-            static const int pair = getenv("DEMFI_PAIR") ? atoi(getenv("DEMFI_PAIR")) : 0;    // A/B switch: 1 skewed pair kernel, 2 unskewed
-            if (pair) return launch_pair(h, dev, st, pair == 1);
-            return launch_persist<2>(h, dev, st);
+#ifdef DEMFI_TRACE
+            if (getenv("DEMFI_PAIR") && atoi(getenv("DEMFI_PAIR")) == 4) return launch_persist<2>(h, dev, st);   // phase trace of the 4-wave kernel
+#endif
+            return launch_stg(h, dev, st);
         }
         return launch_persist<1>(h, dev, st);
     }
@@ -2270,3 +2291,17 @@ general:
 #endif
     return h->dtype == DEMFI_F16 ? dispatch<half_t>(h, dev, st, (size_t)lds) : dispatch<float>(h, dev, st, (size_t)lds);
 }
+
+#ifdef DEMFI_TRACE
+// trace build only: copy the phase trace out (see TRACE_STAMP) and clear it
+extern "C" int demfi_trace_dump(unsigned long long* out, int64_t n)
+{
+    const int64_t have = (int64_t)TR_WGS * TR_WAVES * TR_TILES * TR_STAMPS;
+    if (!out || n < have) return demfi_set_error(DEMFI_ERR_ARG, "demfi_trace_dump: need room for %lld entries", (long long)have);
+    DEMFI_HIP_CHECK(hipDeviceSynchronize());
+    DEMFI_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trace), have * 8));
+    static unsigned long long zeros[TR_WGS * TR_WAVES * TR_TILES * TR_STAMPS];
+    DEMFI_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_trace), zeros, have * 8));
+    return (int)have;
+}
+#endif
