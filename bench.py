@@ -100,6 +100,48 @@ def synthetic_clip_u8(h, w, n_frames, seed):
     return out
 
 
+def png_side_figure(a, model, runner):
+    """Side figure (--with-png; NOT the headline, SURVEY.md section 8d excludes the codec): one scene folder of PNG frames ->
+    folder of PNG frames through ClipRunner.run_folder (streamed decode ahead of the GPU, bounded encode queue behind it), so that
+    the host side of an 8-GPU node is a number: frames/s of this GPU with the codec inside, host threads used, and the
+    single-core codec times that say how many cores a GPU needs to stay busy."""
+    import shutil
+    import tempfile
+    from demfi_amd import clipio
+    from demfi_amd.clip import ClipRunner
+    d = tempfile.mkdtemp(prefix='demfi_png_')
+    try:
+        scene = os.path.join(d, 'scene')
+        os.makedirs(scene)
+        clip = synthetic_clip_u8(a.height, a.width, 19, seed=77)           # 19 frames -> 16 windows
+        t0 = time.perf_counter()
+        for i, f in enumerate(clip):
+            clipio.write_frame(os.path.join(scene, '%05d.png' % i), f.numpy())
+        enc_ms = 1e3 * (time.perf_counter() - t0) / len(clip)
+        t0 = time.perf_counter()
+        for i in range(len(clip)):
+            clipio.read_frame(os.path.join(scene, '%05d.png' % i))
+        dec_ms = 1e3 * (time.perf_counter() - t0) / len(clip)
+        threads = int(os.environ.get('DEMFI_IO_THREADS', 0)) or min(32, os.cpu_count() or 4)
+        pool = clipio.FramePool(threads)
+        cr = ClipRunner(model, a.height, a.width, a.n_tst, a.mfi, batch=a.batch, final_only=False, n_ctx=runner.n_ctx, n_trunk=runner.n_trunk)
+        cr.run_folder(scene, os.path.join(d, 'warm'), pool=pool)
+        t0 = time.perf_counter()
+        nw, nf = cr.run_folder(scene, os.path.join(d, 'out'), pool=pool)
+        dt = time.perf_counter() - t0
+        pool.close()
+        fps = nw * (a.mfi - 1) / dt
+        per_st = (nf / float(nw * (a.mfi - 1)))                             # PNGs written per St frame (St + deblurred)
+        return {'value': round(fps, 2), 'unit': 'St frames/s, PNG folder -> PNG folder, 1 GPU', 'windows': nw, 'png_written': nf,
+                'png_read': len(clip), 'host_threads': threads, 'host_cores': os.cpu_count(),
+                'encode_ms_per_frame_one_core': round(enc_ms, 1), 'decode_ms_per_frame_one_core': round(dec_ms, 1),
+                'cores_to_feed_one_gpu_at_headline_rate': None,                 # filled by main() once the headline is known
+                'png_per_St_frame': round(per_st, 3),
+                'note': 'NOT the headline (the metric excludes the codec); zlib level 1 / Sub filter / Z_RLE = OpenCV defaults'}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def load_pmc_traffic():
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary (profiles/r02_pmc_traffic.json,
     written by tools/pmc_traffic.py on the GPU box: separate --pmc passes, 2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction)."""
@@ -219,18 +261,35 @@ def main():
         ach = g_fl / (g_ms * 1e-3) / 1e12
         pmc = load_pmc_traffic() if a.dtype == 'fp16' and (eng.H, eng.W) == (736, 1280) else None
         kname = runner.engine.dominant_kernel_name() if hasattr(runner.engine, 'dominant_kernel_name') else \
-            ('conv3x3_c64_persist_kernel<2>' if a.dtype == 'fp16' else 'conv_kernel<float,2>')
+            ('conv3x3_c64_stg_kernel' if a.dtype == 'fp16' else 'conv_kernel<float,2>')
+        # The kernel is co-bound: arithmetic intensity 288 (no residual) / 192 flop/B (residual) sits below the chip balance
+        # point of 312, so both ceilings are reported per variant.  Algorithmic bytes (every tensor once):
+        # input + output (+ residual) = 2 (3) x H x W x 64 ch x 2 B per image.
+        img_bytes = eng.H * eng.W * 64 * 2
+        variants = {}
+        for key, sel, ntens in (('no_residual', '.conv1', 2), ('residual', '.conv2', 3)):
+            g2 = [p for p in grp if p[2].endswith(sel)]
+            v_ms = sum(p[3] for p in g2) / len(g2)
+            v_fl = 2.0 * sum(p[4] for p in g2) / len(g2)
+            v_by = float(ntens * img_bytes * 3 * nb)
+            variants[key] = {'launches': len(g2), 'avg_launch_ms': round(v_ms, 4), 'TFLOPs': round(v_fl / v_ms / 1e9, 1),
+                             'frac_mfma': round(v_fl / v_ms / 1e9 / peak, 4), 'algorithmic_bytes': v_by,
+                             'GBs': round(v_by / v_ms / 1e6, 1), 'frac_hbm': round(v_by / v_ms / 1e6 / HBM_PEAK_GBS, 4)}
         out['roofline'] = {'kernel': '%s: D1 residual blocks, 3x3 64->64, batch 3 x %d time instants per launch (%d launches per %d frames)' % (kname, nb, len(grp), nb),
-                           'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak,
+                           'bound': 'mfma', 'co_bound': 'mfma+hbm', 'achieved': round(ach, 2), 'peak': peak,
                            'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
+                           'variants': variants,
                            # HBM bytes per launch from rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE, gfx950 correction), read from
-                           # the committed summary of the same code (profiles/r02_pmc_traffic.json)
-                           # (the PMC summary is per batch-3 image group: x nb for a launch of the batched plan)
+                           # the committed summary (profiles/r02_pmc_traffic.json; per batch-3 image group: x nb for a launch of the batched plan)
                            'traffic': (pmc.get('dominant_traffic_bytes_b21') if nb == 7 and pmc.get('dominant_traffic_bytes_b21')
                                        else pmc.get('dominant_traffic_bytes') * nb) if pmc else None,
                            'algorithmic_bytes': pmc.get('dominant_algorithmic_bytes') * nb if pmc else None,
                            'traffic_source': pmc.get('source') if pmc else None,
-                           'avg_launch_ms': round(g_ms, 4), 'flop_per_launch': g_fl, 'timing': 'mean of 5 launches per op, HIP events on the launch stream around each launch (agrees with the rocprofv3 in-sequence kernel durations in profiles/r02f_seq_trace_by_op.md; events BETWEEN consecutive launches of a whole pass read 5-8 us higher: launch gaps)',
+                           'avg_launch_ms': round(g_ms, 4), 'flop_per_launch': g_fl,
+                           'timing': 'IN SEQUENCE: mean over 5 passes of the whole launch plan, HIP events on the launch stream between consecutive '
+                                     'launches (includes the 5-8 us launch gap; reproduces the rocprofv3 in-sequence kernel durations of profiles/ within ~1 %)',
+                           'sustained_clock_note': 'in-kernel s_memtime trace (profiles/r03_notes.md): 1.7 GHz under this kernel, i.e. the dense-fp16 ceiling '
+                                                   'at the sustained clock is 2500 x 1.7 / 2.4 = 1771 TFLOP/s; frac is quoted against the 2.4 GHz peak',
                            'all_convs_TFLOPs': round(tot_conv_fl / (tot_conv_ms * 1e-3) / 1e12, 2),
                            'slowest_conv': '%s %.3f ms' % (dom[2], dom[3])}
         wb = [p for p in prof if p[1] == 'warp_fat']
@@ -269,6 +328,12 @@ def main():
                                         'note': 'NOT the headline: D2 of recursions 0..N-2 skipped (outputs-only work); delivered uint8 '
                                                 'frames bit-identical (tests/test_gpu_e2e.py::test_final_only_runner_delivers_the_same_frames)'}
             del fo
+        if a.with_png and world == 1:
+            pp = png_side_figure(a, model, runner)
+            # cores one GPU needs at the headline rate: (encode of the St + deblurred frames + decode of ~1 input frame per window) per second
+            pp['cores_to_feed_one_gpu_at_headline_rate'] = round(out['value'] * (pp['png_per_St_frame'] * pp['encode_ms_per_frame_one_core'] +
+                                                                                 pp['decode_ms_per_frame_one_core'] / (a.mfi - 1)) / 1e3, 1)
+            out['png_pipeline'] = pp
         if world == 1 and not a.no_cpu_baseline:
             out['cpu_baseline'], out['psnr'] = cpu_baseline(a.n_tst, eng.H * eng.W, model, dev)
         print(json.dumps(out))

@@ -76,7 +76,8 @@ class FramePool:
     one frame copy)."""
 
     def __init__(self, threads=None, max_pending=None):
-        self.threads = threads or min(32, os.cpu_count() or 4)
+        # DEMFI_IO_THREADS: this rank's share of the host cores (tools/run_node.sh sets it to nproc / ranks)
+        self.threads = threads or int(os.environ.get('DEMFI_IO_THREADS', 0)) or min(32, os.cpu_count() or 4)
         self.pool = ThreadPoolExecutor(max_workers=self.threads)
         self.max_pending = max_pending or 4 * self.threads
         self._pending = collections.deque()

@@ -1211,13 +1211,11 @@ extern "C" int demfi_ctx_create(int H, int W, int max_updates, int dtype, const 
     if (h.num_resb_facfb < 0 || h.num_resb_dec < 0 || h.num_resb_facfb > 32 || h.num_resb_dec > 32)
         return demfi_set_error(DEMFI_ERR_ARG, "demfi_ctx_create: residual block counts");
     // fgac_rr / fgac_sr: the radii hard-coded to 0 at DeMFInet.py:401-402; > 0 selects the generalised window FGAC
-    // (demfi_fgac_window, fp16 path only; h._pad = index map: 0 reference code, 1 pixel-centred window)
+    // (demfi_fgac_window, both path dtypes; h._pad = index map: 0 reference code, 1 pixel-centred window)
     if (h.fgac_rr < 0 || h.fgac_rr > 2 || h.fgac_sr < 0 || h.fgac_sr > 4 || (h._pad != 0 && h._pad != 1))
         return demfi_set_error(DEMFI_ERR_ARG, "demfi_ctx_create: fgac_rr in 0..2, fgac_sr in 0..4, map in {0,1}");
     if (h.fgac_rr == 0 && h.fgac_sr != 0)
         return demfi_set_error(DEMFI_ERR_ARG, "demfi_ctx_create: fgac_sr > 0 needs fgac_rr > 0 (the pooled point-wise form is not built)");
-    if (h.fgac_rr > 0 && dtype != DEMFI_F16)
-        return demfi_set_error(DEMFI_ERR_ARG, "demfi_ctx_create: the generalised FGAC kernel is built for the fp16 path");
     demfi_ctx* c = new demfi_ctx();
     c->H = H; c->W = W; c->N = max_updates; c->dtype = dtype; c->n_trunk = n_trunk; c->n_ctx = n_ctx; c->hp = h;
     layer_table(c);

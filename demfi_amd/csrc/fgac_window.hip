@@ -28,16 +28,52 @@ namespace {
 constexpr int FW_NT = 256;
 constexpr int FW_MAXR = 5;                       // rr <= 2
 
-__device__ __forceinline__ float group8_sum(float v)
+// sum over the LPP lanes of a pixel (8 for fp16, 16 for fp32: 16 bytes of channels per lane)
+template <int LPP>
+__device__ __forceinline__ float group_sum(float v)
 {
     v += __shfl_xor(v, 1, 64);
     v += __shfl_xor(v, 2, 64);
     v += __shfl_xor(v, 4, 64);
+    if constexpr (LPP == 16) v += __shfl_xor(v, 8, 64);
     return v;
 }
 
-__device__ __forceinline__ void bilerp8(const char* base, int64_t sx, int64_t sy, const SampleMap& m, int H, int W, float* o)
+// the N = 16 / sizeof(T) channels of a 16-byte slice as floats, and back
+template <typename T> struct Slice {
+    static constexpr int N = 16 / sizeof(T);
+    static __device__ __forceinline__ void unpack(const uint4& raw, float* o)
+    {
+        if constexpr (sizeof(T) == 2) {
+            const h8_t v = __builtin_bit_cast(h8_t, raw);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (float)v[j];
+        } else {
+            const f4_t v = __builtin_bit_cast(f4_t, raw);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = v[j];
+        }
+    }
+    static __device__ __forceinline__ uint4 pack(const float* o)
+    {
+        if constexpr (sizeof(T) == 2) {
+            h8_t v;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (half_t)o[j];
+            return __builtin_bit_cast(uint4, v);
+        } else {
+            f4_t v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = o[j];
+            return __builtin_bit_cast(uint4, v);
+        }
+    }
+};
+
+template <typename T>
+__device__ __forceinline__ void bilerp_slice(const char* base, int64_t sx, int64_t sy, const SampleMap& m, int H, int W, float* o)
 {
+    constexpr int N = Slice<T>::N;
     uint4 raw[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -45,39 +81,38 @@ __device__ __forceinline__ void bilerp8(const char* base, int64_t sx, int64_t sy
         raw[k] = ld_global16(base + (int64_t)yy * sy + (int64_t)xx * sx);
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = 0.0f;
+    for (int j = 0; j < N; ++j) o[j] = 0.0f;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const h8_t v = __builtin_bit_cast(h8_t, raw[k]);
+        float v[N];
+        Slice<T>::unpack(raw[k], v);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = o[j] + (float)v[j] * m.w[k];
+        for (int j = 0; j < N; ++j) o[j] = o[j] + v[j] * m.w[k];
     }
 }
 
-// fp16 NHWC views, C = 64.  R = 2 rr + 1 (template: the per-element values stay in registers).
-template <int R, int MODE>
+// NHWC views of the path dtype T (fp16, or fp32 for the strict-parity configuration), C = 64.  R = 2 rr + 1 (template: the
+// per-element values stay in registers).  LPP = 64 * sizeof(T) / 16 lanes per pixel, N = 16 / sizeof(T) channels per lane.
+template <typename T, int R, int MODE>
 __global__ __launch_bounds__(FW_NT) void fgac_window_kernel(demfi_view REF, demfi_view SRC, const float* __restrict__ flow,
                                                             demfi_view O, int H, int W, float* __restrict__ attn)
 {
     constexpr int E = R * R, rr = R / 2;
-    // mode 1: per-pixel texel window [(R+1)*(R+1)][64 ch] fp16 = 128 B per texel, 32 pixels per workgroup (dynamic LDS:
-    // 64 KiB for R = 3, 144 KiB for R = 5)
+    constexpr int N = Slice<T>::N, ESZ = sizeof(T), LPP = 64 * ESZ / 16, LSH = ESZ == 2 ? 3 : 4, TEX = 64 * ESZ;
+    // mode 1: per-pixel texel window [(R+1)*(R+1)][64 ch] = TEX bytes per texel, FW_NT / LPP pixels per workgroup (dynamic LDS:
+    // fp16 64 KiB for R = 3, 144 KiB for R = 5; fp32: the same -- half the pixels, twice the texel)
     extern __shared__ __attribute__((aligned(16))) char win[];
     const int64_t hw = (int64_t)H * W;
     const int64_t gi = (int64_t)blockIdx.x * FW_NT + threadIdx.x;
-    const int64_t pix = gi >> 3;
-    const int part = (int)(gi & 7);
+    const int64_t pix = gi >> LSH;
+    const int part = (int)(gi & (LPP - 1));
     const bool live = pix < hw;
     const int y = live ? (int)(pix / W) : 0, x = live ? (int)(pix - (int64_t)y * W) : 0;
     const char* rbase = (const char*)REF.ptr + part * 16;
-    const int64_t rsx = REF.sx * 2, rsy = REF.sy * 2;
-    float sk[8];
-    {
-        const h8_t v = __builtin_bit_cast(h8_t, ld_global16((const char*)SRC.ptr + ((int64_t)y * SRC.sy + (int64_t)x * SRC.sx) * 2 + part * 16));
-#pragma unroll
-        for (int j = 0; j < 8; ++j) sk[j] = (float)v[j];
-    }
-    float g[E][8];
+    const int64_t rsx = REF.sx * ESZ, rsy = REF.sy * ESZ;
+    float sk[N];
+    Slice<T>::unpack(ld_global16((const char*)SRC.ptr + ((int64_t)y * SRC.sy + (int64_t)x * SRC.sx) * ESZ + part * 16), sk);
+    float g[E][N];
     float corr[E];
     if constexpr (MODE == 1) {
         // ---- stage the (R+1)^2 texel window around the centroid: one 16-byte slice per lane and texel -----------
@@ -87,7 +122,7 @@ __global__ __launch_bounds__(FW_NT) void fgac_window_kernel(demfi_view REF, demf
         // every sample's own coordinate is recomputed below and the window is addressed relative to the floor of sample 0
         const float fx0 = floorf(ix), fy0 = floorf(iy);
         const int bx = (int)fminf(fmaxf(fx0, -8.0f), (float)W + 8.0f), by = (int)fminf(fmaxf(fy0, -8.0f), (float)H + 8.0f);
-        char* mywin = win + (threadIdx.x >> 3) * ((R + 1) * (R + 1) * 128) + part * 16;
+        char* mywin = win + (threadIdx.x >> LSH) * ((R + 1) * (R + 1) * TEX) + part * 16;
 #pragma unroll
         for (int ty = 0; ty <= R; ++ty)
 #pragma unroll
@@ -95,9 +130,9 @@ __global__ __launch_bounds__(FW_NT) void fgac_window_kernel(demfi_view REF, demf
                 const int yy = by + ty, xx = bx + tx;
                 uint4 v = make_uint4(0, 0, 0, 0);                            // zeros padding
                 if (live && yy >= 0 && yy < H && xx >= 0 && xx < W) v = ld_global16(rbase + (int64_t)yy * rsy + (int64_t)xx * rsx);
-                *(uint4*)(mywin + (ty * (R + 1) + tx) * 128) = v;
+                *(uint4*)(mywin + (ty * (R + 1) + tx) * TEX) = v;
             }
-        __builtin_amdgcn_wave_barrier();                                     // window rows are private to 8 lanes of one wave
+        __builtin_amdgcn_wave_barrier();                                     // window rows are private to the LPP lanes of a pixel (one wave)
 #pragma unroll
         for (int ki = 0; ki < R; ++ki)
 #pragma unroll
@@ -109,18 +144,20 @@ __global__ __launch_bounds__(FW_NT) void fgac_window_kernel(demfi_view REF, demf
                 // texel coordinates relative to the staged window; a sample whose floor falls outside it (possible only through
                 // the non-linear round trip at huge coordinates) contributes its in-window corners, the rest is zero = padding
 #pragma unroll
-                for (int j = 0; j < 8; ++j) g[e][j] = 0.0f;
+                for (int j = 0; j < N; ++j) g[e][j] = 0.0f;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     if (!(m.inb & (1 << k))) continue;                       // out-of-image corner: weight 0
                     const int ty = m.y0 + (k >> 1) - by, tx = m.x0 + (k & 1) - bx;
-                    h8_t v;
+                    uint4 raw;
                     if (ty < 0 || ty > R || tx < 0 || tx > R)               // a floor() that moved by one through the round trip: rare, exact
-                        v = __builtin_bit_cast(h8_t, ld_global16(rbase + (int64_t)(m.y0 + (k >> 1)) * rsy + (int64_t)(m.x0 + (k & 1)) * rsx));
+                        raw = ld_global16(rbase + (int64_t)(m.y0 + (k >> 1)) * rsy + (int64_t)(m.x0 + (k & 1)) * rsx);
                     else
-                        v = *(const h8_t*)(mywin + (ty * (R + 1) + tx) * 128);
+                        raw = *(const uint4*)(mywin + (ty * (R + 1) + tx) * TEX);
+                    float v[N];
+                    Slice<T>::unpack(raw, v);
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) g[e][j] = g[e][j] + (float)v[j] * m.w[k];
+                    for (int j = 0; j < N; ++j) g[e][j] = g[e][j] + v[j] * m.w[k];
                 }
             }
     } else {
@@ -131,7 +168,7 @@ __global__ __launch_bounds__(FW_NT) void fgac_window_kernel(demfi_view REF, demf
                 const int e = ki * R + kj;
                 const int r = y * R - rr + ki, c = x * R - rr + kj;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) g[e][j] = 0.0f;
+                for (int j = 0; j < N; ++j) g[e][j] = 0.0f;
                 if (r < 0 || r >= R * H || c < 0 || c >= R * W) continue;       // unfold's zero padding (427)
                 const int i = r / H, h = r - i * H, jj = c / W, w = c - jj * W;
                 const int fy = (h * R + i) % H, fx = (w * R + jj) % W;          // tiled centroid grid (411)
@@ -140,7 +177,7 @@ __global__ __launch_bounds__(FW_NT) void fgac_window_kernel(demfi_view REF, demf
                 const float sx_ = unnormalized_coord(px, (float)(W - 1), (float)(W - 1));
                 const float sy_ = unnormalized_coord(py, (float)(H - 1), (float)(H - 1));
                 const SampleMap m = make_sample_map(sx_, sy_, H, W);
-                bilerp8(rbase, rsx, rsy, m, H, W, g[e]);
+                bilerp_slice<T>(rbase, rsx, rsy, m, H, W, g[e]);
             }
     }
     // ---- correlation over the channels: 8 per lane, then across the 8 lanes of the pixel (wavefront shuffles) ----------
@@ -149,68 +186,88 @@ __global__ __launch_bounds__(FW_NT) void fgac_window_kernel(demfi_view REF, demf
     for (int e = 0; e < E; ++e) {
         float s = 0.0f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) s = s + g[e][j] * sk[j];
-        corr[e] = group8_sum(s);
+        for (int j = 0; j < N; ++j) s = s + g[e][j] * sk[j];
+        corr[e] = group_sum<LPP>(s);
         mx = fmaxf(mx, corr[e]);
     }
     float den = 0.0f;
 #pragma unroll
     for (int e = 0; e < E; ++e) { corr[e] = expf(corr[e] - mx); den += corr[e]; }     // nn.Softmax(dim=1), 441
-    float o[8];
+    float o[N];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = 0.0f;
+    for (int j = 0; j < N; ++j) o[j] = 0.0f;
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const float a = corr[e] / den;
         if (attn && live && part == 0) attn[(int64_t)e * hw + pix] = a;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = o[j] + a * g[e][j];
+        for (int j = 0; j < N; ++j) o[j] = o[j] + a * g[e][j];
     }
-    if (live) {
-        h8_t ov;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) ov[j] = (half_t)o[j];
-        st_global16((char*)O.ptr + ((int64_t)y * O.sy + (int64_t)x * O.sx) * 2 + part * 16, __builtin_bit_cast(uint4, ov));
-    }
+    if (live) st_global16((char*)O.ptr + ((int64_t)y * O.sy + (int64_t)x * O.sx) * ESZ + part * 16, Slice<T>::pack(o));
 }
 
-// F.avg_pool2d(x, (P,P), (1,1), padding=sr) with count_include_pad (DeMFInet.py:417, 434): NHWC fp16, 16 bytes per lane.
+// F.avg_pool2d(x, (P,P), (1,1), padding=sr) with count_include_pad (DeMFInet.py:417, 434): NHWC of the path dtype, 16 bytes per lane.
+template <typename T>
 __global__ void avg_pool_fat_kernel(demfi_view S, demfi_view O, int C, int H, int W, int sr)
 {
-    const int lpp = C / 8;
+    constexpr int N = Slice<T>::N, ESZ = sizeof(T);
+    const int lpp = C / N;
     const int64_t i = (int64_t)blockIdx.x * FW_NT + threadIdx.x;
     const int64_t pix = i / lpp;
     if (pix >= (int64_t)H * W) return;
     const int part = (int)(i - pix * lpp);
     const int y = (int)(pix / W), x = (int)(pix - (int64_t)y * W);
-    float acc[8];
+    float acc[N];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = 0.0f;
+    for (int j = 0; j < N; ++j) acc[j] = 0.0f;
     for (int dy = -sr; dy <= sr; ++dy)
         for (int dx = -sr; dx <= sr; ++dx) {
             const int yy = y + dy, xx = x + dx;
             if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
-            const h8_t v = __builtin_bit_cast(h8_t, ld_global16((const char*)S.ptr + ((int64_t)yy * S.sy + (int64_t)xx * S.sx) * 2 + part * 16));
+            float v[N];
+            Slice<T>::unpack(ld_global16((const char*)S.ptr + ((int64_t)yy * S.sy + (int64_t)xx * S.sx) * ESZ + part * 16), v);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] += (float)v[j];
+            for (int j = 0; j < N; ++j) acc[j] += v[j];
         }
-    const float inv = 1.0f / (float)((2 * sr + 1) * (2 * sr + 1));
-    h8_t o;
+    // ATen: sum / pool_size with count_include_pad (a division, not a multiplication by the reciprocal: exact for fp32 parity)
+    const float cnt = (float)((2 * sr + 1) * (2 * sr + 1));
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = (half_t)(acc[j] * inv);
-    st_global16((char*)O.ptr + ((int64_t)y * O.sy + (int64_t)x * O.sx) * 2 + part * 16, __builtin_bit_cast(uint4, o));
+    for (int j = 0; j < N; ++j) acc[j] = acc[j] / cnt;
+    st_global16((char*)O.ptr + ((int64_t)y * O.sy + (int64_t)x * O.sx) * ESZ + part * 16, Slice<T>::pack(acc));
 }
 
-bool fat16(const demfi_view* v) { return v && v->ptr && v->sc == 1 && !v->is_f32; }
+bool fat_view(const demfi_view* v) { return v && v->ptr && v->sc == 1; }
+
+template <typename T>
+int launch_window(const demfi_view* ref_k, const demfi_view* source_k, const float* flow, const demfi_view* out, int H, int W, int rr, int mode,
+                  float* attn_out, hipStream_t st)
+{
+    constexpr int LPP = 64 * sizeof(T) / 16;
+    const int64_t n = (int64_t)H * W * LPP;
+    const dim3 grid((unsigned)((n + FW_NT - 1) / FW_NT)), blk(FW_NT);
+    const int R = 2 * rr + 1;
+    const size_t lds = mode == 1 ? (size_t)(FW_NT / LPP) * (R + 1) * (R + 1) * 64 * sizeof(T) : 0;
+    DEMFI_LDS_ATTR((fgac_window_kernel<T, 3, 1>));
+    DEMFI_LDS_ATTR((fgac_window_kernel<T, 5, 1>));
+    if (rr == 1 && mode == 0) hipLaunchKernelGGL((fgac_window_kernel<T, 3, 0>), grid, blk, lds, st, *ref_k, *source_k, flow, *out, H, W, attn_out);
+    else if (rr == 1) hipLaunchKernelGGL((fgac_window_kernel<T, 3, 1>), grid, blk, lds, st, *ref_k, *source_k, flow, *out, H, W, attn_out);
+    else if (mode == 0) hipLaunchKernelGGL((fgac_window_kernel<T, 5, 0>), grid, blk, lds, st, *ref_k, *source_k, flow, *out, H, W, attn_out);
+    else hipLaunchKernelGGL((fgac_window_kernel<T, 5, 1>), grid, blk, lds, st, *ref_k, *source_k, flow, *out, H, W, attn_out);
+    DEMFI_HIP_CHECK(hipGetLastError());
+    return DEMFI_OK;
+}
 
 }  // namespace
 
 extern "C" int demfi_avg_pool_fat(const demfi_view* src, const demfi_view* out, int C, int H, int W, int sr, void* stream)
 {
-    if (!fat16(src) || !fat16(out) || C <= 0 || C % 8 || H <= 0 || W <= 0 || sr < 0 || sr > 4)
-        return demfi_set_error(DEMFI_ERR_ARG, "demfi_avg_pool_fat: fp16 NHWC views, C %% 8 == 0, 0 <= sr <= 4");
-    const int64_t n = (int64_t)H * W * (C / 8);
-    hipLaunchKernelGGL(avg_pool_fat_kernel, dim3((unsigned)((n + FW_NT - 1) / FW_NT)), dim3(FW_NT), 0, (hipStream_t)stream, *src, *out, C, H, W, sr);
+    if (!fat_view(src) || !fat_view(out) || src->is_f32 != out->is_f32 || C <= 0 || C % 8 || H <= 0 || W <= 0 || sr < 0 || sr > 4)
+        return demfi_set_error(DEMFI_ERR_ARG, "demfi_avg_pool_fat: NHWC views of one dtype, C %% 8 == 0, 0 <= sr <= 4");
+    const int per = src->is_f32 ? 4 : 8;
+    const int64_t n = (int64_t)H * W * (C / per);
+    const dim3 grid((unsigned)((n + FW_NT - 1) / FW_NT));
+    if (src->is_f32) hipLaunchKernelGGL(avg_pool_fat_kernel<float>, grid, dim3(FW_NT), 0, (hipStream_t)stream, *src, *out, C, H, W, sr);
+    else hipLaunchKernelGGL(avg_pool_fat_kernel<half_t>, grid, dim3(FW_NT), 0, (hipStream_t)stream, *src, *out, C, H, W, sr);
     DEMFI_HIP_CHECK(hipGetLastError());
     return DEMFI_OK;
 }
@@ -218,22 +275,12 @@ extern "C" int demfi_avg_pool_fat(const demfi_view* src, const demfi_view* out, 
 extern "C" int demfi_fgac_window(const demfi_view* ref_k, const demfi_view* source_k, const float* flow, const demfi_view* out,
                                  int C, int H, int W, int rr, int mode, float* attn_out, void* stream)
 {
-    if (!fat16(ref_k) || !fat16(source_k) || !fat16(out) || !flow || C != 64 || H <= 1 || W <= 1)
-        return demfi_set_error(DEMFI_ERR_ARG, "demfi_fgac_window: fp16 NHWC views with C = 64 expected");
+    if (!fat_view(ref_k) || !fat_view(source_k) || !fat_view(out) || !flow || C != 64 || H <= 1 || W <= 1 ||
+        ref_k->is_f32 != source_k->is_f32 || ref_k->is_f32 != out->is_f32)
+        return demfi_set_error(DEMFI_ERR_ARG, "demfi_fgac_window: NHWC views of one dtype (fp16 or fp32) with C = 64 expected");
     if (rr < 1 || rr > 2 || (mode != 0 && mode != 1))
         return demfi_set_error(DEMFI_ERR_ARG, "demfi_fgac_window: rr in {1, 2}, mode in {0, 1} (rr = 0 is demfi_fgac_gather)");
     if ((int64_t)H * W * (2 * rr + 1) >= (1ll << 30)) return demfi_set_error(DEMFI_ERR_ARG, "demfi_fgac_window: image too large");
-    const int64_t n = (int64_t)H * W * 8;
-    const dim3 grid((unsigned)((n + FW_NT - 1) / FW_NT)), blk(FW_NT);
-    hipStream_t st = (hipStream_t)stream;
-    const int R = 2 * rr + 1;
-    const size_t lds = mode == 1 ? (size_t)32 * (R + 1) * (R + 1) * 128 : 0;
-    DEMFI_LDS_ATTR((fgac_window_kernel<3, 1>));
-    DEMFI_LDS_ATTR((fgac_window_kernel<5, 1>));
-    if (rr == 1 && mode == 0) hipLaunchKernelGGL((fgac_window_kernel<3, 0>), grid, blk, lds, st, *ref_k, *source_k, flow, *out, H, W, attn_out);
-    else if (rr == 1) hipLaunchKernelGGL((fgac_window_kernel<3, 1>), grid, blk, lds, st, *ref_k, *source_k, flow, *out, H, W, attn_out);
-    else if (mode == 0) hipLaunchKernelGGL((fgac_window_kernel<5, 0>), grid, blk, lds, st, *ref_k, *source_k, flow, *out, H, W, attn_out);
-    else hipLaunchKernelGGL((fgac_window_kernel<5, 1>), grid, blk, lds, st, *ref_k, *source_k, flow, *out, H, W, attn_out);
-    DEMFI_HIP_CHECK(hipGetLastError());
-    return DEMFI_OK;
+    if (ref_k->is_f32) return launch_window<float>(ref_k, source_k, flow, out, H, W, rr, mode, attn_out, (hipStream_t)stream);
+    return launch_window<half_t>(ref_k, source_k, flow, out, H, W, rr, mode, attn_out, (hipStream_t)stream);
 }

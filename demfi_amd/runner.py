@@ -37,16 +37,18 @@ class WindowRunner:
         W = (width + 31) // 32 * 32
         env_trunk = os.environ.get('DEMFI_NTRUNK')
         env_ctx = os.environ.get('DEMFI_NCTX')
-        cached = getattr(model, '_engines', {}).get((H, W, model.path_dtype)) if use_graph else None
+        # batched mode (default): the time instants of a window run as ONE launch sequence whose convolutions are batched
+        # over n_ctx per-t contexts (demfi_forward_tb).  DEMFI_TB=0: one graph per time instant on n_ctx streams (round-2a).
+        self.tb = bool(use_graph and mfi > 2 and os.environ.get('DEMFI_TB', '1') != '0')
+        # a runner built earlier on this model for the same frame size fixed the engine's shape: take it over (batched mode) instead
+        # of probing the memory again -- a second runner (bench.py's final_only one) must not force a second multi-GB engine
+        cached = getattr(model, '_engines', {}).get((H, W, model.path_dtype)) if self.tb else None
         if cached is not None and cached.n_ctx <= 1:     # a plain forward()'s engine says nothing about a runner's configuration
             cached = None
         how = 'explicit'
         if n_trunk is None:
             n_trunk = int(env_trunk) if env_trunk else (cached.n_trunk if cached is not None else None)
         self.n_trunk = (n_trunk or 2) if use_graph else 1
-        # batched mode (default): the time instants of a window run as ONE launch sequence whose convolutions are batched
-        # over n_ctx per-t contexts (demfi_forward_tb).  DEMFI_TB=0: one graph per time instant on n_ctx streams (round-2a).
-        self.tb = bool(use_graph and mfi > 2 and os.environ.get('DEMFI_TB', '1') != '0')
         if self.tb:
             lib = L.load()
             dt = L.F32 if model.path_dtype == torch.float32 else L.F16

@@ -131,6 +131,64 @@ def test_config2_720p_runner_batched_equals_module():
     torch.cuda.empty_cache()
 
 
+def test_config2_720p_benched_path_bytes_equal_module_path():
+    """the EXACT code path bench.py times -- run_clip_u8 = pinned host frames -> H2D -> fused uint8 ingest ->
+    batched 7-context plan -> uint8 sink epilogue -> D2H -- at the benched size, against the reference-shaped path on the same
+    frames (one DeMFInet.forward per t through pad_forward_crop, separate normalise / denorm kernels): every byte of the 7 St
+    frames and of S0 / S1 of every window.  bench.py runs the same check on its last timed window and fails on a mismatch."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import synthetic_clip_u8
+    from demfi_amd.clip import window_list
+    from demfi_amd.harness import module_window_u8
+    from demfi_amd.runner import WindowRunner
+    h, w, N, M = 720, 1280, 3, 8
+    m = _model(torch.float16)
+    frames = synthetic_clip_u8(h, w, 6, seed=4242)                     # 6 frames -> 3 windows, pinned host memory
+    wins = window_list(len(frames))
+    runner = WindowRunner(m, h, w, n_tst=N, mfi=M)
+    assert runner.tb and runner.n_ctx == 7 and runner.engine.supports_u8_sink
+    got = {}
+    n = runner.run_clip_u8(frames, wins, lambda k, st, s01: got.__setitem__(k, (st.clone(), s01.clone())), batch=2, reuse_frames=False)
+    assert n == 3 and sorted(got) == [0, 1, 2]
+    for k, win in enumerate(wins):
+        st_ref, s01_ref = module_window_u8(m, [frames[i] for i in win], N, M)
+        assert torch.equal(got[k][0], st_ref.cpu()), 'St bytes of window %d' % k
+        assert torch.equal(got[k][1], s01_ref.cpu()), 'S0/S1 bytes of window %d' % k
+    assert got[0][0].float().std() > 5.0                               # real frames, not a constant
+    del runner, m
+    torch.cuda.empty_cache()
+
+
+def test_config2_720p_fp16_gates_three_windows_three_t():
+    """the fp16 acceptance gate on 3 windows x t in {1/8, 1/2, 7/8} instead of one window at t = 1/2.
+    Reference = this repo's fp32 HIP path on the same window, which is itself pinned to the fp32 oracle at this size to
+    |dPSNR| <= 1e-3 dB / PSNR > 60 dB (test_config4_720p_fp32_n5_strict_psnr) -- nine 36-second oracle forwards on the host would
+    not fit the suite; the one direct fp16-vs-oracle comparison stays in test_config2_720p_fp16_n3_psnr_bounds.
+    Gate: PSNR(fp16, fp32) >= 44 dB and |dPSNR vs pseudo-GT| <= 5e-3 dB for St, S0 and S1 of the last recursion."""
+    from demfi_amd.runner import WindowRunner
+    h, w, N, M = 720, 1280, 3, 8
+    m16, m32 = _model(torch.float16), _model(torch.float32)
+    r16 = WindowRunner(m16, h, w, n_tst=N, mfi=M)
+    r32 = WindowRunner(m32, h, w, n_tst=N, mfi=M, n_ctx=1)
+    worst = (1e9, 0.0)
+    for seed in (11, 12, 13):
+        x = synthetic_window(h, w, seed).to(DEV)
+        st16, s16 = [t.cpu().numpy().copy() for t in r16.run_window(x)]
+        st32, s32 = [t.cpu().numpy().copy() for t in r32.run_window(x)]
+        gt = x[0, :, 0].cpu().numpy()
+        for j in (0, 3, 6):                                          # t = 1/8, 1/2, 7/8
+            ps, dps = O.psnr(st16[j], st32[j]), O.psnr(st16[j], gt) - O.psnr(st32[j], gt)
+            worst = (min(worst[0], ps), max(worst[1], abs(dps)))
+            assert np.isfinite(st16[j]).all() and ps >= 44.0 and abs(dps) <= 5e-3, (seed, j, ps, dps)
+        for i in range(2):                                           # deblurred frames (kept from the first time instant)
+            ps, dps = O.psnr(s16[i], s32[i]), O.psnr(s16[i], gt) - O.psnr(s32[i], gt)
+            assert ps >= 44.0 and abs(dps) <= 5e-3, (seed, 'S%d' % i, ps, dps)
+    print('720p fp16 vs fp32 HIP path, 3 windows x 3 t: worst PSNR %.2f dB, worst |dPSNR vs pseudo-GT| %.4f dB' % worst)
+    del r16, r32, m16, m32
+    torch.cuda.empty_cache()
+
+
 # ------------------------------------------------------------------------------------------------------
 # configs[4]: 1080p -> 1088x1920, x16 (15 time instants, t_schedule(16)), N_tst = 3, fp16
 # ------------------------------------------------------------------------------------------------------

@@ -140,13 +140,13 @@ def test_plan_non_shared_fgac():
 
 @pytest.mark.parametrize('rr,sr,fmap', [(1, 0, 0), (1, 1, 1)])
 def test_plan_generalised_fgac(rr, sr, fmap):
-    """hp.fgac_rr / fgac_sr > 0: the plan gains conv_source_k, the optional pooling and the window op (fp16 path only);
-    interpreted on CPU it follows the oracle's generalised FGAC (itself pinned to the patched reference)."""
+    """hp.fgac_rr / fgac_sr > 0: the plan gains conv_source_k, the optional pooling and the window op (both path dtypes since
+    round 3); interpreted on CPU it follows the oracle's generalised FGAC (itself pinned to the patched reference)."""
     hp = HyperParams(fgac_rr=rr, fgac_sr=sr, fgac_map=fmap)
     sd = synthetic_state_dict(0)
     H, W = 32, 32
-    with pytest.raises(L.DemfiError):
-        Engine(sd, H, W, torch.float32, 'cpu', max_updates=1, hp=hp)            # window kernel is fp16-only
+    e32 = Engine(sd, H, W, torch.float32, 'cpu', max_updates=1, hp=hp)          # fp32 instantiation of the window kernel (round 3)
+    assert [op.kind for op in e32.ops(0)].count(8) == 2
     eng = Engine(sd, H, W, torch.float16, 'cpu', max_updates=1, hp=hp)
     kinds = [op.kind for op in eng.ops(0)]
     assert kinds.count(8) == 2 and kinds.count(4) == 0 and kinds.count(9) == (4 if sr else 0)
