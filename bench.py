@@ -145,7 +145,9 @@ def png_side_figure(a, model, runner):
 def load_pmc_traffic():
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary (profiles/r02_pmc_traffic.json,
     written by tools/pmc_traffic.py on the GPU box: separate --pmc passes, 2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction)."""
-    path = os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')
+    path = os.path.join(ROOT, 'profiles', 'r03_pmc_traffic.json')
+    if not os.path.exists(path):
+        path = os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')
     if not os.path.exists(path):
         return None
     with open(path) as f:
@@ -295,12 +297,18 @@ def main():
         wb = [p for p in prof if p[1] == 'warp_fat']
         wb_ms = sum(p[3] for p in wb) / len(wb)
         esz = 2 if a.dtype == 'fp16' else 4
-        wb_bytes = (3 * 64 * esz + 20) * eng.H * eng.W                       # 3*C*e + 20 B/px
-        out['roofline_hbm'] = {'kernel': 'warp_blend_fat C=64 (bwarp x2 + Eq.2 blend), in-network flows', 'bound': 'hbm',
+        # FAC + warp kernel of the north star: Ft = Eq.(2) blend of the two backward-warped trunk feature maps.  In the batched plan ONE
+        # launch covers the nb time instants of a window with the contexts innermost per tile, so its algorithmic bytes are: F0 and
+        # F1 once (2 C e B/px) + per time instant the output (C e) and the two flows + logit (20 B/px).  Per-t launches: 3 C e + 20.
+        wb_nb = 1                                                # the fat warp runs one launch per time instant (batched it was slower: profiles/r03_notes.md)
+        wb_bytes = (2 * 64 * esz + wb_nb * (64 * esz + 20)) * eng.H * eng.W
+        out['roofline_hbm'] = {'kernel': 'warp_blend_fat C=64 (bwarp x2 + Eq.2 blend), in-network flows, %d time instants per launch' % wb_nb, 'bound': 'hbm',
                                'achieved': round(wb_bytes / (wb_ms * 1e-3) / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                                'frac': round(wb_bytes / (wb_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                'traffic': pmc.get('warp_traffic_bytes') if pmc else None,
-                               'avg_launch_ms': round(wb_ms, 4), 'bytes_per_launch': wb_bytes}
+                               'avg_launch_ms': round(wb_ms, 4), 'bytes_per_launch': wb_bytes,
+                               'per_t_equivalent': {'bytes_per_t_launch': (3 * 64 * esz + 20) * eng.H * eng.W,
+                                                    'note': 'one launch per time instant reads F0 / F1 every time: 404 B/px x nb'}}
         cfr = [p for p in prof if p[1] == 'cfr']
         out['breakdown_ms'] = {'trunk_once_per_window': round(trunk, 2), 'per_t': round(per_t, 2),
                                'time_instants_per_launch_sequence': nb,

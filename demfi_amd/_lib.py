@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('DEMFI_HIP_LIB') or os.path.join(_HERE, 'csrc', 'libdemfi_hip.so')   # override: ablation builds
 
 F16, F32 = 0, 1
-ABI_VERSION = 4
+ABI_VERSION = 5
 ACT_NONE, ACT_RELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3
 MODE_STORE, MODE_MUL, MODE_GRU = 0, 1, 2
 MAX_PIECES, MAX_CHUNKS, MAX_SEGS, MAX_OCTS = 48, 40, 8, 32
@@ -66,9 +66,16 @@ class HParams(C.Structure):
                 ('shared_fgac', C.c_int32), ('fgac_rr', C.c_int32), ('fgac_sr', C.c_int32), ('_pad', C.c_int32)]
 
 
+class Batch(C.Structure):
+    """demfi_batch: one launch for nb per-t contexts; byte strides between the contexts' copies of every pointer."""
+    _fields_ = [('nb', C.c_int32), ('_pad', C.c_int32), ('a', C.c_int64), ('b', C.c_int64), ('o', C.c_int64), ('t', C.c_int64),
+                ('p', C.c_int64 * 32)]
+
+
 class Op(C.Structure):
     _fields_ = [('kind', C.c_int32), ('conv', C.c_int32), ('nch', C.c_int32), ('_pad', C.c_int32), ('macs', C.c_int64),
-                ('a', View), ('b', View), ('o', View), ('p', C.c_void_p * 32), ('t', C.c_void_p), ('name', C.c_char * 64)]
+                ('a', View), ('b', View), ('o', View), ('p', C.c_void_p * 32), ('t', C.c_void_p), ('name', C.c_char * 64),
+                ('bt', Batch)]
 
 
 _SIGS = {
@@ -91,6 +98,13 @@ _SIGS = {
                                    C.POINTER(View), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     'demfi_warp_blend_pack': (C.c_int, [C.POINTER(View), C.c_void_p, C.POINTER(View), C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.POINTER(View), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    'demfi_warp_blend_batched': (C.c_int, [C.POINTER(View), C.c_void_p, C.POINTER(View), C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.POINTER(View), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(Batch),
+                                           C.c_void_p]),
+    'demfi_cfr_flow_align_batched': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                               C.POINTER(Batch), C.c_void_p]),
+    'demfi_pack_planes_batched': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.POINTER(Batch),
+                                            C.c_void_p]),
     'demfi_fgac_gather': (C.c_int, [C.POINTER(View), C.c_void_p, C.POINTER(View), C.c_int, C.c_int, C.c_int,
                                     C.c_void_p, C.c_void_p]),
     'demfi_fgac_window': (C.c_int, [C.POINTER(View), C.POINTER(View), C.c_void_p, C.POINTER(View), C.c_int, C.c_int, C.c_int,

@@ -923,7 +923,7 @@ __device__ __forceinline__ float res_mix_hi(unsigned a, float c)
 #endif
 constexpr int SG_NH = 4;                                         // helper waves
 constexpr int SG_NT = NT + 64 * SG_NH;
-template <bool RES>
+template <bool RES, bool TANH = false>   // TANH: tanh after the residual add (Refine_Module.dec3's feature halves, DeMFInet.py:86-87) instead of ReLU / identity
 __global__ __launch_bounds__(SG_NT, 1) void conv3x3_c64_stg_kernel(const demfi_conv* __restrict__ d)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1228,10 +1228,14 @@ __global__ __launch_bounds__(SG_NT, 1) void conv3x3_c64_stg_kernel(const demfi_c
                             v[2 * q + 1] = res_mix_hi(r[q], v[2 * q + 1]);
                         }
                     }
+                    if constexpr (TANH) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] = fast_tanh(v[j]);
+                    }
                     h8_t o;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) o[j] = (half_t)v[j];
-                    o = __builtin_elementwise_max(o, act_floor8);
+                    if constexpr (!TANH) o = __builtin_elementwise_max(o, act_floor8);
                     *(u4_t*)(tbase + (wave * 2 + p) * 4096 + soff[s][m2]) = __builtin_bit_cast(u4_t, o);
                 }
             }
@@ -1246,14 +1250,18 @@ __global__ __launch_bounds__(SG_NT, 1) void conv3x3_c64_stg_kernel(const demfi_c
 static int launch_stg(const demfi_conv* h, const demfi_conv* dev, hipStream_t st)
 {
     const size_t lds = 9 * 4 * 2 * 1024 + 2 * P_TILE_BYTES + 1024;
-    DEMFI_LDS_ATTR((conv3x3_c64_stg_kernel<true>));
-    DEMFI_LDS_ATTR((conv3x3_c64_stg_kernel<false>));
+    DEMFI_LDS_ATTR((conv3x3_c64_stg_kernel<true, false>));
+    DEMFI_LDS_ATTR((conv3x3_c64_stg_kernel<false, false>));
+    DEMFI_LDS_ATTR((conv3x3_c64_stg_kernel<true, true>));
+    DEMFI_LDS_ATTR((conv3x3_c64_stg_kernel<false, true>));
     const int total = ((h->W + TW - 1) / TW) * ((h->H + TH - 1) / TH) * h->batch;
     const int grid = total >= 256 ? 256 : total;
-    if (h->segs[h->sub_seg[0]].res.ptr != nullptr)
-        hipLaunchKernelGGL((conv3x3_c64_stg_kernel<true>), dim3(grid), dim3(SG_NT), lds, st, dev);
-    else
-        hipLaunchKernelGGL((conv3x3_c64_stg_kernel<false>), dim3(grid), dim3(SG_NT), lds, st, dev);
+    const demfi_seg& sg = h->segs[h->sub_seg[0]];
+    const bool res = sg.res.ptr != nullptr, th = sg.act == DEMFI_ACT_TANH;
+    if (res && th)  hipLaunchKernelGGL((conv3x3_c64_stg_kernel<true, true>), dim3(grid), dim3(SG_NT), lds, st, dev);
+    else if (res)   hipLaunchKernelGGL((conv3x3_c64_stg_kernel<true, false>), dim3(grid), dim3(SG_NT), lds, st, dev);
+    else if (th)    hipLaunchKernelGGL((conv3x3_c64_stg_kernel<false, true>), dim3(grid), dim3(SG_NT), lds, st, dev);
+    else            hipLaunchKernelGGL((conv3x3_c64_stg_kernel<false, false>), dim3(grid), dim3(SG_NT), lds, st, dev);
     DEMFI_HIP_CHECK(hipGetLastError());
     return DEMFI_OK;
 }
@@ -1300,7 +1308,11 @@ struct NarrowFrag { uint4 a[2], b0, b1; };
 // NDMA: waves that issue the LDS-DMA of a tile (instruction i belongs to DMA wave i % NDMA).  One wave needs 43 x ~80 cycles
 // just to ISSUE a 128-byte-record tile; the thin-output layers (little MFMA work per tile, two tile buffers) are bound by
 // exactly that latency, so they use two.
-template <int NCO, int REC, int EPI, int KS = 3, int NDMA = NarrowCfg<REC, KS>::NDMA>
+// NOCT (THIN only): number of live 8-cout octets (they are the first NOCT ones).  The thin-output layers have 1-3 (Dec_last2 1,
+// flow_occ.conv2 / dec3's planes 2, Dec_last2_2 3); round 2 walked all four unconditionally: 32 scalar residual loads and four
+// dependent LDS bias reads per tile whatever the layer -- the phase trace (profiles/r03_notes.md) shows 1 860 + 2 810 of a 8 260-cycle
+// period of Dec_last2 there.
+template <int NCO, int REC, int EPI, int KS = 3, int NDMA = NarrowCfg<REC, KS>::NDMA, int NOCT = 4>
 __global__ __launch_bounds__(NT + 64 * NDMA, 1) void conv3x3_narrow_persist_kernel(const demfi_conv* __restrict__ d)
 {
     constexpr bool RES = EPI == 1, THIN = EPI == 2;
@@ -1367,21 +1379,27 @@ __global__ __launch_bounds__(NT + 64 * NDMA, 1) void conv3x3_narrow_persist_kern
         const char* const zeros = (const char*)d->zero_page;
         // instruction i covers records PPI*i ..; lane -> (record PPI*i + lane/SL, physical slot lane%SL)
         int off[NI], meta[NI];                                    // meta = row | column << 8 | piece << 16 (piece 2 = zeros)
+        bool any_other = false;                                   // some lane of some instruction is NOT a plain piece-0 slot
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int px = i * Cfg::PPI + lane / SL;
-            const int ly = px / P_LW;
-            const int lxx = px - ly * P_LW;
+            const int pxc = min(px, P_NP - 1);                   // records past the tile (last instruction): re-read the last record, never consumed
+            const int ly = pxc / P_LW;
+            const int lxx = pxc - ly * P_LW;
             const int byte = (((lane & (SL - 1)) ^ Cfg::swz(lxx)) << 4);      // logical slot held by this physical slot
             int sel = 2;
-            if (px < P_NP) {
-                if (byte >= pb0[0] && byte < pb1[0]) sel = 0;
-                else if (byte >= pb0[1] && byte < pb1[1]) sel = 1;
-            }
+            if (byte >= pb0[0] && byte < pb1[0]) sel = 0;
+            else if (byte >= pb0[1] && byte < pb1[1]) sel = 1;
             const int pi = sel == 1 ? 1 : 0;
             off[i] = (int)(ly * psy[pi] + lxx * psx[pi]) + byte - pb0[pi];
-            meta[i] = ly | (lxx << 8) | (sel << 16);
+            meta[i] = px < P_NP ? (ly | (lxx << 8) | (sel << 16)) : (0xffff | (2 << 16));
+            any_other = any_other || sel != 0;
         }
+        // SIMPLE layers (one real piece that fills the whole record: Dec_last2*, flow_occ.conv2, dec3's planes, ...): an interior tile
+        // is "uniform base + precomputed lane offset" per instruction -- 2 VALU instead of ~10 (select between two pieces / the zero
+        // page, bounds).  The DMA waves are younger than the MFMA waves and get few issue slots (phase trace: 4 500 cycles for the
+        // 11 instructions of a wave), and with a short MFMA phase their issue time IS the tile period.
+        const bool simple = __builtin_amdgcn_readfirstlane(__ballot(any_other) == 0 ? 1 : 0) != 0;
         auto issue_tile = [&](int k) {
             int bimg, oy0, ox0;
             tile_coords(t_first + k * t_step, bimg, oy0, ox0);
@@ -1389,12 +1407,21 @@ __global__ __launch_bounds__(NT + 64 * NDMA, 1) void conv3x3_narrow_persist_kern
             const char* base1 = src[1] + (int64_t)bimg * psb[1] + (int64_t)(oy0 - PAD) * psy[1] + (int64_t)(ox0 - PAD) * psx[1];
             char* dst = tbuf + (k % NBUF) * TILE_BYTES;
             const bool interior = oy0 >= PAD && oy0 + TH + PAD <= H && ox0 >= PAD && ox0 + TW + PAD <= W;
+            if (simple && interior) {
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    if (NDMA > 1 && (i % NDMA) != dw) continue;  // wave-uniform
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base0 + off[i]),
+                                                     (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+                }
+                return;
+            }
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
                 if (NDMA > 1 && (i % NDMA) != dw) continue;      // wave-uniform
                 const int sel = meta[i] >> 16;
                 const int iy = oy0 - PAD + (meta[i] & 255), ix = ox0 - PAD + ((meta[i] >> 8) & 255);
-                const bool ok = sel != 2 && (interior || (iy >= 0 && iy < H && ix >= 0 && ix < W));
+                const bool ok = sel != 2 && (meta[i] & 0xffff) != 0xffff && (interior || (iy >= 0 && iy < H && ix >= 0 && ix < W));
                 const char* g = ok ? (sel == 1 ? base1 : base0) + off[i] : zeros;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                                  (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
@@ -1411,9 +1438,12 @@ __global__ __launch_bounds__(NT + 64 * NDMA, 1) void conv3x3_narrow_persist_kern
             if (ahead >= 2)      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NIW <= 63 ? 2 * NIW : 0) : "memory");
             else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NIW <= 63 ? NIW : 0) : "memory");
             else                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            TRACE_STAMP(wave, k, 0);
             __syncthreads();                                    // hand tile k to the MFMA waves
+            TRACE_STAMP(wave, k, 1);
             // ring slot of tile k+NBUF-1 = slot of tile k-1: every MFMA wave finished reading it before this barrier
             if (k + NBUF - 1 < n_tiles) issue_tile(k + NBUF - 1);
+            TRACE_STAMP(wave, k, 2);
         }
         return;
     }
@@ -1444,20 +1474,24 @@ __global__ __launch_bounds__(NT + 64 * NDMA, 1) void conv3x3_narrow_persist_kern
     const float* t_res[4];
     int t_on[4], t_act[4], t_nq[4], t_rmul[4];
     int64_t t_dsb[4], t_rsb[4];
-    const int64_t t_sc = (int64_t)H * W;                        // channel stride of every planar view (checked by the host)
+    int64_t t_dsc[4], t_dsx[4], t_dsy[4], t_rsc[4], t_rsx[4], t_rsy[4];   // element strides of the planar views (any: e.g. the parity views of dec3)
+    f4_t t_bias[4];                                              // bias of this lane's quad of octet g, in registers (was: LDS read per tile)
     if constexpr (THIN) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
+        for (int g = 0; g < NOCT; ++g) {
+            t_bias[g] = *gcp<f4_t>(d->bias + g * 8 + 4 * hi);
             t_on[g] = d->oct_n[g];
             const demfi_seg& sg = d->segs[d->oct_seg[g]];
             t_act[g] = sg.act;
             t_nq[g] = min(max(t_on[g] - 4 * hi, 0), 4);
             const int c0 = d->oct_ch[g] + (t_nq[g] > 0 ? 4 * hi : 0);       // lanes without a valid channel shadow channel 0 (never stored)
-            t_dst[g] = (float*)sg.dst.ptr + c0 * t_sc;
+            t_dsc[g] = sg.dst.sc; t_dsx[g] = sg.dst.sx; t_dsy[g] = sg.dst.sy;
+            t_rsc[g] = sg.res.sc; t_rsx[g] = sg.res.sx; t_rsy[g] = sg.res.sy;
+            t_dst[g] = (float*)sg.dst.ptr + c0 * t_dsc[g];
             // no residual (or an empty octet): the prefetch below reads the zero page with all strides multiplied by 0, so
             // that it stays unconditional (conditional loads leave register copies + an s_waitcnt in front of the MFMAs)
             const bool hasres = t_on[g] > 0 && sg.res.ptr != nullptr;
-            t_res[g] = hasres ? (const float*)sg.res.ptr + c0 * t_sc : (const float*)d->zero_page;
+            t_res[g] = hasres ? (const float*)sg.res.ptr + c0 * t_rsc[g] : (const float*)d->zero_page;
             t_rmul[g] = hasres ? 1 : 0;
             t_dsb[g] = sg.dst.sb;
             t_rsb[g] = sg.res.sb;
@@ -1480,21 +1514,21 @@ __global__ __launch_bounds__(NT + 64 * NDMA, 1) void conv3x3_narrow_persist_kern
                 const bool on = sk->iter == d->u8_iter;
                 s_h = sk->h; s_w = sk->w;
 #pragma unroll
-                for (int g = 0; g < 4; ++g) s_dst[g] = (on && t_on[g] == 3 && d->oct_ch[g] == 0) ? sk->frame[d->oct_seg[g]] : nullptr;
+                for (int g = 0; g < NOCT; ++g) s_dst[g] = (on && t_on[g] == 3 && d->oct_ch[g] == 0) ? sk->frame[d->oct_seg[g]] : nullptr;
             }
         }
         u4_t rreg[NCO][2][2];
         float tr[4][2][4];                                      // THIN: residual [octet][row][j], prefetched like rreg
         if constexpr (THIN) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
+            for (int g = 0; g < NOCT; ++g) {
 #pragma unroll
                 for (int p = 0; p < 2; ++p) {
                     const int oy = min(oy0 + wave * 2 + p, H - 1), oxx = min(ox0 + lx, W - 1);
-                    const float* rp = t_res[g] + (bimg * t_rsb[g] + (int64_t)oy * W + oxx) * t_rmul[g];
+                    const float* rp = t_res[g] + (bimg * t_rsb[g] + (int64_t)oy * t_rsy[g] + (int64_t)oxx * t_rsx[g]) * t_rmul[g];
 #pragma unroll
                     for (int j = 0; j < 4; ++j)                 // invalid j of this lane: re-read its first channel (value unused)
-                        tr[g][p][j] = *gcp<float>(rp + (j < t_nq[g] ? j : 0) * t_sc * t_rmul[g]);
+                        tr[g][p][j] = *gcp<float>(rp + (j < t_nq[g] ? j : 0) * t_rsc[g] * t_rmul[g]);
                 }
             }
         }
@@ -1510,7 +1544,9 @@ __global__ __launch_bounds__(NT + 64 * NDMA, 1) void conv3x3_narrow_persist_kern
                 }
             }
         }
+        TRACE_STAMP(wave, k, 0);
         asm volatile("s_barrier" ::: "memory");                 // tile k is in ring slot `slot`
+        TRACE_STAMP(wave, k, 1);
         f16x_t acc[NCO][2];
 #pragma unroll
         for (int s = 0; s < NCO; ++s) {
@@ -1519,7 +1555,56 @@ __global__ __launch_bounds__(NT + 64 * NDMA, 1) void conv3x3_narrow_persist_kern
         }
         const char* tb = tbuf + slot * TILE_BYTES + (wave * 2) * (P_LW * REC);
         slot = slot == NBUF - 1 ? 0 : slot + 1;
-        {
+        if constexpr (KS == 3) {
+            // (kx, k-step) groups with the three ky taps inside, like the 64 -> 64 kernel: output rows p = 0, 1 and ky = 0..2 touch the
+            // four input rows p + ky at one column offset, so 4 row fragments + 3*NCO weight fragments feed 6*NCO MFMAs (round 2: one
+            // (tap, k-step) at a time = 2 + NCO reads per 2*NCO MFMAs with a scheduling fence per step; the phase trace shows 3 400
+            // cycles for the 36 MFMAs of the 64 -> 3 layers).  The next group's reads are interleaved 1:1 with this group's MFMAs.
+            constexpr int NG = 3 * NKS;                         // groups: g = kx*NKS + ks
+            struct RowFragN { uint4 a[3][NCO]; uint4 b[4]; };
+            auto load_g = [&](RowFragN& f, int g) {
+                const int kx = g / NKS, ks = g % NKS;
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+                    for (int s = 0; s < NCO; ++s) f.a[ky][s] = *(const uint4*)(wl + ((((ky * 3 + kx) * NKS + ks) * NCO) + s) * 1024);
+                }
+                const char* p0 = tb + boff[kx * NKS + ks];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) f.b[r] = *(const uint4*)(p0 + r * (P_LW * REC));
+            };
+            auto mma_g = [&](const RowFragN& f) {
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+                    for (int s = 0; s < NCO; ++s) {
+                        Mma<half_t>::run(acc[s][0], f.a[ky][s], f.b[ky]);
+                        Mma<half_t>::run(acc[s][1], f.a[ky][s], f.b[ky + 1]);
+                    }
+                }
+            };
+            auto groups = [&](bool loads) {
+#pragma unroll
+                for (int q = 0; q < 6 * NCO; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (loads) {
+                        if (NCO == 1 && q == 0) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);    // 7 reads between 6 MFMAs
+                        else if (q < 3 * NCO + 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            // fragments TWO groups ahead: a group is only 6*NCO MFMAs (192 cycles for NCO = 1), less than an LDS round trip under load
+            RowFragN f[3];
+            load_g(f[0], 0);
+            if constexpr (NG > 1) load_g(f[1], 1);
+            static_for<0, NG>([&](auto G_) {
+                constexpr int g = decltype(G_)::value;
+                if constexpr (g + 2 < NG) load_g(f[(g + 2) % 3], g + 2);
+                mma_g(f[g % 3]);
+                groups(g + 2 < NG);
+            });
+        } else {
             auto load_step = [&](NarrowFrag& f, int g) {        // g = tap*NKS + ks
                 const int tap = g / NKS, ks = g % NKS;
                 const int ky = tap / KS, kx = tap % KS;
@@ -1544,16 +1629,21 @@ __global__ __launch_bounds__(NT + 64 * NDMA, 1) void conv3x3_narrow_persist_kern
                 __builtin_amdgcn_sched_barrier(0);
             });
         }
+#if defined(DEMFI_TRACE) && defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+        for (int s = 0; s < NCO; ++s) { asm volatile("" ::"v"(acc[s][0])); asm volatile("" ::"v"(acc[s][1])); }
+        TRACE_STAMP(wave, k, 2);
+#endif
         if constexpr (THIN) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {                       // retire the prefetch here (see the 64-channel kernel)
+            for (int g = 0; g < NOCT; ++g) {                    // retire the prefetch here (see the 64-channel kernel)
 #pragma unroll
                 for (int q = 0; q < 8; ++q) asm volatile("" : "+v"(tr[g][q >> 2][q & 3]));
             }
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
+            for (int g = 0; g < NOCT; ++g) {
                 if (t_on[g] == 0) continue;                     // wave-uniform
-                const f4_t bq = *(const f4_t*)(bias_lds + g * 8 + 4 * hi);
+                const f4_t bq = t_bias[g];
 #pragma unroll
                 for (int p = 0; p < 2; ++p) {
                     float v[4];
@@ -1574,13 +1664,14 @@ __global__ __launch_bounds__(NT + 64 * NDMA, 1) void conv3x3_narrow_persist_kern
                         continue;
                     }
                     if (oy < H && oxx < W) {
-                        float* dp = t_dst[g] + bimg * t_dsb[g] + (int64_t)oy * W + oxx;
+                        float* dp = t_dst[g] + bimg * t_dsb[g] + (int64_t)oy * t_dsy[g] + (int64_t)oxx * t_dsx[g];
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
-                            if (j < t_nq[g]) *gp<float>(dp + j * t_sc) = v[j];
+                            if (j < t_nq[g]) *gp<float>(dp + j * t_dsc[g]) = v[j];
                     }
                 }
             }
+            TRACE_STAMP(wave, k, 3);
             continue;
         }
         if constexpr (RES) {
@@ -1632,10 +1723,20 @@ int launch_narrow(const demfi_conv* h, const demfi_conv* dev, hipStream_t st, bo
     const int total = ((h->W + TW - 1) / TW) * ((h->H + TH - 1) / TH) * h->batch;
     const int grid = total >= 256 ? 256 : total;
     if (thin) {
-        if constexpr (NCO == 1)
-            hipLaunchKernelGGL((conv3x3_narrow_persist_kernel<1, REC, 2, KS>), dim3(grid),
-                               dim3(NT + 64 * NarrowCfg<REC, KS>::NDMA), lds, st, dev);
-        else
+        if constexpr (NCO == 1) {
+            constexpr int ND = NarrowCfg<REC, KS>::NDMA;
+            int noct = 0;                                        // live octets must be the leading ones for the specialised instantiations
+            while (noct < 4 && h->oct_n[noct] > 0) ++noct;
+            for (int g = noct; g < 4; ++g) if (h->oct_n[g] > 0) noct = 4;
+            DEMFI_LDS_ATTR((conv3x3_narrow_persist_kernel<1, REC, 2, KS, ND, 1>));
+            DEMFI_LDS_ATTR((conv3x3_narrow_persist_kernel<1, REC, 2, KS, ND, 2>));
+            DEMFI_LDS_ATTR((conv3x3_narrow_persist_kernel<1, REC, 2, KS, ND, 3>));
+            const dim3 blk(NT + 64 * ND);
+            if (noct == 1)      hipLaunchKernelGGL((conv3x3_narrow_persist_kernel<1, REC, 2, KS, ND, 1>), dim3(grid), blk, lds, st, dev);
+            else if (noct == 2) hipLaunchKernelGGL((conv3x3_narrow_persist_kernel<1, REC, 2, KS, ND, 2>), dim3(grid), blk, lds, st, dev);
+            else if (noct == 3) hipLaunchKernelGGL((conv3x3_narrow_persist_kernel<1, REC, 2, KS, ND, 3>), dim3(grid), blk, lds, st, dev);
+            else                hipLaunchKernelGGL((conv3x3_narrow_persist_kernel<1, REC, 2, KS>), dim3(grid), blk, lds, st, dev);
+        } else
             return demfi_set_error(DEMFI_ERR_ARG, "demfi_conv2d: thin epilogue needs nco == 1");
     } else if (h->segs[h->sub_seg[0]].res.ptr != nullptr)
         hipLaunchKernelGGL((conv3x3_narrow_persist_kernel<NCO, REC, 1, KS>), dim3(grid), dim3(NT + 64 * NarrowCfg<REC, KS>::NDMA), lds, st, dev);
@@ -2049,7 +2150,7 @@ static int launch_sep(const demfi_conv* h, const demfi_conv* dev, hipStream_t st
 #endif
 
 // epilogue of the persistent 3x3 kernels: ONE NHWC fp16 destination holding all NCO*32 channels (optional residual)
-static bool persist_out_eligible(const demfi_conv* h);
+static bool persist_out_eligible(const demfi_conv* h, bool allow_tanh = false);
 
 bool persist_eligible(const demfi_conv* h)
 {
@@ -2057,7 +2158,7 @@ bool persist_eligible(const demfi_conv* h)
     if (h->n_chunks != 1 || h->n_pieces != 1 || h->chunks[0].nks != 4 || h->rec_bytes != 128) return false;
     const demfi_piece& p = h->pieces[0];
     if (!p.fat || p.nch != 64 || p.up_shift != 0 || !p.v.ptr || p.v.is_f32) return false;
-    return persist_out_eligible(h);
+    return persist_out_eligible(h, h->nco == 2);                  // the staged-store kernel (NCO == 2) also has a tanh epilogue
 }
 
 // THIN epilogue of the narrow kernel: <= 32 packed couts, every octet routed to a planar fp32 [C,H,W] destination
@@ -2065,15 +2166,14 @@ bool persist_eligible(const demfi_conv* h)
 static bool thin_out_eligible(const demfi_conv* h)
 {
     if (h->nco != 1 || h->cout_pad != 32 || !h->zero_page || h->inH != h->H || h->inW != h->W || h->sub_seg[0] >= 0) return false;
-    const int64_t hw = (int64_t)h->H * h->W;
     bool any = false;
     for (int g = 0; g < 4; ++g) {
         if (h->oct_n[g] == 0) continue;
         any = true;
         const demfi_seg& sg = h->segs[h->oct_seg[g]];
         if (sg.mode != DEMFI_MODE_STORE || sg.scale != 1 || sg.dy != 0 || sg.dx != 0) return false;
-        if (!sg.dst.ptr || !sg.dst.is_f32 || sg.dst.sx != 1 || sg.dst.sy != h->W || sg.dst.sc != hw) return false;
-        if (sg.res.ptr && (!sg.res.is_f32 || sg.res.sx != 1 || sg.res.sy != h->W || sg.res.sc != hw)) return false;
+        if (!sg.dst.ptr || !sg.dst.is_f32) return false;            // any element strides (round 3: the parity views of dec3)
+        if (sg.res.ptr && !sg.res.is_f32) return false;
     }
     return any;
 }
@@ -2100,7 +2200,7 @@ static bool narrow_eligible(const demfi_conv* h)
     return persist_out_eligible(h) || thin_out_eligible(h);
 }
 
-static bool persist_out_eligible(const demfi_conv* h)
+static bool persist_out_eligible(const demfi_conv* h, bool allow_tanh)
 {
     if (h->nco > 2 || h->cout_pad != 32 * h->nco || !h->zero_page || h->inH != h->H || h->inW != h->W) return false;
     const int sg = h->sub_seg[0];
@@ -2109,7 +2209,7 @@ static bool persist_out_eligible(const demfi_conv* h)
         if (h->sub_seg[sb] != sg || h->oct_ch[sb * 4] != h->oct_ch[0] + 32 * sb) return false;
     const demfi_seg& seg = h->segs[sg];
     if (seg.mode != DEMFI_MODE_STORE || seg.scale != 1 || seg.dy != 0 || seg.dx != 0) return false;
-    if (seg.act != DEMFI_ACT_NONE && seg.act != DEMFI_ACT_RELU) return false;
+    if (seg.act != DEMFI_ACT_NONE && seg.act != DEMFI_ACT_RELU && !(allow_tanh && seg.act == DEMFI_ACT_TANH)) return false;
     return true;
 }
 

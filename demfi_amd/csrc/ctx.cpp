@@ -730,7 +730,22 @@ struct Builder {
         op.kind = kind;
         strncpy(op.name, name, sizeof(op.name) - 1);
         if (tb <= 1) { seg.push_back(op); return; }
-        for (int q = 0; q < tb; ++q) {                          // batched plan: the point-wise launch of every context, pointers rebased
+        // batched plan.  CFR and the thin (3-channel) warps: ONE launch for all tb per-t contexts (ABI v5, demfi_batch): the pointers
+        // are those of context 0, every pointer gets the byte stride of the buffer it lies in (per-t buffers: their context stride;
+        // window-level buffers of the trunk set: 0).  Measured in sequence at 720p x 7 contexts (profiles/r03_notes.md): cfr 81 -> 67 us
+        // and warp_thin 37 -> 35 us per time instant.  The fat warp and the plane packs stay one launch per context: batched they
+        // were SLOWER (pack 23 -> 31 us per context; fat warp with the contexts innermost per tile 85 -> 73 / 90 us: the gathered
+        // neighbourhoods of a tile do not survive in the 4 MB L2 across seven time instants with these incoherent flows).
+        const bool one_launch = kind == DEMFI_OP_CFR || (kind == DEMFI_OP_WARP && op.nch == 3);
+        if (one_launch) {
+            auto stride = [&](const void* p) { const int64_t cs = ctx_stride_of(p); return cs > 0 ? cs : (int64_t)0; };
+            op.bt.nb = tb;
+            op.bt.a = stride(op.a.ptr); op.bt.b = stride(op.b.ptr); op.bt.o = stride(op.o.ptr); op.bt.t = stride(op.t);
+            for (int i = 0; i < 32; ++i) op.bt.p[i] = stride(op.p[i]);
+            seg.push_back(op);
+            return;
+        }
+        for (int q = 0; q < tb; ++q) {                          // one launch per context, pointers rebased
             demfi_op o = op;
             o.a.ptr = (void*)tb_ptr(op.a.ptr, q);
             o.b.ptr = (void*)tb_ptr(op.b.ptr, q);
@@ -956,31 +971,50 @@ struct Builder {
                 v.sx *= 2; v.sy *= 2;
                 return v;
             };
-            const Layer l2 = {l3.cout, l3.cin, 2, 2};
+            // Round 3: each parity runs as THREE launches of the fast 64-input-channel kernels instead of one 160-cout launch of the
+            // general kernel (0.50 ms per parity at 0.09 of the MFMA peak): the 2x2 filter is embedded in a 3x3 one (taps outside the
+            // 2x2 footprint are zero: the 2.25x MAC saving is given back, the layer is memory-bound either way), so that the two
+            // 64-channel feature halves (tanh + residual aF0 / aF1) go to the staged-store 64 -> 64 kernel and the 5 flow / occlusion
+            // planes to a 32-cout launch.
+            const Layer l9 = {l3.cout, l3.cin, 3, 3};
             for (int dy = 0; dy < 2 && status >= 0; ++dy)
                 for (int dx = 0; dx < 2 && status >= 0; ++dx) {
-                    std::vector<float> w2, b2;
+                    std::vector<float> w9e, b2;
                     if (!dry) {
-                        w2.assign((size_t)l3.cout * l3.cin * 4, 0.0f);
+                        w9e.assign((size_t)l3.cout * l3.cin * 9, 0.0f);
                         for (int co = 0; co < l3.cout; ++co)
                             for (int ci = 0; ci < l3.cin; ++ci) {
                                 const float* w9 = &iw->second.data[((size_t)co * l3.cin + ci) * 9];
-                                float* w4 = &w2[((size_t)co * l3.cin + ci) * 4];
+                                float* we = &w9e[((size_t)co * l3.cin + ci) * 9];
                                 for (int ky = 0; ky < 3; ++ky)
                                     for (int kx = 0; kx < 3; ++kx) {
+                                        // source row of tap ky for output parity dy: rows {y-1, y} (dy = 0) or {y, y+1} (dy = 1) of the low-res image
                                         const int a = dy == 0 ? (ky >= 1) : (ky >= 2), b = dx == 0 ? (kx >= 1) : (kx >= 2);
-                                        w4[a * 2 + b] += w9[ky * 3 + kx];
+                                        we[(a + dy) * 3 + (b + dx)] += w9[ky * 3 + kx];      // embedded position: low-res row y - 1 + (a + dy)
                                     }
                             }
                         b2 = ib->second.data;
                     }
                     const std::string nm = p + "dec3#p" + std::to_string(dy) + std::to_string(dx);
-                    conv(th, nm, {fsrc(B["d2"], 0)},
-                         {D(phase_view(fview(B["rF"], 0, 0), dy, dx), range(5, 69), T, DEMFI_MODE_STORE, phase_view(fview(aF, 0, 0), dy, dx)),
-                          D(phase_view(fview(B["rF"], 0, 1), dy, dx), range(69, 133), T, DEMFI_MODE_STORE, phase_view(fview(aF, 0, 1), dy, dx)),
-                          D(phase_view(delta_v(0, 0), dy, dx), range(0, 4), DEMFI_ACT_NONE, DEMFI_MODE_STORE, phase_view(tview(B["ft"]), dy, dx)),
+                    // every output channel of a call's weight must be routed: slice the embedded filter per launch
+                    auto slice = [&](int c0, int c1, std::vector<float>& w, std::vector<float>& b) {
+                        if (dry) return;
+                        w.assign(w9e.begin() + (size_t)c0 * l3.cin * 9, w9e.begin() + (size_t)c1 * l3.cin * 9);
+                        b.assign(b2.begin() + c0, b2.begin() + c1);
+                    };
+                    std::vector<float> wa, ba, wb, bb, wf, bf;
+                    slice(5, 69, wa, ba); slice(69, 133, wb, bb); slice(0, 5, wf, bf);
+                    const Layer l64 = {64, l3.cin, 3, 3}, l5 = {5, l3.cin, 3, 3};
+                    conv(th, nm + "a", {fsrc(B["d2"], 0)},
+                         {D(phase_view(fview(B["rF"], 0, 0), dy, dx), range(0, 64), T, DEMFI_MODE_STORE, phase_view(fview(aF, 0, 0), dy, dx))},
+                         H2, W2, 1, 1, &wa, &ba, &l64);
+                    conv(th, nm + "b", {fsrc(B["d2"], 0)},
+                         {D(phase_view(fview(B["rF"], 0, 1), dy, dx), range(0, 64), T, DEMFI_MODE_STORE, phase_view(fview(aF, 0, 1), dy, dx))},
+                         H2, W2, 1, 1, &wb, &bb, &l64);
+                    conv(th, nm + "f", {fsrc(B["d2"], 0)},
+                         {D(phase_view(delta_v(0, 0), dy, dx), range(0, 4), DEMFI_ACT_NONE, DEMFI_MODE_STORE, phase_view(tview(B["ft"]), dy, dx)),
                           D(phase_view(delta_v(0, 4), dy, dx), {4}, DEMFI_ACT_NONE, DEMFI_MODE_STORE, phase_view(tview(ffo, 4), dy, dx))},
-                         H2, W2, 1, 1, &w2, &b2, &l2, 1 - dy, 1 - dx);
+                         H2, W2, 1, 1, &wf, &bf, &l5);
                 }
         } else
         conv(th, p + "dec3", {fsrc(B["d2"], 0, 0, -1, -1, 1)},
@@ -1447,6 +1481,8 @@ extern "C" int demfi_run_op(demfi_ctx* c, const demfi_op* op, void* stream)
         if (op->conv < 0 || op->conv >= (int)c->descs.size()) return demfi_set_error(DEMFI_ERR_ARG, "demfi_run_op: descriptor index");
         return demfi_conv2d(&c->descs[op->conv], (const demfi_conv*)(c->base + c->desc_off) + op->conv, stream);
     case DEMFI_OP_PACK:
+        if (op->bt.nb > 1)
+            return demfi_pack_planes_batched((const float* const*)op->p, op->nch, op->o.ptr, c->dtype, op->o.sx, H, W, &op->bt, stream);
         return demfi_pack_planes((const float* const*)op->p, op->nch, op->o.ptr, c->dtype, op->o.sx, H, W, stream);
     case DEMFI_OP_S2D:
         return demfi_space_to_depth((const float*)op->p[0], (void*)op->p[1], c->dtype, H, W, stream);
@@ -1461,9 +1497,15 @@ extern "C" int demfi_run_op(demfi_ctx* c, const demfi_op* op, void* stream)
     case DEMFI_OP_GATE:
         return demfi_gate_blend((const float*)op->p[0], &op->a, &op->b, &op->o, op->nch, H, W, stream);
     case DEMFI_OP_CFR:
+        if (op->bt.nb > 1)
+            return demfi_cfr_flow_align_batched((const float*)op->p[0], (const float*)op->p[1], (const float*)op->t, H, W, (int64_t*)op->p[2],
+                                                (float*)op->p[3], &op->bt, stream);
         return demfi_cfr_flow_align((const float*)op->p[0], (const float*)op->p[1], (const float*)op->t, H, W, (int64_t*)op->p[2],
                                     (float*)op->p[3], nullptr, stream);
     case DEMFI_OP_WARP:
+        if (op->bt.nb > 1)
+            return demfi_warp_blend_batched(&op->a, (const float*)op->p[0], &op->b, (const float*)op->p[1], (const float*)op->p[2],
+                                            (const float*)op->t, &op->o, op->nch, H, W, (float*)op->p[3], (void*)op->p[4], c->dtype, &op->bt, stream);
         if (op->p[4])
             return demfi_warp_blend_pack(&op->a, (const float*)op->p[0], &op->b, (const float*)op->p[1], (const float*)op->p[2],
                                          (const float*)op->t, &op->o, H, W, (float*)op->p[3], (void*)op->p[4], c->dtype, stream);

@@ -7,6 +7,9 @@
 
 namespace {
 
+// pointer of per-t context q in a batched launch: base + q * (byte stride); NULL stays NULL
+template <typename P> __device__ __forceinline__ P* bofs(P* p, int64_t bytes) { return p ? (P*)((const char*)p + bytes) : p; }
+
 constexpr int NT = 256;
 
 inline unsigned blocks_for(int64_t n) { return (unsigned)((n + NT - 1) / NT); }
@@ -110,10 +113,16 @@ __device__ __forceinline__ int cfr_target(const CfrSrc& s, int cidx, int y, int 
 __device__ __forceinline__ unsigned long long cfr_fix(float p) { return (unsigned long long)__double2ll_rn((double)p * FIX); }
 
 // One thread per SOURCE pixel and flow: debug index maps for every source, global accumulation for the far ones only.
+struct CfrBatch { int64_t f01, f10, t, acc, out; };          // byte strides between per-t contexts (blockIdx.y)
 __global__ void cfr_far_kernel(const float* __restrict__ flow01, const float* __restrict__ flow10,
                                const float* __restrict__ tptr, int H, int W, long long* __restrict__ acc,
-                               int* __restrict__ tile_flag, int* __restrict__ dbg)
+                               int* __restrict__ tile_flag, int* __restrict__ dbg, CfrBatch bt)
 {
+    {
+        const int q = blockIdx.y;
+        flow01 = bofs(flow01, q * bt.f01); flow10 = bofs(flow10, q * bt.f10); tptr = bofs(tptr, q * bt.t);
+        acc = bofs(acc, q * bt.acc); tile_flag = bofs(tile_flag, q * bt.acc);
+    }
     const int64_t hw = (int64_t)H * W;
     const int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x;
     if (i >= 2 * hw) return;
@@ -145,9 +154,14 @@ __global__ void cfr_far_kernel(const float* __restrict__ flow01, const float* __
 __global__ __launch_bounds__(NT) void cfr_tile_kernel(const float* __restrict__ flow01, const float* __restrict__ flow10,
                                                       const float* __restrict__ tptr, int H, int W,
                                                       long long* __restrict__ acc, int* __restrict__ tile_flag,
-                                                      float* __restrict__ out)
+                                                      float* __restrict__ out, CfrBatch bt)
 {
     __shared__ unsigned long long lacc[6][CFR_TH * CFR_TW];       // [flow k][img0, img1, weight] -> 48 KiB
+    {
+        const int q = blockIdx.y;
+        flow01 = bofs(flow01, q * bt.f01); flow10 = bofs(flow10, q * bt.f10); tptr = bofs(tptr, q * bt.t);
+        acc = bofs(acc, q * bt.acc); tile_flag = bofs(tile_flag, q * bt.acc); out = bofs(out, q * bt.out);
+    }
     const int64_t hw = (int64_t)H * W;
     const int tiles_x = (W + CFR_TW - 1) / CFR_TW;
     const int ntile = tiles_x * ((H + CFR_TH - 1) / CFR_TH);
@@ -345,6 +359,9 @@ __device__ __forceinline__ void store16(char* p, const float* v)
 // round trips (8 IEEE divisions + exp per warp pair): now each wave first computes the maps of 64 consecutive pixels
 // with ONE lane per pixel, parks them in a wave-private LDS record, and then walks the pixels LPP lanes at a time
 // (16 bytes of channels per lane): broadcast LDS reads, 8 unconditional 16-byte gathers, FMA accumulation.
+// Byte strides between the per-t contexts of a batched launch (demfi_batch): context q uses pointer + q * stride.
+struct WarpBatch { int nb; int64_t a, b, o, fa, fb, logit, t, occ, pack; };
+
 struct WarpRec {                    // 20 dwords per pixel
     int offa[4], offb[4];           // byte offsets of the 4 (clamped) corner records of the two warps
     float wa[4], wb[4];             // corner weights, out-of-bounds and invalid-mask already folded to 0
@@ -352,10 +369,10 @@ struct WarpRec {                    // 20 dwords per pixel
 };
 
 template <typename T, int ROWS = 4, bool NTS = false>      // ROWS: rows of the tile = waves of the workgroup; NTS: streaming output stores
-__global__ __launch_bounds__(ROWS * 64) void warp_blend_fat_kernel(demfi_view A, const float* __restrict__ fa, demfi_view B,
-                                      const float* __restrict__ fb, const float* __restrict__ logit,
-                                      const float* __restrict__ tptr, demfi_view O, int lpp_shift, int H, int W,
-                                      float* __restrict__ occ_out, int* __restrict__ dbg)
+__global__ __launch_bounds__(ROWS * 64) void warp_blend_fat_kernel(demfi_view A0, const float* __restrict__ fa0, demfi_view B0,
+                                      const float* __restrict__ fb0, const float* __restrict__ logit0,
+                                      const float* __restrict__ tptr0, demfi_view O0, int lpp_shift, int H, int W,
+                                      float* __restrict__ occ_out0, int* __restrict__ dbg, WarpBatch bt)
 {
     constexpr int N = Vec16<T>::N;
     __shared__ WarpRec recs[ROWS * 64];                           // 64 records per wave
@@ -378,6 +395,17 @@ __global__ __launch_bounds__(ROWS * 64) void warp_blend_fat_kernel(demfi_view A,
     const int pix0 = y * W + x0;                                   // first pixel of this wave
     const int nvalid = min(64, W - x0);
     WarpRec* wr = recs + wave * 64;
+    // Batched launch (bt.nb > 1): the per-t contexts are the INNERMOST loop of the tile -- the source rows the seven time instants of
+    // a window gather from are the same neighbourhood of F0 / F1 (flow_t scales with t), so after the first context they come
+    // from L1 / the XCD's L2 and the features are fetched from HBM once per window instead of once per time instant.
+    for (int q = 0; q < bt.nb; ++q) {
+    demfi_view A = A0, B = B0, O = O0;
+    A.ptr = bofs((char*)A0.ptr, q * bt.a); B.ptr = bofs((char*)B0.ptr, q * bt.b); O.ptr = bofs((char*)O0.ptr, q * bt.o);
+    const float* __restrict__ fa = bofs(fa0, q * bt.fa);
+    const float* __restrict__ fb = bofs(fb0, q * bt.fb);
+    const float* __restrict__ logit = bofs(logit0, q * bt.logit);
+    const float* __restrict__ tptr = bofs(tptr0, q * bt.t);
+    float* __restrict__ occ_out = bofs(occ_out0, q * bt.occ);
     // ---- phase 1: one lane per pixel -------------------------------------------------------------------
     {
         const int pix = pix0 + lane;
@@ -484,6 +512,9 @@ __global__ __launch_bounds__(ROWS * 64) void warp_blend_fat_kernel(demfi_view A,
         if (it + 2 < lpp) issue(it + 2, ra0, rb0, r0);
         finish(it + 1, ra1, rb1, r1);
     }
+    __builtin_amdgcn_wave_barrier();                              // the records are rewritten for the next context
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
 }
 
 // Thin (any strides) warp+blend, one thread per pixel, loops over C channels (C = 3 frames).
@@ -493,11 +524,18 @@ __global__ __launch_bounds__(ROWS * 64) void warp_blend_fat_kernel(demfi_view A,
 __global__ void warp_blend_thin_kernel(demfi_view A, const float* __restrict__ fa, demfi_view B,
                                        const float* __restrict__ fb, const float* __restrict__ logit,
                                        const float* __restrict__ tptr, demfi_view O, int C, int H, int W,
-                                       float* __restrict__ occ_out, int* __restrict__ dbg, void* __restrict__ pack8, int pack_f32)
+                                       float* __restrict__ occ_out, int* __restrict__ dbg, void* __restrict__ pack8, int pack_f32,
+                                       WarpBatch bt)
 {
     const int64_t hw = (int64_t)H * W;
     const int64_t pix = (int64_t)blockIdx.x * NT + threadIdx.x;
     if (pix >= hw) return;
+    {                                                             // batched launch: blockIdx.y = per-t context
+        const int q = blockIdx.y;
+        A.ptr = bofs((char*)A.ptr, q * bt.a); B.ptr = bofs((char*)B.ptr, q * bt.b); O.ptr = bofs((char*)O.ptr, q * bt.o);
+        fa = bofs(fa, q * bt.fa); fb = bofs(fb, q * bt.fb); logit = bofs(logit, q * bt.logit); tptr = bofs(tptr, q * bt.t);
+        occ_out = bofs(occ_out, q * bt.occ); pack8 = bofs((char*)pack8, q * bt.pack);
+    }
     const int y = (int)(pix / W), x = (int)(pix - (int64_t)y * W);
     bool va, vb;
     const SampleMap ma = bwarp_map(x, y, fa[pix], fa[hw + pix], H, W, va);
@@ -591,22 +629,24 @@ __global__ void gate_blend_kernel(const float* __restrict__ w, demfi_view S, dem
 // Gather up to 32 planar fp32 channels (flows, logits, frames) into an NHWC slice of the path dtype, so that the
 // consuming convolution stages them with 16-byte vector loads instead of element-wise "thin" loads.
 struct PackArgs { const float* plane[32]; };
+struct PackBatch { int64_t plane[32]; int64_t dst; };          // byte strides between per-t contexts (blockIdx.y)
 
 template <typename T>
-__global__ void pack_planes_kernel(PackArgs a, int nch8, T* __restrict__ dst, int64_t dst_sx, int hw)
+__global__ void pack_planes_kernel(PackArgs a, int nch8, T* __restrict__ dst, int64_t dst_sx, int hw, PackBatch bt)
 {
     constexpr int G = 16 / sizeof(T);                  // channels per 16-byte store
     const int i = blockIdx.x * NT + threadIdx.x;
     const int ngrp = nch8 * 8 / G;
     if (i >= hw * ngrp) return;
+    const int q = blockIdx.y;                           // batched launch: per-t context
     const int g = i / hw, pix = i - g * hw;            // pixel fastest: plane reads coalesce
     float v[G];
 #pragma unroll
     for (int j = 0; j < G; ++j) {
-        const float* p = a.plane[g * G + j];
+        const float* p = bofs(a.plane[g * G + j], q * bt.plane[g * G + j]);
         v[j] = p ? p[pix] : 0.0f;
     }
-    store16<T>((char*)(dst + (int64_t)pix * dst_sx + g * G), v);
+    store16<T>((char*)(dst + (int64_t)pix * dst_sx + g * G) + q * bt.dst, v);
 }
 
 // ---- uint8 frame I/O of the boundary caller --------------------------------------------
@@ -764,29 +804,52 @@ extern "C" int demfi_cfr_reset(int64_t* acc, int H, int W, void* stream)
     return DEMFI_OK;
 }
 
-extern "C" int demfi_cfr_flow_align(const float* flow01, const float* flow10, const float* t, int H, int W,
-                                    int64_t* acc, float* out, int32_t* dbg_idx, void* stream)
+static int cfr_impl(const float* flow01, const float* flow10, const float* t, int H, int W, int64_t* acc, float* out, int32_t* dbg_idx,
+                    const demfi_batch* bt, void* stream)
 {
     if (!flow01 || !flow10 || !t || !acc || !out || H <= 0 || W <= 0 || (int64_t)H * W >= (1ll << 31))
         return demfi_set_error(DEMFI_ERR_ARG, "demfi_cfr_flow_align: bad args");
+    const int nb = bt && bt->nb > 1 ? bt->nb : 1;
+    if (nb > 1 && dbg_idx) return demfi_set_error(DEMFI_ERR_ARG, "demfi_cfr_flow_align_batched: no debug maps in a batched launch");
+    CfrBatch cb = {0, 0, 0, 0, 0};
+    if (nb > 1) { cb.f01 = bt->p[0]; cb.f10 = bt->p[1]; cb.t = bt->t; cb.acc = bt->p[2]; cb.out = bt->p[3]; }
     hipStream_t st = (hipStream_t)stream;
     const int64_t hw = (int64_t)H * W;
     int* tile_flag = (int*)(acc + 6 * hw);                       // behind the six int64 planes (demfi_cfr_workspace_bytes)
-    hipLaunchKernelGGL(cfr_far_kernel, dim3(blocks_for(2 * hw)), dim3(NT), 0, st, flow01, flow10, t, H, W,
-                       (long long*)acc, tile_flag, dbg_idx);
+    hipLaunchKernelGGL(cfr_far_kernel, dim3(blocks_for(2 * hw), nb), dim3(NT), 0, st, flow01, flow10, t, H, W,
+                       (long long*)acc, tile_flag, dbg_idx, cb);
     const int ntile = ((W + CFR_TW - 1) / CFR_TW) * ((H + CFR_TH - 1) / CFR_TH);
-    hipLaunchKernelGGL(cfr_tile_kernel, dim3(8 * ((ntile + 7) / 8)), dim3(NT), 0, st, flow01, flow10, t, H, W,
-                       (long long*)acc, tile_flag, out);
+    hipLaunchKernelGGL(cfr_tile_kernel, dim3(8 * ((ntile + 7) / 8), nb), dim3(NT), 0, st, flow01, flow10, t, H, W,
+                       (long long*)acc, tile_flag, out, cb);
     DEMFI_HIP_CHECK(hipGetLastError());
     return DEMFI_OK;
 }
 
+extern "C" int demfi_cfr_flow_align(const float* flow01, const float* flow10, const float* t, int H, int W,
+                                    int64_t* acc, float* out, int32_t* dbg_idx, void* stream)
+{
+    return cfr_impl(flow01, flow10, t, H, W, acc, out, dbg_idx, nullptr, stream);
+}
+
+extern "C" int demfi_cfr_flow_align_batched(const float* flow01, const float* flow10, const float* t, int H, int W, int64_t* acc,
+                                            float* out, const demfi_batch* bt, void* stream)
+{
+    if (!bt || bt->nb < 1 || bt->nb > 64) return demfi_set_error(DEMFI_ERR_ARG, "demfi_cfr_flow_align_batched: batch description");
+    return cfr_impl(flow01, flow10, t, H, W, acc, out, nullptr, bt, stream);
+}
+
 static int warp_blend_impl(const demfi_view* A, const float* fa, const demfi_view* B, const float* fb, const float* logit,
                            const float* t, const demfi_view* out, int C, int H, int W, float* occ_out, int32_t* dbg_maps,
-                           void* pack8, int pack_dtype, void* stream)
+                           void* pack8, int pack_dtype, void* stream, const demfi_batch* bt = nullptr)
 {
     if (!A || !B || !out || !A->ptr || !B->ptr || !out->ptr || !fa || !fb || !logit || !t || C <= 0 || H <= 0 || W <= 0)
         return demfi_set_error(DEMFI_ERR_ARG, "demfi_warp_blend: bad args");
+    WarpBatch wb = {1, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (bt && bt->nb > 1) {
+        if (dbg_maps) return demfi_set_error(DEMFI_ERR_ARG, "demfi_warp_blend_batched: no debug maps in a batched launch");
+        wb.nb = bt->nb; wb.a = bt->a; wb.b = bt->b; wb.o = bt->o; wb.fa = bt->p[0]; wb.fb = bt->p[1]; wb.logit = bt->p[2]; wb.t = bt->t;
+        wb.occ = bt->p[3]; wb.pack = bt->p[4];
+    }
     hipStream_t st = (hipStream_t)stream;
     const int64_t hw = (int64_t)H * W;
     const bool fat = A->sc == 1 && B->sc == 1 && out->sc == 1 && A->is_f32 == B->is_f32 && A->is_f32 == out->is_f32
@@ -807,7 +870,7 @@ static int warp_blend_impl(const demfi_view* A, const float* fa, const demfi_vie
         const unsigned nblk = 8u * (unsigned)((((W + 63) / 64) * ((H + rows - 1) / rows) + 7) / 8);
 #define DEMFI_WARP_LAUNCH(TT, R, N)                                                                                   \
         hipLaunchKernelGGL((warp_blend_fat_kernel<TT, R, N>), dim3(nblk), dim3(R * 64), 0, st, *A, fa, *B, fb, logit, t, *out, sh, H, W, \
-                           occ_out, dbg_maps)
+                           occ_out, dbg_maps, wb)
         if (f32) {
             if (var == 0) DEMFI_WARP_LAUNCH(float, 4, false); else if (var == 1) DEMFI_WARP_LAUNCH(float, 4, true);
             else if (var == 2) DEMFI_WARP_LAUNCH(float, 8, false); else DEMFI_WARP_LAUNCH(float, 8, true);
@@ -818,8 +881,8 @@ static int warp_blend_impl(const demfi_view* A, const float* fa, const demfi_vie
 #undef DEMFI_WARP_LAUNCH
     } else {
         if (pack8 && C != 3) return demfi_set_error(DEMFI_ERR_ARG, "demfi_warp_blend_pack: the packed record is defined for C == 3");
-        hipLaunchKernelGGL(warp_blend_thin_kernel, dim3(blocks_for(hw)), dim3(NT), 0, st, *A, fa, *B, fb, logit, t, *out, C,
-                           H, W, occ_out, dbg_maps, pack8, pack_dtype == DEMFI_F32 ? 1 : 0);
+        hipLaunchKernelGGL(warp_blend_thin_kernel, dim3(blocks_for(hw), wb.nb), dim3(NT), 0, st, *A, fa, *B, fb, logit, t, *out, C,
+                           H, W, occ_out, dbg_maps, pack8, pack_dtype == DEMFI_F32 ? 1 : 0, wb);
     }
     DEMFI_HIP_CHECK(hipGetLastError());
     return DEMFI_OK;
@@ -839,6 +902,15 @@ extern "C" int demfi_warp_blend_pack(const demfi_view* A, const float* fa, const
     if (!pack8 || (pack_dtype != DEMFI_F16 && pack_dtype != DEMFI_F32) || !A || A->sc == 1)
         return demfi_set_error(DEMFI_ERR_ARG, "demfi_warp_blend_pack: planar 3-channel views and a pack buffer expected");
     return warp_blend_impl(A, fa, B, fb, logit, t, out, 3, H, W, occ_out, nullptr, pack8, pack_dtype, stream);
+}
+
+extern "C" int demfi_warp_blend_batched(const demfi_view* A, const float* fa, const demfi_view* B, const float* fb, const float* logit,
+                                        const float* t, const demfi_view* out, int C, int H, int W, float* occ_out, void* pack8,
+                                        int pack_dtype, const demfi_batch* bt, void* stream)
+{
+    if (!bt || bt->nb < 1 || bt->nb > 64) return demfi_set_error(DEMFI_ERR_ARG, "demfi_warp_blend_batched: batch description");
+    if (pack8 && (pack_dtype != DEMFI_F16 && pack_dtype != DEMFI_F32)) return demfi_set_error(DEMFI_ERR_ARG, "demfi_warp_blend_batched: pack dtype");
+    return warp_blend_impl(A, fa, B, fb, logit, t, out, C, H, W, occ_out, nullptr, pack8, pack_dtype, stream, bt);
 }
 
 extern "C" int demfi_fgac_gather(const demfi_view* src, const float* flow, const demfi_view* out, int C, int H, int W,
@@ -879,25 +951,41 @@ extern "C" int demfi_gate_blend(const float* w, const demfi_view* source, const 
     return DEMFI_OK;
 }
 
-extern "C" int demfi_pack_planes(const float* const* planes, int nch, void* dst, int dtype, int64_t dst_pix_stride,
-                                 int H, int W, void* stream)
+static int pack_impl(const float* const* planes, int nch, void* dst, int dtype, int64_t dst_pix_stride, int H, int W,
+                     const demfi_batch* bt, void* stream)
 {
     if (!planes || !dst || nch <= 0 || nch > 32 || nch % 8 || H <= 0 || W <= 0)
         return demfi_set_error(DEMFI_ERR_ARG, "demfi_pack_planes: nch=%d must be a multiple of 8, <= 32", nch);
     PackArgs a;
-    for (int i = 0; i < 32; ++i) a.plane[i] = i < nch ? planes[i] : nullptr;
+    PackBatch pb;
+    const int nb = bt && bt->nb > 1 ? bt->nb : 1;
+    for (int i = 0; i < 32; ++i) { a.plane[i] = i < nch ? planes[i] : nullptr; pb.plane[i] = nb > 1 ? bt->p[i] : 0; }
+    pb.dst = nb > 1 ? bt->o : 0;
     const int hw = H * W;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == DEMFI_F16)
-        hipLaunchKernelGGL(pack_planes_kernel<half_t>, dim3(blocks_for((int64_t)hw * nch / 8)), dim3(NT), 0, st, a, nch / 8,
-                           (half_t*)dst, dst_pix_stride, hw);
+        hipLaunchKernelGGL(pack_planes_kernel<half_t>, dim3(blocks_for((int64_t)hw * nch / 8), nb), dim3(NT), 0, st, a, nch / 8,
+                           (half_t*)dst, dst_pix_stride, hw, pb);
     else if (dtype == DEMFI_F32)
-        hipLaunchKernelGGL(pack_planes_kernel<float>, dim3(blocks_for((int64_t)hw * nch / 4)), dim3(NT), 0, st, a, nch / 8,
-                           (float*)dst, dst_pix_stride, hw);
+        hipLaunchKernelGGL(pack_planes_kernel<float>, dim3(blocks_for((int64_t)hw * nch / 4), nb), dim3(NT), 0, st, a, nch / 8,
+                           (float*)dst, dst_pix_stride, hw, pb);
     else
         return demfi_set_error(DEMFI_ERR_ARG, "demfi_pack_planes: dtype");
     DEMFI_HIP_CHECK(hipGetLastError());
     return DEMFI_OK;
+}
+
+extern "C" int demfi_pack_planes(const float* const* planes, int nch, void* dst, int dtype, int64_t dst_pix_stride,
+                                 int H, int W, void* stream)
+{
+    return pack_impl(planes, nch, dst, dtype, dst_pix_stride, H, W, nullptr, stream);
+}
+
+extern "C" int demfi_pack_planes_batched(const float* const* planes, int nch, void* dst, int dtype, int64_t dst_pix_stride, int H, int W,
+                                         const demfi_batch* bt, void* stream)
+{
+    if (!bt || bt->nb < 1 || bt->nb > 64) return demfi_set_error(DEMFI_ERR_ARG, "demfi_pack_planes_batched: batch description");
+    return pack_impl(planes, nch, dst, dtype, dst_pix_stride, H, W, bt, stream);
 }
 
 extern "C" int demfi_u8_to_window(const uint8_t* const* frames, int h, int w, float* x, int H, int W, void* stream)

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DEMFI_ABI_VERSION 4
+#define DEMFI_ABI_VERSION 5
 
 enum demfi_dtype { DEMFI_F16 = 0, DEMFI_F32 = 1 };
 
@@ -228,6 +228,27 @@ int demfi_warp_blend_pack(const demfi_view* A, const float* fa, const demfi_view
                           const float* logit, const float* t, const demfi_view* out, int H, int W, float* occ_out,
                           void* pack8, int pack_dtype, void* stream);
 
+/* ---- batched point-wise launches (ABI v5): the same op for the nb per-t contexts of one trunk set in ONE launch ----------------
+ * The per-t buffers of a context set are laid out tensor-major (copy c of a buffer sits c * stride bytes behind copy 0), so a
+ * batched launch takes the pointers of context 0 plus one BYTE stride per pointer (0 = a window-level buffer every context shares:
+ * trunk features, flow_01 / flow_10).  Counterpart of the reference running its whole forward once per t (main.py:1121-1178):
+ * the t loop moves inside the kernel.  For the fat warp (Ft = blend of the two warped trunk feature maps, DeMFInet.py:66-71) the
+ * contexts are the INNERMOST loop of a tile, so F0 / F1 are fetched from HBM once per window instead of once per t. */
+typedef struct demfi_batch {
+    int32_t nb;            /* contexts in the launch; 0 or 1 = a plain launch                                              */
+    int32_t _pad;
+    int64_t a, b, o;       /* byte strides of the op's A / B / out views                                                   */
+    int64_t t;             /* ... of the device time instant                                                               */
+    int64_t p[32];         /* ... of the op's pointer arguments, in demfi_op.p order                                       */
+} demfi_batch;
+/* p order: fa, fb, logit, occ_out, pack8 (demfi_op of kind WARP) */
+int demfi_warp_blend_batched(const demfi_view* A, const float* fa, const demfi_view* B, const float* fb, const float* logit,
+                             const float* t, const demfi_view* out, int C, int H, int W, float* occ_out, void* pack8,
+                             int pack_dtype, const demfi_batch* bt, void* stream);
+/* p order: flow01, flow10, acc, out (kind CFR) */
+int demfi_cfr_flow_align_batched(const float* flow01, const float* flow10, const float* t, int H, int W, int64_t* acc, float* out,
+                                 const demfi_batch* bt, void* stream);
+
 /* bilinear_sampler at ABSOLUTE flow coordinates (FGAC, DeMFInet.py:413-419, 499-514; rr = sr = 0):
  * src, out fat views with C channels; flow planar fp32 [2,H,W]. */
 int demfi_fgac_gather(const demfi_view* src, const float* flow, const demfi_view* out, int C, int H,
@@ -255,6 +276,9 @@ int demfi_gate_blend(const float* w, const demfi_view* source, const demfi_view*
  * dst_pix_stride in elements. */
 int demfi_pack_planes(const float* const* planes, int nch, void* dst, int dtype, int64_t dst_pix_stride,
                       int H, int W, void* stream);
+/* batched over contexts: bt->p[i] = byte stride of plane i, bt->o = byte stride of dst */
+int demfi_pack_planes_batched(const float* const* planes, int nch, void* dst, int dtype, int64_t dst_pix_stride, int H, int W,
+                              const demfi_batch* bt, void* stream);
 
 /* uint8 frame I/O of the boundary caller.
  * demfi_u8_to_window: frames = HOST array of 4 device pointers to BGR uint8 [h,w,3] images in the module's frame order
@@ -359,6 +383,7 @@ typedef struct demfi_op {
                                CFR: flow01, flow10, acc, out; S2D / OVERLAY: x, out; all: t where needed  */
     const void* t;          /* device fp32 time instant (CFR, WARP)                                      */
     char name[64];
+    demfi_batch bt;         /* batched plan: nb > 1 = ONE launch for the nb per-t contexts (CFR, WARP, PACK)   */
 } demfi_op;
 
 int     demfi_ctx_create(int H, int W, int max_updates, int dtype, const demfi_hparams* hp /* NULL = defaults */,

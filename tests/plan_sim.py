@@ -150,11 +150,33 @@ class PlanSim:
     def planes(self, ptr, n, H, W):
         return self.strided(L.View(ptr, 1, W, H * W, 0, 1, 0), n, H, W)
 
+    @staticmethod
+    def expand(op):
+        """A batched point-wise op (demfi_op.bt.nb > 1: one launch for all per-t contexts) as its nb per-context ops."""
+        nb = int(op.bt.nb)
+        if nb <= 1:
+            return [op]
+        out = []
+        for q in range(nb):
+            o = L.Op.from_buffer_copy(bytes(op))
+            o.bt.nb = 1
+            for name, st in (('a', op.bt.a), ('b', op.bt.b), ('o', op.bt.o)):
+                v = getattr(o, name)
+                if v.ptr:
+                    v.ptr = v.ptr + q * st
+            if o.t:
+                o.t = o.t + q * op.bt.t
+            for i in range(32):
+                if o.p[i]:
+                    o.p[i] = o.p[i] + q * op.bt.p[i]
+            out.append(o)
+        return out
+
     def run(self, ops):
         e = self.e
         H, W = e.H, e.W
         f32 = e.f32
-        for op in ops:
+        for op in [x for big in ops for x in self.expand(big)]:
             k = op.kind
             if k == 0:
                 self.conv(e.conv_desc(op.conv))

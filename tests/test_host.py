@@ -41,7 +41,8 @@ def test_library_exports_every_declared_symbol():
     lib = L.load()
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.demfi_abi_version() == L.ABI_VERSION == 4
+    assert lib.demfi_abi_version() == L.ABI_VERSION == 5
+    assert C.sizeof(L.Batch) == 8 + 4 * 8 + 32 * 8
     assert C.sizeof(L.View) == 48 and C.sizeof(L.Piece) == 64 and C.sizeof(L.Chunk) == 24 and C.sizeof(L.Seg) == 168
 
 
@@ -203,10 +204,15 @@ def test_batched_per_t_plan_equals_per_context_plans(synthetic_sd, dtype):
         for k, v in want[c].items():
             assert torch.equal(eng._ctxs[0][c][k], v), (c, k)
     assert not torch.equal(want[0]['finals'], want[1]['finals'])
-    # one launch per convolution for all contexts, NC launches per point-wise op
-    from demfi_amd.engine import SEG_HEAD, SEG_TB_HEAD
+    # one launch per convolution for all contexts (batch dimension); CFR and the thin warps also ONE launch (demfi_batch, ABI v5:
+    # pointers of context 0 + one byte stride per pointer, 0 for window-level buffers); fat warp and plane packs NC launches
+    from demfi_amd.engine import SEG_HEAD, SEG_TB_HEAD, SEG_TB_ITER
     one, tb = eng.ops(SEG_HEAD), eng.ops(SEG_TB_HEAD)
-    n_conv = sum(1 for o in one if o.kind == 0)
-    assert len(tb) == n_conv + NC * (len(one) - n_conv)
+    n_single = sum(1 for o in one if o.kind == 0 or o.kind == 6)
+    assert len(tb) == n_single + NC * (len(one) - n_single)
+    cfr = [o for o in tb if o.kind == 6]
+    assert len(cfr) == 1 and cfr[0].bt.nb == NC and cfr[0].bt.p[0] == 0 and cfr[0].bt.p[3] > 0 and cfr[0].bt.t > 0   # flows shared, outputs strided
+    thin = [o for o in eng.ops(SEG_TB_ITER, it=0) if o.kind == 7]
+    assert len(thin) == 1 and thin[0].nch == 3 and thin[0].bt.nb == NC and thin[0].bt.o > 0
     d1 = [o for o in tb if o.name.decode() == 'Dec_first'][0]
     assert eng.conv_desc(d1.conv).batch == 3 * NC

@@ -24,12 +24,57 @@ import tools.conv_probe as P                             # noqa: E402
 WGS, WAVES, TILES, STAMPS = 32, 10, 24, 6
 
 
+def trace_plan_op(name, lib):
+    """op:<name> -- one launch of a named op of the batched 720p plan (736x1280, fp16, N_tst = 3, 7 contexts), with the buffers
+    a real window left behind.  Works for every persistent kernel that carries stamps (64->64 and narrow kernels)."""
+    from demfi_amd import DeMFInet, HyperParams, synthetic_state_dict, synthetic_window
+    from demfi_amd.engine import SEG_TB_HEAD, SEG_TB_ITER, SEG_TRUNK
+    from demfi_amd.runner import WindowRunner
+    m = DeMFInet(HyperParams(), dtype=torch.float16)
+    m.load_state_dict(synthetic_state_dict(0))
+    m = m.to(P.DEV).eval()
+    r = WindowRunner(m, 720, 1280, n_tst=3, mfi=8, n_trunk=1)
+    r.run_window(synthetic_window(720, 1280, 3).to(P.DEV))
+    torch.cuda.synchronize()
+    e = r.engine
+    ops = e.ops(SEG_TRUNK) + e.ops(SEG_TB_HEAD) + [o for it in range(3) for o in e.ops(SEG_TB_ITER, it=it)]
+    op = [o for o in ops if o.name.decode() == name][0]
+    st = torch.cuda.current_stream().cuda_stream
+    buf = np.zeros(WGS * WAVES * TILES * STAMPS, np.uint64)
+    e.run_op(op, st)
+    torch.cuda.synchronize()
+    L.check(lib.demfi_trace_dump(buf.ctypes.data, buf.size))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    e.run_op(op, st)
+    e1.record()
+    e1.synchronize()
+    L.check(lib.demfi_trace_dump(buf.ctypes.data, buf.size))
+    tr = buf.reshape(WGS, WAVES, TILES, STAMPS).astype(np.int64)
+    lo, hi = 4, 20
+    print('op %s : launch %.4f ms' % (name, e0.elapsed_time(e1)))
+    period = (tr[:, 0, hi, 1] - tr[:, 0, lo, 1]) / float(hi - lo)
+    print('  period (release to release, wave 0): mean %.0f cycles  (min %.0f max %.0f)' % (period.mean(), period.min(), period.max()))
+    for w in range(WAVES):
+        t, nxt = tr[:, w, lo:hi, :], tr[:, w, lo + 1:hi + 1, :]
+        if not t[..., 1].any():
+            continue
+        if w < 4:
+            print('  MFMA wave %d   wait at barrier %6.0f | MFMA phase %6.0f | epilogue %6.0f | to next barrier arrival %6.0f' %
+                  (w, (t[..., 1] - t[..., 0]).mean(), (t[..., 2] - t[..., 1]).mean(), (t[..., 3] - t[..., 2]).mean(), (nxt[..., 0] - t[..., 3]).mean()))
+        else:
+            print('  DMA wave %d    landed -> released %6.0f | issue of the next tile(s) %6.0f | issued -> landed %6.0f' %
+                  (w - 4, (t[..., 1] - t[..., 0]).mean(), (t[..., 2] - t[..., 1]).mean(), (nxt[..., 0] - t[..., 2]).mean()))
+
+
 def main():
     case = sys.argv[1] if len(sys.argv) > 1 else 'c3x3'
     batch = int(sys.argv[2]) if len(sys.argv) > 2 else 3
     lib = L.load()
     lib.demfi_trace_dump.restype = C.c_int
     lib.demfi_trace_dump.argtypes = [C.c_void_p, C.c_int64]
+    if case.startswith('op:'):
+        return trace_plan_op(case[3:], lib)
     pl = Plan(P.H, P.W, torch.float16, P.DEV)
     P.conv_case(pl, case, 64, 64, 3, 3, batch, res=(case == 'c3x3res'), act=L.ACT_NONE if case == 'c3x3res' else L.ACT_RELU)
     pl._upload()

@@ -1,5 +1,5 @@
 """GPU-box helper: rocprofv3 PMC passes (separate runs, --kernel-trace only) of the probes of the two roofline kernels and
-a JSON summary for bench.py (profiles/r02_pmc_traffic.json).
+a JSON summary for bench.py (profiles/r03_pmc_traffic.json).
 
     python tools/pmc_traffic.py <outdir>
 
@@ -38,7 +38,7 @@ def run(case, outdir, env=None):
                 acc[k][r['Counter_Name']] += float(r['Counter_Value'])
                 disp[k].add(r['Dispatch_Id'])
             for k, v in acc.items():
-                if 'persist' in k or 'warp_blend_fat' in k or 'cfr_' in k:
+                if 'persist' in k or 'c64_stg' in k or 'warp_blend_fat' in k or 'cfr_' in k:
                     n = len(disp[k])
                     res.setdefault(k, {}).update({c: x / n for c, x in v.items()})
                     res[k]['dispatches'] = n
@@ -92,8 +92,8 @@ def main():
 
     def hbm(entry):
         return 2 * entry.get('FETCH_SIZE', 0) * 1024 + entry.get('WRITE_SIZE', 0) * 1024
-    conv = [v for k, v in summary['c3x3'].items() if 'persist' in k]
-    convr = [v for k, v in summary['c3x3res'].items() if 'persist' in k]
+    conv = [v for k, v in summary['c3x3'].items() if 'persist' in k or 'c64_stg' in k]
+    convr = [v for k, v in summary['c3x3res'].items() if 'persist' in k or 'c64_stg' in k]
     warp = [v for k, v in summary['warp'].items() if 'warp_blend_fat' in k]
     out = {'source': 'rocprofv3 --pmc (separate passes) of tools/conv_probe.py c3x3 / c3x3res / warp at 736x1280 fp16 batch 3, '
                      'post-ReLU-like activations; 2 x FETCH_SIZE + WRITE_SIZE (KiB), gfx950 correction',
@@ -110,8 +110,8 @@ def main():
     # the batched per-t plan launches the same kernel over batch 3 x 7 time instants = 21 images
     big = {c: run(c, os.path.join(outdir, 'b21'), {'PROBE_DATA': 'relu', 'PROBE_B': '21'}) for c in ('c3x3', 'c3x3res')}
     summary['c3x3_b21'], summary['c3x3res_b21'] = big['c3x3'], big['c3x3res']
-    cb = [v for k, v in big['c3x3'].items() if 'persist' in k]
-    cbr = [v for k, v in big['c3x3res'].items() if 'persist' in k]
+    cb = [v for k, v in big['c3x3'].items() if 'persist' in k or 'c64_stg' in k]
+    cbr = [v for k, v in big['c3x3res'].items() if 'persist' in k or 'c64_stg' in k]
     if cb and cbr:
         out['dominant_traffic_bytes_b21'] = (hbm(cb[0]) + hbm(cbr[0])) / 2
         out['dominant_algorithmic_bytes_b21'] = 7 * (723.5e6 + 1085.2e6) / 2
@@ -125,7 +125,7 @@ def main():
     if wk:
         out['warp_traffic_bytes_probe_white_noise'] = out.get('warp_traffic_bytes')
         out['warp_traffic_bytes'] = wk[0]['hbm_bytes_per_launch']             # the network's own flows, in sequence
-    json.dump(out, open(os.path.join(outdir, 'r02_pmc_traffic.json'), 'w'), indent=1)
+    json.dump(out, open(os.path.join(outdir, 'r03_pmc_traffic.json'), 'w'), indent=1)
     print(json.dumps({k: v for k, v in out.items() if k not in ('raw', 'in_network')}, indent=1))
     for k, v in sorted(innet.items(), key=lambda kv: -kv[1]['hbm_bytes_per_launch'])[:14]:
         print('%-52s %8.1f MB/launch  L2 hit %.2f  (%d launches)' % (k[:52], v['hbm_bytes_per_launch'] / 1e6, v['l2_hit'], v['dispatches']))
