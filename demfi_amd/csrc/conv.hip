@@ -1814,7 +1814,9 @@ __device__ __forceinline__ void sep_mfma_waves(const demfi_conv* __restrict__ d,
     }
     const char* const wl = wlds + lane * 16;
     int ub = 0;                                                 // ring slot of the next unit
+    [[maybe_unused]] int trk = -1;
     for (int it = a.t_first; it < a.t_end; it += a.t_step) {
+        ++trk;
         int bimg, os0, ol0;
         sep_item_coords(a, it, bimg, os0, ol0);
         // h (and z) of this tile: unconditional clamped loads issued before the MFMA phases (see the 3x3 kernel)
@@ -1849,7 +1851,11 @@ __device__ __forceinline__ void sep_mfma_waves(const demfi_conv* __restrict__ d,
             constexpr int q = decltype(Q_)::value;              // unit q: channels 32q .. 32q+31 of the 128
             // unit q of this tile is in ring slot ub (the DMA wave waited for it); raw barrier: nothing of this wave
             // has to drain (its stores and aux loads stay in flight)
+            if constexpr (q == 0) TRACE_STAMP(wave, trk, 0);
+            if constexpr (q == 2) TRACE_STAMP(wave, trk, 4);    // arrival at the third unit's barrier
             asm volatile("s_barrier" ::: "memory");
+            if constexpr (q == 0) TRACE_STAMP(wave, trk, 1);
+            if constexpr (q == 2) TRACE_STAMP(wave, trk, 5);
             const char* tb = tbuf + ub * S_BUF_BYTES + (wave * 2) * (S_LL * 64);
             ub = (ub + 1) & (S_NBUF - 1);
             auto load_tap = [&](FragSet<NCO>& f, int tap) {
@@ -1903,6 +1909,11 @@ __device__ __forceinline__ void sep_mfma_waves(const demfi_conv* __restrict__ d,
             mma_tap(f0);
             __builtin_amdgcn_sched_barrier(0);
         });
+#if defined(DEMFI_TRACE) && defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+        for (int s = 0; s < NCO; ++s) { asm volatile("" ::"v"(acc[s][0])); asm volatile("" ::"v"(acc[s][1])); }
+        TRACE_STAMP(wave, trk, 2);
+#endif
         // ---- register epilogue ----
         if constexpr (VAR == 1) {
 #pragma unroll
@@ -1962,6 +1973,7 @@ __device__ __forceinline__ void sep_mfma_waves(const demfi_conv* __restrict__ d,
                 }
             }
         }
+        TRACE_STAMP(wave, trk, 3);
     }
 }
 
@@ -2078,9 +2090,12 @@ __global__ __launch_bounds__(NT + 64 * S_NDMA, 1) void conv_sep5_c128_persist_ke
             if (u + 2 < n_units)      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * S_NI / S_NDMA) : "memory");
             else if (u + 1 < n_units) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(S_NI / S_NDMA) : "memory");
             else                      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if ((u & 3) == 0) TRACE_STAMP(wave, u >> 2, 0);
             __syncthreads();                                    // hand unit u to the MFMA waves
+            if ((u & 3) == 0) TRACE_STAMP(wave, u >> 2, 1);
             // ring slot of unit u+3 = slot of unit u-1: every MFMA wave finished reading it before reaching this barrier
             if (VAR != 3 && u + 3 < n_units) issue_unit(u + 3);
+            if ((u & 3) == 0) TRACE_STAMP(wave, u >> 2, 2);
         }
         return;
     }

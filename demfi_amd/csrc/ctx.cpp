@@ -464,9 +464,10 @@ void alloc_t(Layout& L, BufSet& s)
     L.fat(s, "frec0", H, W, 64);
     L.fat(s, "frec1", H, W, 64);
     L.fat(s, "re1", H, W, 32);
-    L.fat(s, "ref_enc", H, W, 32);
+    // Mixer.conv_ref2 | conv_delta2 outputs as the two 32-channel halves of ONE 64-channel buffer: conv_blend1 (cat[ref, delta],
+    // DeMFInet.py:826-827) then stages a single 128-byte record per pixel (the narrow kernel's fast DMA path) instead of two pieces
+    L.fat(s, "rd64", H, W, 64);
     L.fat(s, "de1", H, W, 32);
-    L.fat(s, "de2", H, W, 32);
     L.fat(s, "bl1", H, W, 32);
     L.fat(s, "xb", H, W, 64);
     L.fat(s, "zb", H, W, 64);
@@ -479,7 +480,7 @@ void alloc_t(Layout& L, BufSet& s)
     if (L.c->dtype == DEMFI_F16) { L.fat(s, "ref16", H, W, 16); L.fat(s, "agg16", H, W, 16); }     // per-t planes only (fp16 plan)
     else { L.fat(s, "ref32", H, W, 32); L.fat(s, "agg3s", H, W, 32); }
     L.fat(s, "agg3d", H, W, 8);
-    L.fat(s, "delta8", H, W, 8);
+    L.fat(s, "delta16", H, W, 16);               // 5 flow / occlusion planes + 11 zero channels: a full 32-byte record (one DMA piece)
     L.fat(s, "g_a", H, W, 64);
     L.fat(s, "g_t", H, W, 64);
     L.fat(s, "g_b", H, W, 64);
@@ -1080,7 +1081,7 @@ struct Builder {
             for (int i = 87; i < 99; ++i) agg3s_cin.push_back(i);
             agg3s_cin.insert(agg3s_cin.end(), 5, -1);
         }
-        conv(th, p + "Mixer.conv_ref2", {fsrc(B["re1"], 0)}, {D(fview(B["ref_enc"]), range(0, 32), R)}, H, W);
+        conv(th, p + "Mixer.conv_ref2", {fsrc(B["re1"], 0)}, {D(fview(B["rd64"], 0), range(0, 32), R)}, H, W);
         // Dec_first_2 = relu(conv3x3(Agg3)) with Agg3 = cat[F_rec (64, changes per recursion) | 27 recursion-invariant planes |
         // 8 planes of the current recursion] (DeMFInet.py:151-157), split by linearity in the fp16 plan (see below).
         const std::vector<int32_t> a3d_sel = {6, 7, 8, 82, 83, 84, 85, 86};
@@ -1119,13 +1120,13 @@ struct Builder {
             {
                 std::vector<const float*> pl;
                 for (int i = 0; i < 5; ++i) pl.push_back(delta_p(it, i));
-                pack(sg, pl, B["delta8"]);
+                pack(sg, pl, B["delta16"]);
                 std::vector<int32_t> m = range(0, 5);
-                m.insert(m.end(), 3, -1);
-                conv(sg, p + "Mixer.conv_delta1", {fsrc_map(B["delta8"], m)}, {D(fview(B["de1"]), range(0, 32), R)}, H, W);
+                m.insert(m.end(), 11, -1);
+                conv(sg, p + "Mixer.conv_delta1", {fsrc_map(B["delta16"], m)}, {D(fview(B["de1"]), range(0, 32), R)}, H, W);
             }
-            conv(sg, p + "Mixer.conv_delta2", {fsrc(B["de1"], 0)}, {D(fview(B["de2"]), range(0, 32), R)}, H, W);
-            conv(sg, p + "Mixer.conv_blend1", {fsrc(B["ref_enc"], 0), fsrc(B["de2"], 32)}, {D(fview(B["bl1"]), range(0, 32), R)}, H, W);
+            conv(sg, p + "Mixer.conv_delta2", {fsrc(B["de1"], 0)}, {D(fview(B["rd64"], 32), range(0, 32), R)}, H, W);
+            conv(sg, p + "Mixer.conv_blend1", {fsrc(B["rd64"], 0)}, {D(fview(B["bl1"]), range(0, 32), R)}, H, W);
             conv(sg, p + "Mixer.conv_blend2", {fsrc(B["bl1"], 0)}, {D(fview(B["xb"]), range(0, 64), R)}, H, W);
             const Tensor* h = &hin;
             for (int s = 0; s < 2; ++s) {
