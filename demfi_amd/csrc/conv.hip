@@ -918,6 +918,23 @@ __device__ __forceinline__ float res_mix_hi(unsigned a, float c)
 #endif
     return d;
 }
+// c - (fp16 half of a packed pair) in one VALU op (no v_cvt_f32_f16): the GRU update's tanh(.) - h
+__device__ __forceinline__ float sub_mix_lo(float c, unsigned a)
+{
+    float d = 0.0f;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(a), "v"(c));
+#endif
+    return d;
+}
+__device__ __forceinline__ float sub_mix_hi(float c, unsigned a)
+{
+    float d = 0.0f;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(a), "v"(c));
+#endif
+    return d;
+}
 #ifndef DEMFI_STG_RES_AT
 #define DEMFI_STG_RES_AT 2                                       // k-loop third after which the residual loads are issued (-1: before barrier A)
 #endif
@@ -1773,6 +1790,10 @@ constexpr int S_LDS_BYTES = S_WBYTES + S_NBUF * S_BUF_BYTES + 1024;   // + bias
 static_assert(TH * S_LL % 16 == 0, "unit buffer must be a whole number of DMA instructions");
 static_assert(3 * S_NI <= 63, "three units in flight must be countable in vmcnt");
 enum { SEP_SIG = 0, SEP_MUL = 1, SEP_GRU = 2 };
+#ifndef DEMFI_SEP_GRU_PREFETCH_UNIT
+#define DEMFI_SEP_GRU_PREFETCH_UNIT 1
+#endif
+constexpr int SEP_GRU_PREFETCH_UNIT = DEMFI_SEP_GRU_PREFETCH_UNIT;
 
 struct SepArgs {
     int t_first, t_end, t_step, nh_shift, cb;
@@ -1821,7 +1842,8 @@ __device__ __forceinline__ void sep_mfma_waves(const demfi_conv* __restrict__ d,
         sep_item_coords(a, it, bimg, os0, ol0);
         // h (and z) of this tile: unconditional clamped loads issued before the MFMA phases (see the 3x3 kernel)
         u4_t rreg[NCO][2][2] = {}, zreg[NCO][2][2] = {};
-        if constexpr (EPI != SEP_SIG && VAR != 4 && VAR != 1) {
+        auto prefetch_aux = [&]() {
+          if constexpr (EPI != SEP_SIG && VAR != 4 && VAR != 1) {
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
                 const int os = min(os0 + wave * 2 + p, Slen - 1), ol = min(ol0 + lx, Llen - 1);
@@ -1840,7 +1862,12 @@ __device__ __forceinline__ void sep_mfma_waves(const demfi_conv* __restrict__ d,
                     }
                 }
             }
-        }
+          }
+        };
+        // GRU update (16 loads): issued inside the MFMA phase, behind the second unit's barrier -- before the phase they queue
+        // behind the previous tile's stores in the CU's memory pipe and the wave spends ~3 000 cycles issuing them
+        // (profiles/r03_phase_trace_gru.txt); r * h (8 loads, no stall measured): before the phase as ever
+        if constexpr (EPI != SEP_GRU) prefetch_aux();
         f16x_t acc[NCO][2];
 #pragma unroll
         for (int s = 0; s < NCO; ++s) {
@@ -1858,6 +1885,10 @@ __device__ __forceinline__ void sep_mfma_waves(const demfi_conv* __restrict__ d,
             if constexpr (q == 2) TRACE_STAMP(wave, trk, 5);
             const char* tb = tbuf + ub * S_BUF_BYTES + (wave * 2) * (S_LL * 64);
             ub = (ub + 1) & (S_NBUF - 1);
+            if constexpr (EPI == SEP_GRU && q == SEP_GRU_PREFETCH_UNIT) {
+                prefetch_aux();
+                __builtin_amdgcn_sched_barrier(0);
+            }
             auto load_tap = [&](FragSet<NCO>& f, int tap) {
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
@@ -1943,28 +1974,31 @@ __device__ __forceinline__ void sep_mfma_waves(const demfi_conv* __restrict__ d,
                 const f4_t b1 = *(const f4_t*)(bias_lds + s * 32 + (2 * m2 + 1) * 8 + hi * 4);
 #pragma unroll
                 for (int p = 0; p < 2; ++p) {
+                    // the bias in LDS is pre-multiplied by the exponent's scale K (see the kernel): 2^(K acc + K b) is one fma + v_exp_f32
+                    constexpr float K = EPI == SEP_GRU ? 2.8853900817779268f : -1.4426950408889634f;
                     float v[8];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {              // cout_perm: quads 2*m2, 2*m2+1 of this lane = channels 16*m2 + 8*hi + 0..7
-                        v[j] = acc[s][p][(2 * m2) * 4 + j] + b0[j];
-                        v[4 + j] = acc[s][p][(2 * m2 + 1) * 4 + j] + b1[j];
+                        v[j] = __builtin_fmaf(acc[s][p][(2 * m2) * 4 + j], K, b0[j]);
+                        v[4 + j] = __builtin_fmaf(acc[s][p][(2 * m2 + 1) * 4 + j], K, b1[j]);
                     }
-                    if constexpr (EPI == SEP_SIG) {
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) v[j] = fast_sigmoid(v[j]);
-                    } else if constexpr (EPI == SEP_MUL) {
+                    for (int j = 0; j < 8; ++j) v[j] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v[j]));   // sigmoid(x) resp. 1 / (1 + e^(2x))
+                    if constexpr (EPI == SEP_MUL) {
                         const h8_t r = __builtin_bit_cast(h8_t, rreg[s][p][m2]);
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) v[j] = fast_sigmoid(v[j]) * (float)r[j];
-                    } else {
-                        const h8_t r = __builtin_bit_cast(h8_t, rreg[s][p][m2]);
+                        for (int j = 0; j < 8; ++j) v[j] = __builtin_fmaf(v[j], (float)r[j], 0.0f);     // one v_fma_mix{lo,hi}_f16: product and fp16 rounding
+                    } else if constexpr (EPI == SEP_GRU) {
+                        const u4_t rr = rreg[s][p][m2];
+                        const h8_t r = __builtin_bit_cast(h8_t, rr);
                         const h8_t z = __builtin_bit_cast(h8_t, zreg[s][p][m2]);
 #pragma unroll
                         for (int j = 0; j < 8; ++j) {
-                            // (1 - z) h + z tanh(v) = h + z (tanh(v) - h), tanh(v) = 1 - 2 / (1 + e^(2v)): 7 VALU with explicit fmas
-                            // instead of 10 (this epilogue is as long as the layer's MFMA phase); fp16 path only
-                            const float q = __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * v[j])), 1.0f);
-                            v[j] = __builtin_fmaf((float)z[j], q - (float)r[j], (float)r[j]);
+                            // (1 - z) h + z tanh(x) = h + z (tanh(x) - h), tanh(x) = 1 - 2 / (1 + e^(2x)): fma, v_fma_mix_f32 (tanh - h, h read
+                            // as fp16), v_fma_mix_f16 (z, h as fp16; fp16 result) -- 7 VALU per element with the exponent's fma; fp16 path only
+                            const float q = __builtin_fmaf(-2.0f, v[j], 1.0f);
+                            const float dlt = (j & 1) ? sub_mix_hi(q, rr[j >> 1]) : sub_mix_lo(q, rr[j >> 1]);
+                            v[j] = __builtin_fmaf((float)z[j], dlt, (float)r[j]);
                         }
                     }
                     const int os = os0 + wave * 2 + p, ol = ol0 + lx;
@@ -2102,9 +2136,10 @@ __global__ __launch_bounds__(NT + 64 * S_NDMA, 1) void conv_sep5_c128_persist_ke
 
     // ================= MFMA waves ============================================================================
     float* const bias_lds = (float*)(tbuf + S_NBUF * S_BUF_BYTES);
-    if (tid < 64) bias_lds[tid] = d->bias[a.cb * 64 + tid];
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     const demfi_seg& sg = d->segs[d->sub_seg[a.cb * 2]];
+    // bias pre-multiplied by the scale of the epilogue's exponent: e^(2x) = 2^(2 log2(e) x) (tanh), e^(-x) = 2^(-log2(e) x) (sigmoid)
+    if (tid < 64) bias_lds[tid] = d->bias[a.cb * 64 + tid] * (sg.mode == DEMFI_MODE_GRU ? 2.8853900817779268f : -1.4426950408889634f);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (sg.mode == DEMFI_MODE_GRU)      sep_mfma_waves<SEP_GRU, VAR>(d, a, wlds, tbuf, bias_lds, wave, lane);
     else if (sg.mode == DEMFI_MODE_MUL) sep_mfma_waves<SEP_MUL, VAR>(d, a, wlds, tbuf, bias_lds, wave, lane);
     else                                sep_mfma_waves<SEP_SIG, VAR>(d, a, wlds, tbuf, bias_lds, wave, lane);
