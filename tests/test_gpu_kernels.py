@@ -269,6 +269,35 @@ def test_narrow_persistent_conv_7x7(H, W):
     assert err < 4e-3 * max(1.0, ref.abs().max().item()), err
 
 
+@pytest.mark.parametrize('H,W,batch,act', [(16, 32, 1, L.ACT_TANH), (37, 75, 2, L.ACT_NONE), (64, 96, 1, L.ACT_RELU), (19, 130, 3, L.ACT_TANH),
+                                           (48, 40, 1, L.ACT_NONE)])
+def test_streamed_weight_conv_7x7_192_to_64(H, W, batch, act):
+    """Ch_Reducer (7x7, 3 x 64 -> 64, DeMFInet.py:37, 114): the streamed-weight kernel (16 x 32-pixel tiles, 8 accumulators per wave,
+    A fragments straight from the packed weights in L2, 32-channel activation units through a double buffer) against torch on
+    tiles that are interior, ragged at both edges, several per workgroup sequence, and with a batch stride.  The three pieces
+    are channel slices of ONE 192-channel NHWC buffer, as in the plan."""
+    torch.manual_seed(11)
+    pl = Plan(H, W, torch.float16, DEV)
+    b = pl._fat(H, W, 192, batch)
+    b.copy_(torch.randn(b.shape, device=DEV))
+    out = pl._fat(H, W, 64, batch)
+    wt = torch.randn(64, 192, 7, 7) * (1.0 / (192 * 49) ** 0.5)
+    bs = torch.randn(64) * 0.1
+    pl.conv([], 'Ch_Reducer', [pl.fsrc(b, 0, 0, 64), pl.fsrc(b, 64, 64, 64), pl.fsrc(b, 128, 128, 64)],
+            [_Dst(pl.fview(out), range(64), act)], H, W, batch=batch, weight=wt, bias=bs)
+    assert pl._descs[0].cout_perm == 1, 'the layer must be packed for the streamed-weight kernel'
+    pl._upload()
+    for rep in range(2):
+        out.fill_(7.0)
+        pl.launch_conv(0, _stream())
+    torch.cuda.synchronize()
+    nchw = lambda t: t.permute(0, 3, 1, 2).double().cpu()
+    ref = torch.nn.functional.conv2d(nchw(b), wt.half().double(), bs.double(), padding=3)
+    ref = {L.ACT_TANH: torch.tanh, L.ACT_RELU: torch.relu, L.ACT_NONE: (lambda x: x)}[act](ref)
+    err = (nchw(out) - ref).abs().max().item()
+    assert err < 4e-3 * max(1.0, ref.abs().max().item()), err
+
+
 THIN_CASES = [
     # cin, list of (n couts, residual?) per destination tensor, act, batch
     (64, [(3, True), (3, True), (3, True)], L.ACT_NONE, 1),      # Dec_last2_2: three frames, each + its own residual

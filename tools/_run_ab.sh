@@ -1,7 +1,7 @@
 #!/bin/bash
 # same-box A/B: previous library vs current, alternating
 cd /root/repo
-OPS="Booster_Module.GB.convzr1 Booster_Module.GB.convq1 Booster_Module.GB.convzr2 Booster_Module.GB.convq2"
+OPS="${OPS:-Ch_Reducer}"
 for r in 1 2; do
   for lib in prev cur; do
     if [ $lib = prev ]; then export DEMFI_HIP_LIB=/root/repo/demfi_amd/csrc/libdemfi_hip_prev.so; else unset DEMFI_HIP_LIB; fi
