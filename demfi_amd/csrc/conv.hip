@@ -2663,6 +2663,9 @@ extern "C" int demfi_conv2d(const demfi_conv* h, const demfi_conv* dev, void* st
 #ifdef DEMFI_TRACE
             if (getenv("DEMFI_PAIR") && atoi(getenv("DEMFI_PAIR")) == 4) return launch_persist<2>(h, dev, st);   // phase trace of the 4-wave kernel
 #endif
+#ifdef DEMFI_ABLATION
+            if (pair == 5) return launch_dacc(h, dev, st);       // round-3 double-accumulator experiment (conv_experiments.inc): measured negative
+#endif
             return launch_stg(h, dev, st);
         }
         return launch_persist<1>(h, dev, st);
