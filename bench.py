@@ -294,6 +294,12 @@ def main():
                                                    'at the sustained clock is 2500 x 1.7 / 2.4 = 1771 TFLOP/s; frac is quoted against the 2.4 GHz peak',
                            'all_convs_TFLOPs': round(tot_conv_fl / (tot_conv_ms * 1e-3) / 1e12, 2),
                            'slowest_conv': '%s %.3f ms' % (dom[2], dom[3])}
+        chr_ = [p for p in convs if p[2] == 'Ch_Reducer']
+        if chr_ and a.dtype == 'fp16':
+            c_ms, c_fl = chr_[0][3], 2.0 * chr_[0][4]
+            out['roofline']['second_kernel'] = {'kernel': 'conv_wstream_c64_kernel<7>: Ch_Reducer, 7x7 192->64, %d time instants per launch (round 3: A fragments from L2 '
+                                                          'into a register ring, 8 accumulators per wave)' % nb,
+                                                'avg_launch_ms': round(c_ms, 4), 'TFLOPs': round(c_fl / c_ms / 1e9, 1), 'frac_mfma': round(c_fl / c_ms / 1e9 / peak, 4)}
         wb = [p for p in prof if p[1] == 'warp_fat']
         wb_ms = sum(p[3] for p in wb) / len(wb)
         esz = 2 if a.dtype == 'fp16' else 4
@@ -307,6 +313,9 @@ def main():
                                'frac': round(wb_bytes / (wb_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                'traffic': pmc.get('warp_traffic_bytes') if pmc else None,
                                'avg_launch_ms': round(wb_ms, 4), 'bytes_per_launch': wb_bytes,
+                               'streaming_ceiling_note': 'tools/microbench/hbm_mix (profiles/r03_hbm_mix.txt): a plain streaming kernel with this read : write mix '
+                                                         '(3 : 1) reaches 4.7 TB/s at 2 048 workgroups and 5.9 TB/s at its best grid (512, non-temporal, 4 lines in '
+                                                         'flight per thread); read-only 7.1, write-only 6.6: 0.60 of 8 TB/s is above what most grids of a COPY reach',
                                'per_t_equivalent': {'bytes_per_t_launch': (3 * 64 * esz + 20) * eng.H * eng.W,
                                                     'note': 'one launch per time instant reads F0 / F1 every time: 404 B/px x nb'}}
         cfr = [p for p in prof if p[1] == 'cfr']
