@@ -180,6 +180,35 @@ def test_fp16_plan_with_hoisted_partial_convs(synthetic_sd):
     assert (eng.delta[N, 0:4].float() - ref[2][N][0]).abs().median() < 2e-2
 
 
+def test_ch_reducer_descriptor_is_the_streamed_weight_kernels(synthetic_sd):
+    """Ch_Reducer (7x7, 192 -> 64) runs on conv_wstream_c64_kernel (conv.hip) only if the plan hands it the shape that kernel owns:
+    fp16, six single-piece 32-channel chunks (64-byte records: the two halves of the three 64-channel images of rF, same strides), 64
+    packed couts in the permuted order,
+    one NHWC destination without residual.  A builder change that made the layer ineligible would silently fall back to the general
+    kernel (a 25 % slower layer, invisible to the parity tests): pin the descriptor here, per-t and batched."""
+    from demfi_amd.engine import SEG_HEAD, SEG_TB_HEAD
+    eng = Engine(synthetic_sd, 32, 64, torch.float16, 'cpu', max_updates=1, n_ctx=2)
+    for seg in (SEG_HEAD, SEG_TB_HEAD):
+        op = [o for o in eng.ops(seg) if o.name.decode() == 'Ch_Reducer'][0]
+        d = eng.conv_desc(op.conv)
+        assert (d.kh, d.kw, d.stride, d.pad_y, d.pad_x) == (7, 7, 1, 3, 3)
+        assert d.cout_perm == 1 and d.rec_bytes == 64 and d.n_chunks == 6 and d.cout_pad == 64 and d.nco == 2
+        assert d.batch == (2 if seg == SEG_TB_HEAD else 1)
+        first = d.pieces[d.chunks[0].first_piece].v
+        for c in range(6):
+            ch = d.chunks[c]
+            pc = d.pieces[ch.first_piece]
+            assert ch.n_pieces == 1 and ch.nks == 2 and pc.nch == 32 and pc.fat == 1 and pc.up_shift == 0
+            assert (pc.v.sx, pc.v.sy, pc.v.sc, pc.v.sb) == (64, 64 * 64, 1, first.sb)
+            assert pc.v.ptr == first.ptr + (c // 2) * 32 * 64 * 64 * 2 + (c % 2) * 64          # image c // 2 of rF, channel half c % 2
+        sg = d.segs[d.sub_seg[0]]
+        assert d.sub_seg[1] == d.sub_seg[0] and not sg.res.ptr and sg.dst.sc == 1 and not sg.dst.is_f32
+    # the fp32 plan keeps the layer on the general kernel (no permuted cout order)
+    e32 = Engine(synthetic_sd, 32, 64, torch.float32, 'cpu', max_updates=1)
+    op = [o for o in e32.ops(SEG_HEAD) if o.name.decode() == 'Ch_Reducer'][0]
+    assert e32.conv_desc(op.conv).cout_perm == 0
+
+
 @pytest.mark.parametrize('dtype', [torch.float16, torch.float32])
 def test_batched_per_t_plan_equals_per_context_plans(synthetic_sd, dtype):
     """demfi_forward_tb: ONE op list for all per-t contexts (convolutions batched over the contexts through the contiguous
