@@ -270,7 +270,8 @@ def test_narrow_persistent_conv_7x7(H, W):
 
 
 @pytest.mark.parametrize('H,W,batch,act', [(16, 32, 1, L.ACT_TANH), (37, 75, 2, L.ACT_NONE), (64, 96, 1, L.ACT_RELU), (19, 130, 3, L.ACT_TANH),
-                                           (48, 40, 1, L.ACT_NONE)])
+                                           (48, 40, 1, L.ACT_NONE),
+                                           (152, 420, 2, L.ACT_TANH)])    # 10 x 14 x 2 = 280 tiles > 256 workgroups: XCD bands, several tiles per workgroup
 def test_streamed_weight_conv_7x7_192_to_64(H, W, batch, act):
     """Ch_Reducer (7x7, 3 x 64 -> 64, DeMFInet.py:37, 114): the streamed-weight kernel (16 x 32-pixel tiles, 8 accumulators per wave,
     A fragments straight from the packed weights in L2, 32-channel activation units through a double buffer) against torch on
@@ -292,7 +293,11 @@ def test_streamed_weight_conv_7x7_192_to_64(H, W, batch, act):
         pl.launch_conv(0, _stream())
     torch.cuda.synchronize()
     nchw = lambda t: t.permute(0, 3, 1, 2).double().cpu()
-    ref = torch.nn.functional.conv2d(nchw(b), wt.half().double(), bs.double(), padding=3)
+    big = H * W * batch > 50000                                  # the multi-tile case: fp32 reference on the GPU (a double conv on the CPU takes a minute)
+    if big:
+        ref = torch.nn.functional.conv2d(b.permute(0, 3, 1, 2).float(), wt.half().float().to(DEV), bs.to(DEV), padding=3).double().cpu()
+    else:
+        ref = torch.nn.functional.conv2d(nchw(b), wt.half().double(), bs.double(), padding=3)
     ref = {L.ACT_TANH: torch.tanh, L.ACT_RELU: torch.relu, L.ACT_NONE: (lambda x: x)}[act](ref)
     err = (nchw(out) - ref).abs().max().item()
     assert err < 4e-3 * max(1.0, ref.abs().max().item()), err
