@@ -318,6 +318,16 @@ def main():
                                                          'flight per thread); read-only 7.1, write-only 6.6: 0.60 of 8 TB/s is above what most grids of a COPY reach',
                                'per_t_equivalent': {'bytes_per_t_launch': (3 * 64 * esz + 20) * eng.H * eng.W,
                                                     'note': 'one launch per time instant reads F0 / F1 every time: 404 B/px x nb'}}
+        fg = [p for p in prof if p[1] == 'fgac']
+        if fg:
+            # second gather kernel of the north star (FGAC sampling, DeMFInet.py:413-419, 499-508): input feature map read through the
+            # bilinear gather + output + the 2-plane offset map, every tensor once
+            fg_ms = sum(p[3] for p in fg) / len(fg)
+            fg_bytes = (2 * 64 * esz + 8) * eng.H * eng.W
+            out['roofline_hbm']['fgac_gather'] = {'avg_launch_ms': round(fg_ms, 4), 'bytes_per_launch': fg_bytes,
+                                                  'achieved': round(fg_bytes / (fg_ms * 1e-3) / 1e9, 1), 'frac': round(fg_bytes / (fg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                                  'traffic': next((v.get('hbm_bytes_per_launch') for k, v in (pmc or {}).get('in_network', {}).items()
+                                                                   if 'fgac_gather' in k), None)}
         cfr = [p for p in prof if p[1] == 'cfr']
         out['breakdown_ms'] = {'trunk_once_per_window': round(trunk, 2), 'per_t': round(per_t, 2),
                                'time_instants_per_launch_sequence': nb,
