@@ -1776,8 +1776,8 @@ int launch_narrow(const demfi_conv* h, const demfi_conv* dev, hipStream_t st, bo
 //   * the weights of the workgroup's 64 couts (5 taps x 128 cin = 80 KiB) stay resident, which leaves 72 KiB for the
 //     activations.  A whole 64-channel chunk per buffer (2 x 36 KiB, one chunk in flight) ran at ~2 x HBM latency per
 //     tile (10 us vs ~3 us of MFMA work), so K is streamed in FOUR 32-channel units per tile (64-byte records,
-//     18 KiB) through a 4-slot ring with THREE units in flight, tracked with counted s_waitcnt vmcnt (loads retire
-//     in order: "at most 2 x 18 outstanding" proves the oldest unit has landed);
+//     18 KiB) through a 4-slot ring, handed over in PAIRS (round 3: two barriers per tile; the pair after the one on the
+//     matrix cores is in flight.  Rounds 1-2: one barrier per unit, three units in flight, counted s_waitcnt vmcnt);
 //   * epilogues of the GRU: sigmoid (z), sigmoid * h (r*h), (1-z)*h + z*tanh(.) (state update); h and z are
 //     prefetched into registers before the MFMA phases.
 // ======================================================================================================
@@ -1794,6 +1794,10 @@ enum { SEP_SIG = 0, SEP_MUL = 1, SEP_GRU = 2 };
 #define DEMFI_SEP_GRU_PREFETCH_UNIT 1
 #endif
 constexpr int SEP_GRU_PREFETCH_UNIT = DEMFI_SEP_GRU_PREFETCH_UNIT;
+#ifndef DEMFI_SEP_PAIRS
+#define DEMFI_SEP_PAIRS 1        // round 3: -5 % (z|r) / -6 % (q) against one barrier per unit, same box
+#endif
+constexpr bool SEP_PAIRS = DEMFI_SEP_PAIRS != 0;
 
 struct SepArgs {
     int t_first, t_end, t_step, nh_shift, cb;
@@ -1880,7 +1884,7 @@ __device__ __forceinline__ void sep_mfma_waves(const demfi_conv* __restrict__ d,
             // has to drain (its stores and aux loads stay in flight)
             if constexpr (q == 0) TRACE_STAMP(wave, trk, 0);
             if constexpr (q == 2) TRACE_STAMP(wave, trk, 4);    // arrival at the third unit's barrier
-            asm volatile("s_barrier" ::: "memory");
+            if constexpr (!SEP_PAIRS || (q & 1) == 0) asm volatile("s_barrier" ::: "memory");
             if constexpr (q == 0) TRACE_STAMP(wave, trk, 1);
             if constexpr (q == 2) TRACE_STAMP(wave, trk, 5);
             const char* tb = tbuf + ub * S_BUF_BYTES + (wave * 2) * (S_LL * 64);
@@ -2116,6 +2120,25 @@ __global__ __launch_bounds__(NT + 64 * S_NDMA, 1) void conv_sep5_c128_persist_ke
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // weights landed: from here on vmcnt counts unit loads only
         const int n_units = 4 * ((a.t_end - a.t_first + a.t_step - 1) / a.t_step);   // >= 4
+        if constexpr (SEP_PAIRS) {
+            // units handed over in PAIRS: two barriers per tile instead of four; pair k + 1 is issued behind pair k's barrier (the MFMA waves
+            // have finished pair k - 1 when they arrive there) and has one pair's MFMA time to land
+            issue_unit(0);
+            issue_unit(1);
+            issue_unit(2);
+            issue_unit(3);
+            const int n_pairs = n_units >> 1;
+            for (int k = 0; k < n_pairs; ++k) {
+                if (k == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * S_NI / S_NDMA) : "memory");
+                else        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if ((k & 1) == 0) TRACE_STAMP(wave, k >> 1, 0);
+                __syncthreads();
+                if ((k & 1) == 0) TRACE_STAMP(wave, k >> 1, 1);
+                if (k >= 1 && k + 1 < n_pairs) { issue_unit(2 * k + 2); issue_unit(2 * k + 3); }
+                if ((k & 1) == 0) TRACE_STAMP(wave, k >> 1, 2);
+            }
+            return;
+        }
         issue_unit(0);
         issue_unit(1);
         issue_unit(2);
