@@ -1878,6 +1878,72 @@ __device__ __forceinline__ void sep_mfma_waves(const demfi_conv* __restrict__ d,
 #pragma unroll
             for (int i = 0; i < 16; ++i) { acc[s][0][i] = 0.0f; acc[s][1][i] = 0.0f; }
         }
+        if constexpr (SEP_PAIRS) {
+            // ---- the units in pairs: one barrier, then the ten taps of the two units as ONE software pipeline (the per-unit version
+            //      restarted it -- two exposed LDS round trips -- at every unit)
+            static_for<0, 2>([&](auto P_) {
+                constexpr int pr = decltype(P_)::value;
+                if constexpr (pr == 0) TRACE_STAMP(wave, trk, 0);
+                if constexpr (pr == 1) TRACE_STAMP(wave, trk, 4);
+                asm volatile("s_barrier" ::: "memory");
+                if constexpr (pr == 0) TRACE_STAMP(wave, trk, 1);
+                if constexpr (pr == 1) TRACE_STAMP(wave, trk, 5);
+                const char* const tb0 = tbuf + ub * S_BUF_BYTES + (wave * 2) * (S_LL * 64);
+                const char* const tb1 = tbuf + ((ub + 1) & (S_NBUF - 1)) * S_BUF_BYTES + (wave * 2) * (S_LL * 64);
+                ub = (ub + 2) & (S_NBUF - 1);
+                if constexpr (EPI == SEP_GRU && pr == (SEP_GRU_PREFETCH_UNIT >> 1)) {
+                    prefetch_aux();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if constexpr (VAR == 2) return;
+                auto load_tap = [&](FragSet<NCO>& f, auto T_) {       // T = 5 * (unit of the pair) + tap
+                    constexpr int T = decltype(T_)::value, q = 2 * pr + T / 5, tap = T % 5;
+                    const char* const tb = T < 5 ? tb0 : tb1;
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+#pragma unroll
+                        for (int s = 0; s < NCO; ++s)
+                            f.a[k][s] = *(const uint4*)(wl + ((((q >> 1) * 5 + tap) * 4 + (q & 1) * 2 + k) * NCO + s) * 1024);
+                        const char* p0 = tb + boff[tap * 2 + k];
+                        f.b[k][0] = *(const uint4*)(p0);
+                        f.b[k][1] = *(const uint4*)(p0 + S_LL * 64);
+                    }
+                };
+                auto mma_tap = [&](const FragSet<NCO>& f) {
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+#pragma unroll
+                        for (int s = 0; s < NCO; ++s) {
+                            Mma<half_t>::run(acc[s][0], f.a[k][s], f.b[k][0]);
+                            Mma<half_t>::run(acc[s][1], f.a[k][s], f.b[k][1]);
+                        }
+                    }
+                };
+                auto interleave = [&]() {                               // the 8 ds_reads of the next tap 1:1 with the 8 MFMAs of the current one
+#pragma unroll
+                    for (int q8 = 0; q8 < 8; ++q8) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+                FragSet<NCO> f[2];
+                load_tap(f[0], std::integral_constant<int, 0>{});
+                __builtin_amdgcn_sched_barrier(0);
+                load_tap(f[1], std::integral_constant<int, 1>{});
+                __builtin_amdgcn_sched_barrier(0);
+                mma_tap(f[0]);
+                __builtin_amdgcn_sched_barrier(0);
+                static_for<2, 10>([&](auto T_) {
+                    constexpr int T = decltype(T_)::value;
+                    load_tap(f[T & 1], T_);
+                    mma_tap(f[(T - 1) & 1]);
+                    interleave();
+                });
+                mma_tap(f[1]);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        } else {
         static_for<0, 4>([&](auto Q_) {
             constexpr int q = decltype(Q_)::value;              // unit q: channels 32q .. 32q+31 of the 128
             // unit q of this tile is in ring slot ub (the DMA wave waited for it); raw barrier: nothing of this wave
@@ -1944,6 +2010,7 @@ __device__ __forceinline__ void sep_mfma_waves(const demfi_conv* __restrict__ d,
             mma_tap(f0);
             __builtin_amdgcn_sched_barrier(0);
         });
+        }
 #if defined(DEMFI_TRACE) && defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
         for (int s = 0; s < NCO; ++s) { asm volatile("" ::"v"(acc[s][0])); asm volatile("" ::"v"(acc[s][1])); }
