@@ -385,6 +385,9 @@ __global__ __launch_bounds__(NT, (NCO <= 1 ? 4 : (NCO == 2 ? 3 : 2))) void conv_
         issue_weights(wchunk, 0, nks);                              // overlaps the tile staging below
         // ---------------- stage the haloed input tile of this chunk into LDS ----------------------------
         for (int pi = ch.first_piece; pi < ch.first_piece + ch.n_pieces; ++pi) {
+#ifdef DEMFI_ABLATION
+            if (g_knob & 32) break;                              // experiment: no tile staging (garbage operands): what the staging costs
+#endif
             const demfi_piece& p = d->pieces[pi];
             const char* src = (const char*)p.v.ptr;
             const int ush = p.up_shift;
@@ -395,16 +398,53 @@ __global__ __launch_bounds__(NT, (NCO <= 1 ? 4 : (NCO == 2 ? 3 : 2))) void conv_
                 const int64_t sx = p.v.sx * ESZ, sy = p.v.sy * ESZ;
                 const char* srcb = src + (int64_t)bimg * p.v.sb * ESZ;
                 const int ldsoff = p.lds_ch * ESZ;
-                for (int it = tid; it < nitems; it += NT) {
-                    const int px = it >> vsh;
-                    const int v = it & (vpp - 1);
-                    const int ly = __umulhi((uint32_t)px, lw_magic);
-                    const int lxx = px - ly * LW;
-                    const int iy = iy0 + ly, ix = ix0 + lxx;
-                    uint4 val = make_uint4(0, 0, 0, 0);
-                    if (src != nullptr && iy >= 0 && iy < inH && ix >= 0 && ix < inW)
-                        val = ld_global16(srcb + (iy >> ush) * sy + (ix >> ush) * sx + v * 16);
-                    *(uint4*)(smem + px * rec + ldsoff + v * 16) = val;
+                // STG_UNR independent loads in flight per thread before the first LDS write (round 3: the one-item loop serialised a
+                // global-memory round trip per item -- 10 per thread for a 3x3 tile of 128-byte records -- and cost 25-70 % of the
+                // general kernel's layers: profiles/r03_notes.md section 13)
+                constexpr int STG_UNR = 4;
+                // interior tiles of tensors below 4 GiB per image (every tile but the frame's border): no bounds tests, 32-bit offsets
+                // from a uniform base (the saddr form of the load: no 64-bit address arithmetic per item)
+                const bool fast = src != nullptr && iy0 >= 0 && iy0 + LH <= inH && ix0 >= 0 && ix0 + LW <= inW &&
+                                  (uint64_t)(((inH - 1) >> ush) + 1) * (uint64_t)sy < ((uint64_t)1 << 32) && sy >= 0 && sx >= 0;
+                if (fast) {
+                    const uint32_t sy32 = (uint32_t)sy, sx32 = (uint32_t)sx;
+                    for (int it0 = tid; it0 < nitems; it0 += STG_UNR * NT) {
+                        uint4 val[STG_UNR];
+                        int dsto[STG_UNR];
+#pragma unroll
+                        for (int u = 0; u < STG_UNR; ++u) {
+                            const int it = min(it0 + u * NT, nitems - 1);       // clamped: an unconditional load (re-reads the last item)
+                            const int px = it >> vsh;
+                            const int v = it & (vpp - 1);
+                            const int ly = __umulhi((uint32_t)px, lw_magic);
+                            const int lxx = px - ly * LW;
+                            dsto[u] = it0 + u * NT < nitems ? px * rec + ldsoff + v * 16 : -1;
+                            val[u] = ld_global16(srcb + (uint32_t)(((uint32_t)(iy0 + ly) >> ush) * sy32 + ((uint32_t)(ix0 + lxx) >> ush) * sx32 + v * 16));
+                        }
+#pragma unroll
+                        for (int u = 0; u < STG_UNR; ++u)
+                            if (dsto[u] >= 0) *(uint4*)(smem + dsto[u]) = val[u];
+                    }
+                } else
+                for (int it0 = tid; it0 < nitems; it0 += STG_UNR * NT) {
+                    uint4 val[STG_UNR];
+                    int dsto[STG_UNR];
+#pragma unroll
+                    for (int u = 0; u < STG_UNR; ++u) {
+                        const int it = it0 + u * NT;
+                        const int px = it >> vsh;
+                        const int v = it & (vpp - 1);
+                        const int ly = __umulhi((uint32_t)px, lw_magic);
+                        const int lxx = px - ly * LW;
+                        const int iy = iy0 + ly, ix = ix0 + lxx;
+                        val[u] = make_uint4(0, 0, 0, 0);
+                        dsto[u] = it < nitems ? px * rec + ldsoff + v * 16 : -1;
+                        if (it < nitems && src != nullptr && iy >= 0 && iy < inH && ix >= 0 && ix < inW)
+                            val[u] = ld_global16(srcb + (iy >> ush) * sy + (ix >> ush) * sx + v * 16);
+                    }
+#pragma unroll
+                    for (int u = 0; u < STG_UNR; ++u)
+                        if (dsto[u] >= 0) *(uint4*)(smem + dsto[u]) = val[u];
                 }
             } else {
                 const int nch = p.nch;
