@@ -103,16 +103,6 @@ def main():
     period = (tr[:, 0, hi, 1] - tr[:, 0, lo, 1]) / float(hi - lo)
     print('  period (release to release, wave 0): mean %.0f cycles  (min %.0f max %.0f over %d workgroups)' % (period.mean(), period.min(), period.max(), WGS))
     cyc = (tr[:, 0, hi, 1] - tr[:, 0, lo, 1]).mean()
-    if os.environ.get('PROBE_KERNEL') == 'dacc':
-        # double-accumulator kernel: 4 waves; per tile: stamps 4 / 5 at steps 12 / 24, 2 at step 30 (in front of the counted vmcnt), 0 arrival at the
-        # barrier, 1 released
-        for w in range(4):
-            t = tr[:, w, lo:hi, :]
-            prev = tr[:, w, lo - 1:hi - 1, :]
-            print('  wave %d  step 30 (released) -> step 12 of the next tile %5.0f | steps 12-23 %5.0f | steps 24-29 %5.0f | vmcnt + lgkm wait %5.0f | wait at barrier %5.0f' %
-                  (w, (t[..., 4] - prev[..., 1]).mean(), (t[..., 5] - t[..., 4]).mean(), (t[..., 2] - t[..., 5]).mean(), (t[..., 0] - t[..., 2]).mean(),
-                   (t[..., 1] - t[..., 0]).mean()))
-        return
     for w in range(n_m + n_h):
         t = tr[:, w, lo:hi, :]
         nxt = tr[:, w, lo + 1:hi + 1, :]
