@@ -45,6 +45,8 @@ def parse():
     ap.add_argument('--n-ctx', type=int, default=None, help='per-t contexts batched per launch sequence (default: runner decides, printed in config)')
     ap.add_argument('--n-trunk', type=int, default=None, help='trunk buffer sets pipelined over windows')
     ap.add_argument('--no-verify', action='store_true', help='skip the byte-for-byte check of one sunk window against the module path')
+    ap.add_argument('--checkpoint', default='', help="reference checkpoint (.pt with 'state_dict_Model', main.py:316,351) to load instead of the random-init weights")
+    ap.add_argument('--auto', action='store_true', help='let the runner probe the free memory for n_ctx / n_trunk (default: fixed values)')
     ap.add_argument('--with-png', action='store_true', help='side figure: PNG folder -> PNG folder frames/s of this rank (codec + threads inside)')
     return ap.parse_args()
 
@@ -142,6 +144,36 @@ def png_side_figure(a, model, runner):
         shutil.rmtree(d, ignore_errors=True)
 
 
+def box_id(dev):
+    """Which box / GPU produced the line (boxes differ by +-3 %, profiles/r03_notes.md section 11): host name, device name, PCI bus, the
+    device's maximum shader clock and (when the sysfs node exists) the sclk level table of the first AMD card."""
+    import socket
+    pr = torch.cuda.get_device_properties(dev)
+    out = {'host': socket.gethostname(), 'gpu': pr.name, 'arch': getattr(pr, 'gcnArchName', ''), 'cus': pr.multi_processor_count,
+           'hbm_gb': round(pr.total_memory / 1e9, 1), 'max_sclk_mhz': round(getattr(pr, 'clock_rate', 0) / 1e3, 0),
+           'pci_bus_id': getattr(pr, 'pci_bus_id', None)}
+    try:
+        import glob
+        for f in sorted(glob.glob('/sys/class/drm/card*/device/pp_dpm_sclk')):
+            out['pp_dpm_sclk'] = ' | '.join(l.strip() for l in open(f).read().splitlines())
+            break
+    except OSError:
+        pass
+    return out
+
+
+def load_rocprof_frac():
+    """roofline.frac of the same ten launches from the committed rocprofv3 kernel trace of a sequential bench run
+    (profiles/r04_seq_trace_roofline.json, written by tools/trace_by_op.py on the GPU box) so that the two timings -- HIP events
+    measured live in this run, rocprofv3 kernel durations measured on the box that produced the committed trace -- sit side by side."""
+    for r in ('r04', 'r03'):
+        path = os.path.join(ROOT, 'profiles', r + '_seq_trace_roofline.json')
+        if os.path.exists(path):
+            with open(path) as f:
+                return json.load(f)
+    return None
+
+
 def load_pmc_traffic():
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary (profiles/r02_pmc_traffic.json,
     written by tools/pmc_traffic.py on the GPU box: separate --pmc passes, 2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction)."""
@@ -175,12 +207,16 @@ def main():
     dtype = torch.float16 if a.dtype == 'fp16' else torch.float32
     model = DeMFInet(HyperParams(gpu=local), dtype=dtype)
     if rank == 0:
-        model.load_state_dict(synthetic_state_dict(0))       # random-init weights of the architecture (no checkpoint offline)
+        if a.checkpoint:
+            from demfi_amd.weights import load_checkpoint
+            model.load_state_dict(load_checkpoint(a.checkpoint))         # the reference's .pt (main.py:316,351); other ranks get it by broadcast
+        else:
+            model.load_state_dict(synthetic_state_dict(0))   # random-init weights of the architecture (no checkpoint offline)
     model = model.to(dev).eval()
     # ONE flat broadcast of the 7.4 M parameters (RCCL over xGMI): every rank then owns the real state_dict and packs its
     # own engine, so later engine rebuilds (other frame sizes) are correct on every rank
     D.broadcast_state_dict(model, world, device=dev if backend != 'gloo' else 'cpu')
-    runner = WindowRunner(model, a.height, a.width, a.n_tst, a.mfi, use_graph=not a.no_graph, n_ctx=a.n_ctx, n_trunk=a.n_trunk)
+    runner = WindowRunner(model, a.height, a.width, a.n_tst, a.mfi, use_graph=not a.no_graph, n_ctx=a.n_ctx, n_trunk=a.n_trunk, auto=a.auto)
     # synthetic clip: each rank gets its own 11-frame clip = 8 distinct windows (weak scaling), uint8 frames in PINNED HOST
     # memory: the timed region contains the H2D of every window's 4 frames, the forward, and the D2H of its uint8 outputs
     frames = synthetic_clip_u8(a.height, a.width, 11, seed=1000 * rank + 1)
@@ -208,7 +244,12 @@ def main():
     runner.run_clip_u8(frames, timed, sink, batch=a.batch, reuse_frames=False)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    dt = D.max_over_ranks(dt, dev if backend != 'gloo' else 'cpu')
+    dt_rank = dt
+    cdev = dev if backend != 'gloo' else 'cpu'
+    dt = D.max_over_ranks(dt, cdev)
+    # self-check of a multi-rank line: how many ranks took part (all-reduced count) and the spread of their own clocks
+    seen = D.sum_over_ranks([1.0, dt_rank], cdev)
+    dt_min = -D.max_over_ranks(-dt_rank, cdev)
     D.barrier()
     assert sunk[0] == (a.mfi - 1) * a.steps, 'frames delivered to the host: %d' % sunk[0]
     verify = None
@@ -232,7 +273,11 @@ def main():
             'value': round(frames_out / dt, 3), 'unit': 'frames/s',
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(1e3 * dt / a.steps, 2),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f16' if a.dtype == 'fp16' else 'f32',
-            'data': 'synthetic',
+            'data': 'synthetic' if not a.checkpoint else 'synthetic frames, checkpoint weights (%s)' % os.path.basename(a.checkpoint),
+            'ranks_seen': int(round(float(seen[0]))),
+            'per_rank_fps': {'min': round((a.mfi - 1) * a.steps / dt, 3), 'max': round((a.mfi - 1) * a.steps / dt_min, 3),
+                             'mean_s': round(float(seen[1]) / max(1.0, float(seen[0])), 4)},
+            'box': box_id(dev),
             'config': {'workload': 'DeMFI-Net_rb N_tst=%d, x%d MFI, %dx%d (padded %dx%d), %s, clip-parallel windows, '
                                    'random-init weights; uint8 frames host->HBM->host inside the timed region (PNG codec '
                                    'excluded), %d distinct windows' % (a.n_tst, a.mfi, a.height, a.width, eng.H, eng.W, a.dtype,
@@ -288,12 +333,17 @@ def main():
                            'algorithmic_bytes': pmc.get('dominant_algorithmic_bytes') * nb if pmc else None,
                            'traffic_source': pmc.get('source') if pmc else None,
                            'avg_launch_ms': round(g_ms, 4), 'flop_per_launch': g_fl,
+                           'frac_rocprof': None, 'rocprof': None,
                            'timing': 'IN SEQUENCE: mean over 5 passes of the whole launch plan, HIP events on the launch stream between consecutive '
                                      'launches (includes the 5-8 us launch gap; reproduces the rocprofv3 in-sequence kernel durations of profiles/ within ~1 %)',
                            'sustained_clock_note': 'in-kernel s_memtime trace (profiles/r03_notes.md): 1.7 GHz under this kernel, i.e. the dense-fp16 ceiling '
                                                    'at the sustained clock is 2500 x 1.7 / 2.4 = 1771 TFLOP/s; frac is quoted against the 2.4 GHz peak',
                            'all_convs_TFLOPs': round(tot_conv_fl / (tot_conv_ms * 1e-3) / 1e12, 2),
                            'slowest_conv': '%s %.3f ms' % (dom[2], dom[3])}
+        rp = load_rocprof_frac() if a.dtype == 'fp16' and (eng.H, eng.W) == (736, 1280) and nb == 7 else None
+        if rp:
+            out['roofline']['frac_rocprof'] = round(g_fl / (rp['avg_launch_ms'] * 1e-3) / 1e12 / peak, 4)
+            out['roofline']['rocprof'] = rp
         chr_ = [p for p in convs if p[2] == 'Ch_Reducer']
         if chr_ and a.dtype == 'fp16':
             c_ms, c_fl = chr_[0][3], 2.0 * chr_[0][4]

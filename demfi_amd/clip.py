@@ -57,14 +57,23 @@ def gt_names(frame_names, mfi, t_step_size):
     return out
 
 
+def deblur_time_indices(mfi):
+    """(index of the time instant whose S0 is scored, index whose S1 is scored) as test() does it: S0 at the centre frame
+    t = 0.5 for x8 (testIndex % 7 == 3, main.py:918-955) and at the only t for x2 (main.py:1000-1027); S1 from the LAST sample of
+    a scene, i.e. its last window at the last t (main.py:633-645, 1053-1058).  Other M (not handled by the reference): first t."""
+    return (3 if mfi == 8 else 0), mfi - 2
+
+
 class EvalTable:
     """Per-time-index / per-scene averaging of test() (main.py:889-1103): column j < M-1 collects the metric of the j-th
-    time instant of every window, columns M-1 / M the deblurred S0 / S1; a scene's value is the mean over its windows,
-    the reported value the mean over scenes; ``total`` is the mean over all St samples (intp_PSNRs / intp_SSIMs)."""
+    time instant of every window (PSNR_scene_1..7); column M-1 is the reference's ONE deblur column (PSNR_scene_8_deblur): the S0
+    of every window at the reference's time instant plus the S1 of the scene's last window (``deblur_time_indices``).  A scene's
+    value is the mean over its samples, the reported value the mean over scenes (PSNR_1..7, PSNR_8_deblur); ``total`` /
+    ``deblur_total`` are the means over all samples (intp_PSNRs / deblur_PSNRs)."""
 
     def __init__(self, mfi):
         self.m1 = mfi - 1
-        self.ncol = self.m1 + 2
+        self.ncol = self.m1 + 1
         self.acc = {}                     # (scene, column) -> [sum_psnr, sum_ssim, n]
 
     def update(self, scene, j, psnr, ssim):
@@ -72,6 +81,9 @@ class EvalTable:
         a[0] += psnr
         a[1] += ssim
         a[2] += 1
+
+    def update_deblur(self, scene, psnr, ssim):
+        self.update(scene, self.m1, psnr, ssim)
 
     def keys_for(self, scenes):
         """The key list every rank must use for the reduction: all scenes x all columns, whatever this rank has seen."""
@@ -108,11 +120,15 @@ class EvalTable:
             ps = [self.acc[(s, j)][0] / self.acc[(s, j)][2] for s in scenes if (s, j) in self.acc]
             ss = [self.acc[(s, j)][1] / self.acc[(s, j)][2] for s in scenes if (s, j) in self.acc]
             return (float(np.mean(ps)) if ps else float('nan'), float(np.mean(ss)) if ss else float('nan'))
-        st = [a for (s, j), a in self.acc.items() if j < self.m1]
-        n = sum(a[2] for a in st)
-        tot = (sum(a[0] for a in st) / n, sum(a[1] for a in st) / n) if n else (float('nan'),) * 2
+
+        def pooled(sel):
+            a = [v for (s, j), v in self.acc.items() if sel(j)]
+            n = sum(v[2] for v in a)
+            return ((sum(v[0] for v in a) / n, sum(v[1] for v in a) / n) if n else (float('nan'),) * 2), n
+        tot, n = pooled(lambda j: j < self.m1)
+        dtot, dn = pooled(lambda j: j == self.m1)
         return {'per_index': [column(j) for j in range(self.m1)], 'total': tot, 'samples': n,
-                'deblur': {'S0': column(self.m1), 'S1': column(self.m1 + 1)}}
+                'deblur': column(self.m1), 'deblur_total': dtot, 'deblur_samples': dn}
 
 
 class _StreamedFrames:
@@ -215,9 +231,9 @@ class ClipRunner:
         frames in ``blur_dir``, sharp ground truth in ``sharp_dir``; every window of this rank's block runs through the
         fp32-output path of the runner, and PSNR / MATLAB-SSIM of the D1 (``Sharps_prime``) and D2 (``Sharps_final[-1]``)
         frames against the ground truth are computed on the GPU (prediction rounded, target not) and accumulated per
-        time index: ``tables`` = {'D1': EvalTable, 'D2': EvalTable} (created when None).  S0 / S1 are evaluated on the first
-        time instant's outputs (what the clip pipeline keeps).  Reduce over ranks with ``EvalTable.all_reduce``.
-        Returns (tables, windows evaluated)."""
+        time index: ``tables`` = {'D1': EvalTable, 'D2': EvalTable} (created when None).  The deblur column follows the
+        reference's bookkeeping (``deblur_time_indices``): S0 of every window at t = 0.5 (x8; the only t at x2), S1 of the scene's
+        LAST window at the last t.  Reduce over ranks with ``EvalTable.all_reduce``.  Returns (tables, windows evaluated)."""
         from .metrics import FrameEvaluator, u8_frame_to_tensor
         names = sorted(os.path.join(blur_dir, f) for f in os.listdir(blur_dir) if f.endswith(ext))
         if len(names) < 4:
@@ -225,10 +241,12 @@ class ClipRunner:
         scene = scene if scene is not None else os.path.basename(blur_dir.rstrip(os.sep))
         tables = tables or {'D1': EvalTable(self.mfi), 'D2': EvalTable(self.mfi)}
         lo, wins = self.my_windows(len(names))
+        n_windows = len(names) - 3
         gts = gt_names(names, self.mfi, t_step_size)
         dev = self.runner.engine.device
         ev = FrameEvaluator(self.h, self.w, dev)
         m1 = self.mfi - 1
+        j_s0, j_s1 = deblur_time_indices(self.mfi)
         res = torch.zeros((2, m1 + 2, 3), dtype=torch.float64, device=dev)
         cache = {}
 
@@ -241,22 +259,104 @@ class ClipRunner:
             return t
         for k, win in enumerate(wins):
             x = torch.stack([frame(names[i]) for i in win], 1).unsqueeze(0)
-            st, s01, st1, s011 = self.runner.run_window(x, with_d1=True)
+            st, s01, st1, s011 = self.runner.run_window(x, with_d1=True, s0_at=j_s0, s1_at=j_s1)
             st_gt, s0_gt, s1_gt = gts[lo + k]
+            last = lo + k == n_windows - 1               # the scene's last sample carries the S1 score (main.py:633-645, 1053-1058)
             for j in range(m1):
                 g = frame(os.path.join(sharp_dir, st_gt[j]))
                 ev.launch(st1[j], g, res[0, j])
                 ev.launch(st[j], g, res[1, j])
             for i, nm in enumerate((s0_gt, s1_gt)):
+                if i == 1 and not last:
+                    continue
                 g = frame(os.path.join(sharp_dir, nm))
                 ev.launch(s011[i], g, res[0, m1 + i])
                 ev.launch(s01[i], g, res[1, m1 + i])
             r = res.cpu().numpy()                        # one small D2H per window; also orders the next window's reuse of the buffers
-            for j in range(m1 + 2):
+            for j in range(m1):
                 tables['D1'].update(scene, j, float(r[0, j, 0]), float(r[0, j, 1]))
                 tables['D2'].update(scene, j, float(r[1, j, 0]), float(r[1, j, 1]))
+            for i in range(2 if last else 1):
+                tables['D1'].update_deblur(scene, float(r[0, m1 + i, 0]), float(r[0, m1 + i, 1]))
+                tables['D2'].update_deblur(scene, float(r[1, m1 + i, 0]), float(r[1, m1 + i, 1]))
         return tables, len(wins)
 
     def totals(self, windows, frames, device):
         """Sum of the per-rank counters over all ranks (the only end-of-run collective)."""
         return D.sum_over_ranks([float(windows), float(frames)], device).tolist()
+
+
+def main(argv=None):
+    """``python -m demfi_amd.clip <custom_path> [<out_root>] [--checkpoint PATH] ...`` -- the folder-in / folder-out command
+    of ``main.py --phase test_custom`` (/root/reference/main.py:1108-1196): ``custom_path`` holds one folder of PNG frames per
+    scene (make_2D_dataset_Custom_Test, utils.py:554-580); every scene is interpolated x M and written to
+    ``<out_root or custom_path>/<scene>_sharply_interpolated_x<M>`` under the reference's file names.  ``--checkpoint`` loads the
+    reference's ``.pt`` (``checkpoint['state_dict_Model']``, main.py:316, 351); without it the deterministic random-init weights
+    are used (and said so).  Launched under ``torch.distributed.run`` the windows of every scene are sharded over the ranks
+    (one GPU each, RCCL broadcast of the state_dict from rank 0, no data-path collective)."""
+    import argparse
+    import json
+    import time
+    ap = argparse.ArgumentParser(prog='python -m demfi_amd.clip', description=main.__doc__.split('\n\n')[0])
+    ap.add_argument('custom_path', help='folder with one sub-folder of frames per scene (or a single scene folder of frames)')
+    ap.add_argument('out_root', nargs='?', default=None, help='where the <scene>_sharply_interpolated_xM folders go (default: custom_path)')
+    ap.add_argument('--checkpoint', default='', help="reference checkpoint (.pt holding 'state_dict_Model')")
+    ap.add_argument('--mfi', type=int, default=8, help='multiple_MFI (main.py:98)')
+    ap.add_argument('--n-tst', type=int, default=3, help='N_tst recursive boosts (main.py:101)')
+    ap.add_argument('--dtype', default='fp16', choices=['fp16', 'fp32'])
+    ap.add_argument('--batch', type=int, default=4)
+    ap.add_argument('--ext', default='.png')
+    ap.add_argument('--all-recursions', action='store_true', help='compute every Sharps_final entry (default: the last one only, which is all that is written)')
+    a = ap.parse_args(argv)
+    from . import DeMFInet, HyperParams, synthetic_state_dict
+    from .weights import load_checkpoint
+    rank, local, world = (int(os.environ.get(k, d)) for k, d in (('RANK', 0), ('LOCAL_RANK', 0), ('WORLD_SIZE', 1)))
+    if not torch.cuda.is_available():
+        raise SystemExit('demfi_amd.clip: no GPU visible -- the forward path is HIP-only (no CPU fallback)')
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    D.init(world, rank, local)
+    model = DeMFInet(HyperParams(gpu=local), dtype=torch.float16 if a.dtype == 'fp16' else torch.float32)
+    if rank == 0:
+        model.load_state_dict(load_checkpoint(a.checkpoint) if a.checkpoint else synthetic_state_dict(0))
+    model = model.to(dev).eval()
+    D.broadcast_state_dict(model, world, device=dev)
+    root = a.custom_path.rstrip(os.sep)
+    scenes = sorted(d for d in os.listdir(root) if os.path.isdir(os.path.join(root, d)) and '_sharply_interpolated_x' not in d)
+    if scenes:
+        jobs = [(s, os.path.join(root, s)) for s in scenes]
+        out_root = a.out_root or root
+    else:                                                # a single scene folder
+        jobs = [(os.path.basename(root), root)]
+        out_root = a.out_root or os.path.dirname(root)
+    pool = clipio.FramePool()
+    runners = {}
+    tot_w = tot_f = 0
+    t0 = time.perf_counter()
+    for scene, path in jobs:
+        names = sorted(f for f in os.listdir(path) if f.endswith(a.ext))
+        if len(names) < 4:
+            print('demfi_amd.clip: %s has %d frames (< 4), skipped' % (path, len(names)))
+            continue
+        h, w = clipio.read_frame(os.path.join(path, names[0])).shape[:2]
+        cr = runners.get((h, w))
+        if cr is None:
+            cr = runners[(h, w)] = ClipRunner(model, h, w, a.n_tst, a.mfi, batch=a.batch, world=world, rank=rank,
+                                              final_only=not a.all_recursions)
+        nw, nf = cr.run_folder(path, os.path.join(out_root, scene + '_sharply_interpolated_x' + str(a.mfi)), pool=pool, ext=a.ext)
+        tot_w += nw
+        tot_f += nf
+    pool.close()
+    torch.cuda.synchronize()
+    dt = D.max_over_ranks(time.perf_counter() - t0, dev)
+    tw, tf = (D.sum_over_ranks([float(tot_w), float(tot_f)], dev).tolist() if world > 1 else (tot_w, tot_f))
+    if rank == 0:
+        print(json.dumps({'scenes': len(jobs), 'windows': int(tw), 'png_written': int(tf), 'seconds': round(dt, 2), 'ranks': world,
+                          'St_frames_per_s': round(tw * (a.mfi - 1) / dt, 2) if dt > 0 else None,
+                          'weights': os.path.basename(a.checkpoint) if a.checkpoint else 'synthetic_state_dict(0) (random init: no checkpoint given)',
+                          'out_root': out_root}))
+    D.finalize()
+
+
+if __name__ == '__main__':
+    main()

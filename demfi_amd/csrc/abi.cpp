@@ -109,7 +109,7 @@ extern "C" int demfi_graph_end(void* stream, void** graph_exec_out)
     DEMFI_HIP_CHECK(hipStreamEndCapture((hipStream_t)stream, &g));
     hipGraphExec_t ge = nullptr;
     hipError_t e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
-    hipGraphDestroy(g);
+    (void)hipGraphDestroy(g);
     if (e != hipSuccess) return demfi_set_error(DEMFI_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e));
     *graph_exec_out = (void*)ge;
     return DEMFI_OK;

@@ -3,7 +3,9 @@
 set -e
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -I../../include -Wno-unused-result -Wno-pass-failed $DEMFI_EXTRA_FLAGS"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -I../../include -Wno-unused-result -Wno-pass-failed -Werror=inline-asm -Werror=unused-value"
+# experiment builds only (--ablation / --trace below) take extra flags from the environment; the product compile line is fixed
+XFLAGS="$DEMFI_EXTRA_FLAGS"
 SRCS_HIP="conv.hip pointwise.hip"
 SRCS_CPP="abi.cpp"
 [ -f metrics.hip ] && SRCS_HIP="$SRCS_HIP metrics.hip"
@@ -33,14 +35,14 @@ echo "built $(pwd)/libdemfi_hip.so"
 # DEMFI_CONV_Z, ...); use it with DEMFI_HIP_LIB=$(pwd)/libdemfi_hip_abl.so.  Never loaded by default.
 # --trace: third library whose persistent 64->64 kernels stamp s_memtime at their phase boundaries (tools/phase_trace.py)
 if [ "$1" = "--trace" ]; then
-  $HIPCC $FLAGS $CONV_FLAGS -DDEMFI_TRACE -c conv.hip -o conv_trace.o
+  $HIPCC $FLAGS $XFLAGS $CONV_FLAGS -DDEMFI_TRACE -c conv.hip -o conv_trace.o
   trc=()
   for o in "${objs[@]}"; do [ "$o" = conv.o ] && trc+=(conv_trace.o) || trc+=("$o"); done
   $HIPCC --offload-arch=gfx950 -shared -fPIC "${trc[@]}" -o libdemfi_hip_trace.so -lz -lpthread
   echo "built $(pwd)/libdemfi_hip_trace.so"
 fi
 if [ "$1" = "--ablation" ]; then
-  $HIPCC $FLAGS $CONV_FLAGS -DDEMFI_ABLATION -c conv.hip -o conv_abl.o
+  $HIPCC $FLAGS $XFLAGS $CONV_FLAGS -DDEMFI_ABLATION -c conv.hip -o conv_abl.o
   abl=()
   for o in "${objs[@]}"; do [ "$o" = conv.o ] && abl+=(conv_abl.o) || abl+=("$o"); done
   $HIPCC --offload-arch=gfx950 -shared -fPIC "${abl[@]}" -o libdemfi_hip_abl.so -lz -lpthread

@@ -30,7 +30,12 @@ namespace {
 // Run-time experiment switches of the persistent kernels (env DEMFI_KNOB, read once on the host and copied into this
 // word; 0 = product behaviour):  bit 0: DMA waves at s_setprio 3;  bit 1 (pair kernel): epilogue at priority 2, MFMA
 // phase at 0;  bit 2 (pair kernel): MFMA phase at priority 2, epilogue at 0.
+#if defined(DEMFI_ABLATION) || defined(DEMFI_TRACE)
 __device__ int g_knob = 0;
+#define DEMFI_KNOB_BIT(b) (g_knob & (b))
+#else
+#define DEMFI_KNOB_BIT(b) 0                                      // product build: no device global, no lazy hipMemcpyToSymbol in a launch path
+#endif
 
 // In-kernel phase trace (libdemfi_hip_trace.so, build.sh --trace; never in the product): s_memtime stamps of the first
 // TR_TILES tiles of workgroups 0..TR_WGS-1, [wg][wave][tile][stamp].  MFMA waves: 0 = arrived at barrier A, 1 = released,
@@ -386,7 +391,7 @@ __global__ __launch_bounds__(NT, (NCO <= 1 ? 4 : (NCO == 2 ? 3 : 2))) void conv_
         // ---------------- stage the haloed input tile of this chunk into LDS ----------------------------
         for (int pi = ch.first_piece; pi < ch.first_piece + ch.n_pieces; ++pi) {
 #ifdef DEMFI_ABLATION
-            if (g_knob & 32) break;                              // experiment: no tile staging (garbage operands): what the staging costs
+            if (DEMFI_KNOB_BIT(32)) break;                              // experiment: no tile staging (garbage operands): what the staging costs
 #endif
             const demfi_piece& p = d->pieces[pi];
             const char* src = (const char*)p.v.ptr;
@@ -574,7 +579,7 @@ __global__ __launch_bounds__(NT + 64 * P_NDMA, 1) void conv3x3_c64_persist_kerne
 
     if (wave >= 4) {
         // ================= DMA waves: own every global->LDS transfer, so only THEIR vmcnt tracks them ============
-        if (g_knob & 1) __builtin_amdgcn_s_setprio(3);
+        if (DEMFI_KNOB_BIT(1)) __builtin_amdgcn_s_setprio(3);
         const int dw = wave - 4;
         const demfi_piece& pc = d->pieces[0];
         const char* const src = (const char*)pc.v.ptr;
@@ -1024,7 +1029,7 @@ __global__ __launch_bounds__(SG_NT, 1) void conv3x3_c64_stg_kernel(const demfi_c
 
     if (wave >= 4) {
         // ================= helper waves: tile DMA + the global stores of the staged outputs ==========================
-        if (g_knob & 1) __builtin_amdgcn_s_setprio(2);
+        if (DEMFI_KNOB_BIT(1)) __builtin_amdgcn_s_setprio(2);
         const int dw = wave - 4;
         constexpr int NIW = (P_NI + SG_NH - 1) / SG_NH;          // DMA instructions per helper (11; the last one may not exist)
         const demfi_piece& pc = d->pieces[0];
@@ -1416,7 +1421,7 @@ __global__ __launch_bounds__(NT + 64 * NDMA, 1) void conv3x3_narrow_persist_kern
 
     if (wave >= 4) {
         // ================= DMA wave(s) =======================================================================
-        if (g_knob & 1) __builtin_amdgcn_s_setprio(3);
+        if (DEMFI_KNOB_BIT(1)) __builtin_amdgcn_s_setprio(3);
         const int dw = wave - 4;                                 // this wave issues instructions i with i % NDMA == dw
         constexpr int NIW = NI / NDMA;                           // instructions per tile and wave, rounded DOWN (vmcnt waits err on the safe side)
         // the (at most two) real pieces of the chunk; everything else of the record is zero padding
@@ -2163,7 +2168,7 @@ __global__ __launch_bounds__(NT + 64 * S_NDMA, 1) void conv_sep5_c128_persist_ke
 
     if (wave >= 4) {
         // ================= DMA waves (instruction i of a unit belongs to wave i % S_NDMA) ======================
-        if (g_knob & 1) __builtin_amdgcn_s_setprio(3);
+        if (DEMFI_KNOB_BIT(1)) __builtin_amdgcn_s_setprio(3);
         const int dw = wave - 4;
         const demfi_piece& p0 = d->pieces[d->chunks[0].first_piece];
         const demfi_piece& p1 = d->pieces[d->chunks[1].first_piece];
@@ -2443,7 +2448,12 @@ __global__ __launch_bounds__(NT, 1) void conv_wstream_c64_kernel(const demfi_con
         // business: nobody reads the buffer before the barrier at the end of the unit.
         const unsigned la = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)(buf + i * 1024);
 #if defined(__HIP_DEVICE_COMPILE__)
-        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(la) : "memory", "m0");
+        // m0 (the DMA's LDS base) is a reserved register: naming it as a clobber is undefined behaviour for the compiler (it may keep
+        // its own value live across the statement), so the statement saves and restores it -- m0 is unchanged as far as the compiler
+        // can tell, and the build treats -Winline-asm as an error so that a clobbered reserved register can never come back.
+        unsigned m0_save;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(m0_save) : "v"(g), "s"(la) : "memory");
 #endif
     };
     auto a_load = [&](const Unit& un, int t) {                  // A fragment of step t = (kx, ksl, ky): SGPR base + lane offset, global
@@ -2736,7 +2746,8 @@ extern "C" int demfi_conv2d(const demfi_conv* h, const demfi_conv* dev, void* st
         if (!ok) return demfi_set_error(DEMFI_ERR_ARG, "demfi_conv2d: subtile %d is not eligible for the staged epilogue", sb);
     }
     hipStream_t st = (hipStream_t)stream;
-    {
+#if defined(DEMFI_ABLATION) || defined(DEMFI_TRACE)
+    {   // experiment builds only (a synchronous copy on the first launch: never inside a stream capture)
         static const int knob_set = [] {
             const int k = getenv("DEMFI_KNOB") ? atoi(getenv("DEMFI_KNOB")) : 0;
             if (k) (void)hipMemcpyToSymbol(HIP_SYMBOL(g_knob), &k, sizeof(k));
@@ -2744,6 +2755,7 @@ extern "C" int demfi_conv2d(const demfi_conv* h, const demfi_conv* dev, void* st
         }();
         (void)knob_set;
     }
+#endif
     if ((h->cout_perm != 0) != demfi_persist_eligible(h))
         return demfi_set_error(DEMFI_ERR_ARG, h->cout_perm ? "demfi_conv2d: descriptor packed for a persistent kernel (cout_perm) but not eligible for one (zero_page missing?)"
                                                            : "demfi_conv2d: persistent-kernel layer without cout_perm (build the descriptor with demfi_conv_build)");

@@ -90,11 +90,11 @@ class Plan:
 
     def fsrc_map(self, buf, cin, b=0):
         """Input piece = ALL channels of a fat buffer with an explicit channel -> original-cin list (-1 = unused
-        padding channel, gets zero weights)."""
+        padding channel, gets zero weights).  b=k pins image k, b=None keeps the batch stride (batched conv)."""
         B, h, w, Ct = buf.shape
         assert len(cin) == Ct
-        ptr = buf.data_ptr() + b * h * w * Ct * self.esz
-        return _Src(True, ptr, Ct, w * Ct, 1, 0, self.f32, cin, 0)
+        ptr = buf.data_ptr() + (0 if b is None else b) * h * w * Ct * self.esz
+        return _Src(True, ptr, Ct, w * Ct, 1, h * w * Ct if b is None else 0, self.f32, cin, 0)
 
     def tsrc(self, buf, cin, c0=0, nch=None):
         """Input piece from a planar fp32 buffer [C,h,w]; cin = list of original input channels."""

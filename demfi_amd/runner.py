@@ -22,15 +22,17 @@ from .harness import t_schedule
 
 
 class WindowRunner:
-    def __init__(self, model, height, width, n_tst=3, mfi=8, use_graph=True, final_only=False, n_ctx=None, n_trunk=None):
+    def __init__(self, model, height, width, n_tst=3, mfi=8, use_graph=True, final_only=False, n_ctx=None, n_trunk=None, auto=False):
         """final_only: produce the frames of the LAST recursion only (what test / test_custom consume, utils.py:1430-1434):
         the warp + D2 tail of the earlier recursions feeds nothing else and is skipped (batched plan only); the delivered
         frames are bit-identical.
         n_ctx / n_trunk: per-t contexts batched into one launch sequence / trunk buffer sets pipelined over windows.  Explicit
         values are taken as given (n_ctx must divide M-1 for the batched plan; the workspace must fit or engine creation
         fails loudly).  None = default: env DEMFI_NCTX / DEMFI_NTRUNK, else the configuration of an engine the model
-        already holds for this frame size, else a probe of the free memory -- throughput then depends on co-tenants, so
-        the chosen values are exposed as ``self.n_ctx`` / ``self.n_trunk`` / ``self.config`` and printed by bench.py."""
+        already holds for this frame size, else FIXED values that depend on the arguments only (7 / 3 at 720p x8 fp16, 7 / 2 at
+        720p fp32 N_tst=5, 5 / 3 at 1080p x16); ``auto=True`` (or env DEMFI_AUTO=1) opts into a probe of the free memory instead.  The chosen values and
+        how they were chosen are exposed as ``self.n_ctx`` / ``self.n_trunk`` / ``self.config`` and printed by bench.py."""
+        auto = bool(auto or os.environ.get('DEMFI_AUTO') == '1')
         self.final_only = bool(final_only)
         self.h, self.w = height, width
         H = (height + 31) // 32 * 32
@@ -45,36 +47,54 @@ class WindowRunner:
         cached = getattr(model, '_engines', {}).get((H, W, model.path_dtype)) if self.tb else None
         if cached is not None and cached.n_ctx <= 1:     # a plain forward()'s engine says nothing about a runner's configuration
             cached = None
-        how = 'explicit'
-        if n_trunk is None:
-            n_trunk = int(env_trunk) if env_trunk else (cached.n_trunk if cached is not None else None)
-        self.n_trunk = (n_trunk or 2) if use_graph else 1
+        how = 'explicit' if (n_ctx is not None or n_trunk is not None) else None
+        if n_trunk is None and env_trunk:
+            n_trunk, how = int(env_trunk), 'env'
+        if n_trunk is None and cached is not None:
+            n_trunk, how = cached.n_trunk, 'cached engine'
+        lib = L.load()
+        dt = L.F32 if model.path_dtype == torch.float32 else L.F16
         if self.tb:
-            lib = L.load()
-            dt = L.F32 if model.path_dtype == torch.float32 else L.F16
-            if n_ctx is None and cached is not None and cached.n_ctx > 1 and (mfi - 1) % cached.n_ctx == 0 and not env_ctx:
+            if n_ctx is None and env_ctx:
+                n_ctx, how = int(env_ctx), 'env'
+            if n_ctx is None and cached is not None and (mfi - 1) % cached.n_ctx == 0:
                 n_ctx, how = cached.n_ctx, 'cached engine'
-            if n_ctx is None:
-                # the largest divisor of M-1 (<= DEMFI_NCTX, default 8) whose workspace fits the free memory
-                how = 'env' if env_ctx else 'memory probe'
-                cap = int(env_ctx or 8)
+            if n_ctx is None and auto:
+                # opt-in probe: the largest divisor of M-1 (<= 8) whose workspace fits 85 % of the free memory.  The launch plan
+                # (and the throughput) then depends on co-tenants of the GPU -- never the default
+                how = 'memory probe'
                 free = torch.cuda.mem_get_info(model.device)[0]
                 n_ctx = 1
-                for d in range(min(cap, mfi - 1), 1, -1):
-                    if (mfi - 1) % d == 0 and 0 < lib.demfi_workspace_bytes(H, W, max(n_tst, 3), dt, self.n_trunk, d) < 0.85 * free:
+                for d in range(min(8, mfi - 1), 1, -1):
+                    if (mfi - 1) % d == 0 and 0 < lib.demfi_workspace_bytes(H, W, max(n_tst, 3), dt, n_trunk or 2, d) < 0.85 * free:
                         n_ctx = d
                         break
-                # a third trunk set (its own per-t sets and stream) lets three consecutive windows overlap: +0.7 % at 720p for
-                # 40 GB; taken only when nothing was specified and it leaves half of the GPU's memory free
                 if n_ctx > 1 and n_trunk is None and 0 < lib.demfi_workspace_bytes(H, W, max(n_tst, 3), dt, 3, n_ctx) < 0.5 * free:
-                    self.n_trunk = 3
+                    n_trunk = 3
+            if n_ctx is None:
+                # FIXED default, a function of the arguments only: all time instants of a window in one launch sequence when
+                # M-1 <= 8 (7 at x8), else the largest divisor of M-1 that is <= 8 (5 at x16); three trunk sets (a third window in
+                # flight: +0.7 % at 720p) when their workspace stays below 144 GB = half of an MI355X's HBM, two otherwise.  Engine creation fails loudly when the
+                # workspace does not fit the GPU -- nothing is silently scaled down.
+                how = how or 'fixed default'
+                n_ctx = max(d for d in range(1, min(8, mfi - 1) + 1) if (mfi - 1) % d == 0)
+                if n_trunk is None:
+                    n_trunk = 3 if 0 < lib.demfi_workspace_bytes(H, W, max(n_tst, 3), dt, 3, n_ctx) <= 144 * 10 ** 9 else 2
             elif n_ctx > 1 and (mfi - 1) % n_ctx:
                 raise ValueError('WindowRunner: n_ctx=%d must divide M-1=%d for the batched per-t plan' % (n_ctx, mfi - 1))
             self.n_ctx = int(n_ctx)
             self.tb = self.n_ctx > 1
+        self.n_trunk = (n_trunk or 2) if use_graph else 1
         if not self.tb:
+            if n_ctx is None:
+                how = 'env' if env_ctx else (how or 'fixed default')
             self.n_ctx = (int(n_ctx) if n_ctx else min(int(env_ctx or 5), max(1, mfi - 1))) if (use_graph and mfi > 2) else 1
             self.final_only = False                  # a mode of the batched plan
+        how = how or 'fixed default'
+        need = lib.demfi_workspace_bytes(H, W, max(n_tst, 3), dt, self.n_trunk, self.n_ctx)
+        if torch.cuda.is_available() and need > torch.cuda.get_device_properties(model.device).total_memory:
+            raise RuntimeError('WindowRunner: workspace of %.1f GB for n_ctx=%d, n_trunk=%d at %dx%d exceeds the GPU memory; pass smaller '
+                               'n_ctx / n_trunk (or auto=True to probe)' % (need / 1e9, self.n_ctx, self.n_trunk, H, W))
         self.config = {'n_ctx': self.n_ctx, 'n_trunk': self.n_trunk, 'batched': self.tb, 'final_only': self.final_only, 'chosen_by': how}
         self.model = model
         self._HW = (H, W)
@@ -279,9 +299,11 @@ class WindowRunner:
         return load
 
     # ---------------------------------------------------------------------------------------------------------
-    def run_window(self, x, with_d1=False):
+    def run_window(self, x, with_d1=False, s0_at=0, s1_at=0):
         """x: [1,3,4,h,w] fp32 on the GPU.  Returns (St [M-1,3,h,w], S0S1 [2,3,h,w]) -- views of reused buffers.
-        with_d1: also the Stage-I frames ``Sharps_prime`` (DeMFInet.py:95-103): (St, S0S1, St' [M-1,3,h,w], S0'S1' [2,3,h,w])."""
+        with_d1: also the Stage-I frames ``Sharps_prime`` (DeMFInet.py:95-103): (St, S0S1, St' [M-1,3,h,w], S0'S1' [2,3,h,w]).
+        s0_at / s1_at: index of the time instant whose S0 / S1 are kept (Stage I's S0' / S1' depend on t through the refinement
+        module, DeMFInet.py:75-103; the reference's test() keeps S0 at t = 0.5 and S1 at the last t, main.py:918-955, 633-645)."""
         load = self._loader(x)
         cur = self._begin()
         if with_d1 and getattr(self, 'out_d1', None) is None:
@@ -290,14 +312,16 @@ class WindowRunner:
 
         def emit(j, fin, sh, ctx=None):
             self.out[j].copy_(fin[2, :, :self.h, :self.w], non_blocking=True)
-            if j == 0:
+            if j == s0_at:
                 self.s01[0].copy_(fin[0, :, :self.h, :self.w], non_blocking=True)
+            if j == s1_at:
                 self.s01[1].copy_(fin[1, :, :self.h, :self.w], non_blocking=True)
             if with_d1:
                 d1 = ctx['sharp1']                   # [9,H,W]: S0', S1', St'
                 self.out_d1[j].copy_(d1[6:9, :self.h, :self.w], non_blocking=True)
-                if j == 0:
+                if j == s0_at:
                     self.s01_d1[0].copy_(d1[0:3, :self.h, :self.w], non_blocking=True)
+                if j == s1_at:
                     self.s01_d1[1].copy_(d1[3:6, :self.h, :self.w], non_blocking=True)
         self._window(load, emit, emit_ctx=with_d1)
         self._end(cur)

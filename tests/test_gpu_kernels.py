@@ -210,7 +210,7 @@ def test_narrow_persistent_conv(case, H, W, batch):
         if pc == 'p8':
             b = pl._fat(H, W, 8, batch)
             b.copy_(torch.randn(b.shape, device=DEV))
-            srcs.append(pl.fsrc_map(b, [cin + i for i in range(5)] + [-1] * 3) if batch == 1 else None)
+            srcs.append(pl.fsrc_map(b, [cin + i for i in range(5)] + [-1] * 3, b=None))     # batch stride kept: the batched plan runs this shape at batch 7
             xs.append(b[..., :5])
             cin += 5
         else:
@@ -219,8 +219,6 @@ def test_narrow_persistent_conv(case, H, W, batch):
             srcs.append(pl.fsrc(b, cin))
             xs.append(b)
             cin += pc
-    if any(s is None for s in srcs):
-        pytest.skip('fsrc_map pins one image')
     out = pl._fat(H, W, cout, batch)
     r = pl._fat(H, W, cout, batch) if res else None
     if res:

@@ -245,3 +245,42 @@ def test_batched_per_t_plan_equals_per_context_plans(synthetic_sd, dtype):
     assert len(thin) == 1 and thin[0].nch == 3 and thin[0].bt.nb == NC and thin[0].bt.o > 0
     d1 = [o for o in tb if o.name.decode() == 'Dec_first'][0]
     assert eng.conv_desc(d1.conv).batch == 3 * NC
+
+
+def test_load_checkpoint_reads_the_reference_layout(tmp_path, synthetic_sd):
+    """main.py:316, 351: ``model_net.load_state_dict(checkpoint['state_dict_Model'])`` on the file SaveManager wrote
+    (utils.py:47-66 stores the state_dict beside epoch / optimizer entries).  ``--checkpoint`` of bench.py / demfi_amd.clip goes
+    through weights.load_checkpoint; DataParallel's ``module.`` prefix and a bare state_dict file are accepted, junk is not."""
+    from demfi_amd.weights import load_checkpoint
+    sd = {k: v.clone() for k, v in synthetic_sd.items()}
+    p1, p2, p3 = str(tmp_path / 'a_latest.pt'), str(tmp_path / 'b.pt'), str(tmp_path / 'c.pt')
+    torch.save({'last_epoch': 7, 'state_dict_Model': {'module.' + k: v.half() for k, v in sd.items()}, 'best_PSNR': 0.0}, p1)
+    torch.save(sd, p2)
+    torch.save({'state_dict_Model': {}}, p3)
+    got = load_checkpoint(p1)
+    assert set(got) == set(sd) and all(v.dtype == torch.float32 for v in got.values())
+    assert all(torch.equal(got[k], sd[k].half().float()) for k in sd)
+    m = DeMFInet(HyperParams())
+    m.load_state_dict(load_checkpoint(p2))                      # strict: 260 keys, shapes as registered
+    assert torch.equal(m.state_dict()['Dec_last2_2.weight'], sd['Dec_last2_2.weight'])
+    with pytest.raises(ValueError):
+        load_checkpoint(p3)
+
+
+def test_rank_affinity_slices_a_numa_node_between_its_ranks():
+    """tools/run_node.sh: ranks whose GPUs share a NUMA node get disjoint slices of that node's cores, the node comes
+    from the PCI address of HIP device LOCAL_RANK; without NUMA information the cores are split evenly by rank."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('rank_affinity', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools', 'rank_affinity.py'))
+    ra = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ra)
+    assert ra.parse_cpulist('0-3,8,10-11') == [0, 1, 2, 3, 8, 10, 11] and ra.fmt_cpulist([4, 5]) == '4,5'
+    nodes = [0, 0, 0, 0, 1, 1, 1, 1]
+    node_cpus = {0: list(range(0, 48)) + list(range(96, 144)), 1: list(range(48, 96)) + list(range(144, 192))}
+    allc = list(range(192))
+    got = [ra.affinity(r, 8, nodes, node_cpus, allc) for r in range(8)]
+    assert all(len(c) == 24 for c, _ in got) and [n for _, n in got] == nodes
+    assert sorted(c for cs, _ in got for c in cs) == allc                    # disjoint, every core used once
+    assert set(got[5][0]) <= set(node_cpus[1])
+    even = [ra.affinity(r, 4, [None] * 4, {}, list(range(10))) for r in range(4)]
+    assert [c for c, _ in even] == [[0, 1], [2, 3], [4, 5], [6, 7]] and all(n == -1 for _, n in even)

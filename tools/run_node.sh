@@ -1,6 +1,6 @@
 #!/bin/bash
 # One-node launcher for the clip-parallel bench / clip runs: one process per GPU over RCCL (torch.distributed backend "nccl"),
-# each rank pinned to the CPU cores and memory of the NUMA node its GPU hangs off, host thread pools capped so that 8 ranks
+# each rank pinned to ITS SLICE of the CPU cores (and to the memory) of the NUMA node its GPU hangs off, host thread pools capped so that 8 ranks
 # do not oversubscribe the host (the PNG codec and the pinned-memory copies are the only host work: SURVEY.md section 8e/8f).
 #
 #   tools/run_node.sh [N_GPUS] [bench.py arguments ...]          e.g.  tools/run_node.sh 8 --steps 20 --warmup 5
@@ -20,22 +20,16 @@ fi
 # ---- per-rank child -----------------------------------------------------------------------------------------------
 R=${LOCAL_RANK:-0}
 NCPU=$(nproc)
-# NUMA node of GPU R: /sys/class/drm/cardX/device/numa_node of the R-th render-capable amdgpu device (falls back to an even split)
-NODE=-1
-i=0
-for d in /sys/class/drm/card*/device; do
-  [ -e "$d/vendor" ] && [ "$(cat "$d/vendor")" = "0x1002" ] || continue
-  if [ "$i" = "$R" ]; then NODE=$(cat "$d/numa_node" 2>/dev/null || echo -1); break; fi
-  i=$((i + 1))
-done
+# CPU list and NUMA node of this rank: the node of HIP device $R (PCI address from the HIP runtime -> /sys/bus/pci/devices/<addr>/
+# numa_node), its cores SLICED between the ranks whose GPUs share the node (tools/rank_affinity.py); even split without NUMA info
+read -r CPUS NODE <<<"$(python "$ROOT/tools/rank_affinity.py" "$R" "$DEMFI_NODE_N" 2>/dev/null || echo "")"
 PER=$((NCPU / DEMFI_NODE_N)); [ "$PER" -lt 1 ] && PER=1
-if [ "$NODE" -ge 0 ] && command -v numactl >/dev/null 2>&1; then
-  # cores of that NUMA node, split evenly between the ranks that share it
-  BIND="numactl --cpunodebind=$NODE --membind=$NODE"
-else
-  LO=$((R * PER)); HI=$((LO + PER - 1))
-  BIND="taskset -c $LO-$HI"
-  command -v taskset >/dev/null 2>&1 || BIND=""
+if [ -n "$CPUS" ]; then PER=$(echo "$CPUS" | tr ',' '\n' | wc -l); fi
+BIND=""
+if [ -n "$CPUS" ] && [ "${NODE:--1}" -ge 0 ] && command -v numactl >/dev/null 2>&1; then
+  BIND="numactl --physcpubind=$CPUS --membind=$NODE"
+elif [ -n "$CPUS" ] && command -v taskset >/dev/null 2>&1; then
+  BIND="taskset -c $CPUS"
 fi
 # host threads: the frame pool (decode / encode) gets this rank's share of the cores, the math libraries stay single-threaded
 export DEMFI_IO_THREADS=${DEMFI_IO_THREADS:-$PER} OMP_NUM_THREADS=1 MKL_NUM_THREADS=1
