@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('DEMFI_HIP_LIB') or os.path.join(_HERE, 'csrc', 'libdemfi_hip.so')   # override: ablation builds
 
 F16, F32 = 0, 1
-ABI_VERSION = 5
+ABI_VERSION = 6
 ACT_NONE, ACT_RELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3
 MODE_STORE, MODE_MUL, MODE_GRU = 0, 1, 2
 MAX_PIECES, MAX_CHUNKS, MAX_SEGS, MAX_OCTS = 48, 40, 8, 32
@@ -44,7 +44,8 @@ class Conv(C.Structure):
                 ('chunks', Chunk * MAX_CHUNKS), ('pieces', Piece * MAX_PIECES), ('segs', Seg * MAX_SEGS),
                 ('oct_seg', C.c_int32 * MAX_OCTS), ('oct_n', C.c_int32 * MAX_OCTS), ('oct_ch', C.c_int32 * MAX_OCTS),
                 ('sub_seg', C.c_int32 * (MAX_OCTS // 4)),
-                ('lw_magic', C.c_uint32), ('u8_iter', C.c_int32), ('u8_sink', C.c_void_p)]
+                ('lw_magic', C.c_uint32), ('u8_iter', C.c_int32), ('u8_sink', C.c_void_p),
+                ('pack', View), ('pack_oct_ch', C.c_int32 * 4)]
 
 
 class U8Sink(C.Structure):

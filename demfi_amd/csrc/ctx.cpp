@@ -529,6 +529,14 @@ struct Builder {
     int status = DEMFI_OK;
     const demfi_u8_sink* sink_for_next = nullptr;   // uint8 sink record of the NEXT conv() call (Dec_last2_2)
     int sink_iter = 0;
+    // packed copy of the NEXT conv() call's thin outputs (demfi_conv.pack): NHWC view + channel of each octet (-1 = not packed)
+    demfi_view pack_for_next = {nullptr, 0, 0, 0, 0, 0, 0};
+    int pack_ch_for_next[4] = {-1, -1, -1, -1};
+    void pack_next(demfi_view v, int c0, int c1 = -1, int c2 = -1, int c3 = -1)
+    {
+        pack_for_next = v;
+        pack_ch_for_next[0] = c0; pack_ch_for_next[1] = c1; pack_ch_for_next[2] = c2; pack_ch_for_next[3] = c3;
+    }
     // ---- batched per-t plan (demfi_forward_tb): build_t on context 0 of trunk set tb_k with tb = n_ctx -----------------
     int tb = 1, tb_k = 0;
     // the buffer a device pointer lies in: per-t buffer of context 0 (returns its context stride in bytes), trunk buffer (0),
@@ -649,7 +657,10 @@ struct Builder {
         for (size_t i = 0; i < dsts.size(); ++i)
             cd[i] = {dsts[i].dst, dsts[i].res, dsts[i].aux, dsts[i].act, dsts[i].mode, dsts[i].scale, dsts[i].dy, dsts[i].dx,
                      (int32_t)dsts[i].couts.size(), dsts[i].couts.data()};
+        demfi_view pack_v = pack_for_next;
+        pack_for_next.ptr = nullptr;
         if (tb > 1) {
+            if (!tb_view(pack_v, batch, name.c_str())) return;
             for (auto& x : cs) if (!tb_view(x.v, batch, name.c_str())) return;
             for (auto& x : cd) if (!tb_view(x.dst, batch, name.c_str()) || !tb_view(x.res, batch, name.c_str()) || !tb_view(x.aux, batch, name.c_str())) return;
             batch *= tb;
@@ -689,6 +700,8 @@ struct Builder {
         bc.d.u8_sink = sink_for_next;                // set by the caller for the frame-producing layer only
         bc.d.u8_iter = sink_iter;
         sink_for_next = nullptr;
+        bc.d.pack = pack_v;
+        for (int g = 0; g < 4; ++g) bc.d.pack_oct_ch[g] = pack_v.ptr ? pack_ch_for_next[g] : -1;
         c->descs.push_back(bc.d);
         demfi_op op;
         memset(&op, 0, sizeof(op));
@@ -1012,6 +1025,8 @@ struct Builder {
                     conv(th, nm + "b", {fsrc(B["d2"], 0)},
                          {D(phase_view(fview(B["rF"], 0, 1), dy, dx), range(0, 64), T, DEMFI_MODE_STORE, phase_view(fview(aF, 0, 1), dy, dx))},
                          H2, W2, 1, 1, &wb, &bb, &l64);
+                    // the 5 planes also go, as fp16, into the record Mixer.conv_delta1 stages (delta16): no plane-packing launch
+                    pack_next(phase_view(fview(B["delta16"]), dy, dx), 0, 4);
                     conv(th, nm + "f", {fsrc(B["d2"], 0)},
                          {D(phase_view(delta_v(0, 0), dy, dx), range(0, 4), DEMFI_ACT_NONE, DEMFI_MODE_STORE, phase_view(tview(B["ft"]), dy, dx)),
                           D(phase_view(delta_v(0, 4), dy, dx), {4}, DEMFI_ACT_NONE, DEMFI_MODE_STORE, phase_view(tview(ffo, 4), dy, dx))},
@@ -1118,9 +1133,14 @@ struct Builder {
             const Tensor& hin = B[it % 2 ? "frec1" : "frec0"];
             const Tensor& hout = B[it % 2 ? "frec0" : "frec1"];
             {
-                std::vector<const float*> pl;
-                for (int i = 0; i < 5; ++i) pl.push_back(delta_p(it, i));
-                pack(sg, pl, B["delta16"]);
+                // delta16 = the 5 flow / occlusion planes of step `it` as one NHWC record (+ 11 zero channels).  fp16 plan: written by
+                // the producer's thin epilogue (dec3#f for step 0, flow_occ.conv2 of the previous recursion otherwise: demfi_conv.pack);
+                // fp32 plan (general kernel): a plane-packing launch
+                if (c->dtype != DEMFI_F16) {
+                    std::vector<const float*> pl;
+                    for (int i = 0; i < 5; ++i) pl.push_back(delta_p(it, i));
+                    pack(sg, pl, B["delta16"]);
+                }
                 std::vector<int32_t> m = range(0, 5);
                 m.insert(m.end(), 11, -1);
                 conv(sg, p + "Mixer.conv_delta1", {fsrc_map(B["delta16"], m)}, {D(fview(B["de1"]), range(0, 32), R)}, H, W);
@@ -1140,6 +1160,7 @@ struct Builder {
                 h = &hnext;
             }
             conv(sg, p + "flow_occ.conv1", {fsrc(hout, 0)}, {D(fview(B["fo1"]), range(0, 32), R)}, H, W);
+            if (c->dtype == DEMFI_F16) pack_next(fview(B["delta16"]), 0);      // step it+1's record for the next recursion's conv_delta1
             conv(sg, p + "flow_occ.conv2", {fsrc(B["fo1"], 0)},
                  {D(delta_v(it + 1, 0), range(0, 5), DEMFI_ACT_NONE, DEMFI_MODE_STORE, delta_v(it, 0))}, H, W);
             // PWB of the recursion; the kernel also writes Agg3's per-recursion planes [St_new | rflow_t0, rflow_t1 | occ]

@@ -361,6 +361,13 @@ __device__ __forceinline__ void store16(char* p, const float* v)
 // (16 bytes of channels per lane): broadcast LDS reads, 8 unconditional 16-byte gathers, FMA accumulation.
 // Byte strides between the per-t contexts of a batched launch (demfi_batch): context q uses pointer + q * stride.
 struct WarpBatch { int nb; int64_t a, b, o, fa, fb, logit, t, occ, pack; };
+#ifndef DEMFI_WARP_MINW
+#define DEMFI_WARP_MINW 1                                        // minimum waves per SIMD the register allocation must allow (A/B builds)
+#endif
+#ifndef DEMFI_WARP_WGS_DEFAULT
+#define DEMFI_WARP_WGS_DEFAULT 0
+#define DEMFI_WARP_VAR_DEFAULT 0
+#endif
 
 struct WarpRec {                    // 20 dwords per pixel
     int offa[4], offb[4];           // byte offsets of the 4 (clamped) corner records of the two warps
@@ -369,7 +376,7 @@ struct WarpRec {                    // 20 dwords per pixel
 };
 
 template <typename T, int ROWS = 4, bool NTS = false>      // ROWS: rows of the tile = waves of the workgroup; NTS: streaming output stores
-__global__ __launch_bounds__(ROWS * 64) void warp_blend_fat_kernel(demfi_view A0, const float* __restrict__ fa0, demfi_view B0,
+__global__ __launch_bounds__(ROWS * 64, DEMFI_WARP_MINW) void warp_blend_fat_kernel(demfi_view A0, const float* __restrict__ fa0, demfi_view B0,
                                       const float* __restrict__ fb0, const float* __restrict__ logit0,
                                       const float* __restrict__ tptr0, demfi_view O0, int lpp_shift, int H, int W,
                                       float* __restrict__ occ_out0, int* __restrict__ dbg, WarpBatch bt)
@@ -386,15 +393,25 @@ __global__ __launch_bounds__(ROWS * 64) void warp_blend_fat_kernel(demfi_view A0
     const int tiles_x = (W + 63) >> 6;
     const int ntile = tiles_x * ((H + ROWS - 1) / ROWS);
     const int per = (ntile + 7) >> 3;
-    const int tile = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-    if (tile >= ntile) return;
-    const int ty = tile / tiles_x;
-    const int y = ty * ROWS + wave;
-    const int x0 = (tile - ty * tiles_x) << 6;
-    if (y >= H) return;                                            // whole wave past the image (no workgroup barrier below)
-    const int pix0 = y * W + x0;                                   // first pixel of this wave
-    const int nvalid = min(64, W - x0);
     WarpRec* wr = recs + wave * 64;
+    // PERSISTENT tile walk (round 4): gridDim.x / 8 workgroups per XCD walk that XCD's contiguous band of tiles with a stride of
+    // the group size, so at any moment the chip works on a narrow window of each band (a few tile rows: the gathered source rows
+    // stay in the XCD's L2 and the DRAM pages of F0 / F1 / out are visited once, in order) -- the shape in which a plain streaming
+    // kernel of this read : write mix reaches its best rate (tools/microbench/hbm_mix: 512 workgroups 5.6-5.9 TB/s, 2 048: 4.7).
+    // With gridDim.x = 8 * per this is the old one-tile-per-workgroup launch.  The flows / logit of the NEXT tile are fetched
+    // into registers before this tile's gathers, so phase 1 never waits on HBM again after the first tile.
+    const int wg_per_xcd = gridDim.x >> 3;
+    const int band0 = (blockIdx.x & 7) * per;
+    struct Pre { float ax, ay, bx, by, lg; };
+    auto tile_geom = [&](int ti, int& y, int& x0, int& nvalid) {     // false: nothing to do for this wave
+        const int tile = band0 + ti;
+        if (ti >= per || tile >= ntile) return false;
+        const int ty = tile / tiles_x;
+        y = ty * ROWS + wave;
+        x0 = (tile - ty * tiles_x) << 6;
+        nvalid = min(64, W - x0);
+        return y < H;
+    };
     // Batched launch (bt.nb > 1): the per-t contexts are the INNERMOST loop of the tile -- the source rows the seven time instants of
     // a window gather from are the same neighbourhood of F0 / F1 (flow_t scales with t), so after the first context they come
     // from L1 / the XCD's L2 and the features are fetched from HBM once per window instead of once per time instant.
@@ -406,6 +423,24 @@ __global__ __launch_bounds__(ROWS * 64) void warp_blend_fat_kernel(demfi_view A0
     const float* __restrict__ logit = bofs(logit0, q * bt.logit);
     const float* __restrict__ tptr = bofs(tptr0, q * bt.t);
     float* __restrict__ occ_out = bofs(occ_out0, q * bt.occ);
+    const float t = *tptr;
+    auto prefetch = [&](int ti) {
+        Pre p = {0.f, 0.f, 0.f, 0.f, 0.f};
+        int y, x0, nvalid;
+        if (tile_geom(ti, y, x0, nvalid) && lane < nvalid) {
+            const int pix = y * W + x0 + lane;
+            p.ax = fa[pix]; p.ay = fa[hw + pix]; p.bx = fb[pix]; p.by = fb[hw + pix]; p.lg = logit[pix];
+        }
+        return p;
+    };
+    Pre pre = prefetch(blockIdx.x >> 3);
+    for (int ti = blockIdx.x >> 3; ti < per; ti += wg_per_xcd) {
+    int y, x0, nvalid;
+    const bool live = tile_geom(ti, y, x0, nvalid);
+    const Pre cur = pre;
+    pre = prefetch(ti + wg_per_xcd);                              // in flight during this tile's gathers
+    if (!live) continue;                                          // wave-uniform (whole wave past the image / the band)
+    const int pix0 = y * W + x0;                                   // first pixel of this wave
     // ---- phase 1: one lane per pixel -------------------------------------------------------------------
     {
         const int pix = pix0 + lane;
@@ -413,10 +448,9 @@ __global__ __launch_bounds__(ROWS * 64) void warp_blend_fat_kernel(demfi_view A0
         if (lane < nvalid) {
             const int x = x0 + lane;
             bool va, vb;
-            const SampleMap ma = bwarp_map(x, y, fa[pix], fa[hw + pix], H, W, va);
-            const SampleMap mb = bwarp_map(x, y, fb[pix], fb[hw + pix], H, W, vb);
-            const float t = *tptr;
-            const float o0 = sigmoidf_(logit[pix]);
+            const SampleMap ma = bwarp_map(x, y, cur.ax, cur.ay, H, W, va);
+            const SampleMap mb = bwarp_map(x, y, cur.bx, cur.by, H, W, vb);
+            const float o0 = sigmoidf_(cur.lg);
             const float o1 = 1.0f - o0;
             if (occ_out) occ_out[pix] = o0;
             if (dbg) { dbg_store(dbg, 0, hw, pix, ma, va); dbg_store(dbg, 1, hw, pix, mb, vb); }
@@ -447,20 +481,34 @@ __global__ __launch_bounds__(ROWS * 64) void warp_blend_fat_kernel(demfi_view A0
     const char* ap = (const char*)A.ptr + part * 16;
     const char* bp = (const char*)B.ptr + part * 16;
     const int psub = lane >> lpp_shift;
-    auto issue = [&](int it, uint4 (&ra)[4], uint4 (&rb)[4], WarpRec& r) {
+    // issue() needs the 8 corner offsets only, finish() the weights / blend factors only: each re-reads its part of the record from
+    // LDS (broadcast reads) instead of carrying the whole 20-dword record from one to the other -- 2 x 20 live registers less, which
+    // is what lets four waves per SIMD fit (128 registers) without spilling (round 4: the TA is ~70 % busy and the waves wait: more
+    // waves in flight is the lever that is left, profiles/r04_notes.md)
+    auto issue = [&](int it, uint4 (&ra)[4], uint4 (&rb)[4]) {
         int pl = it * ppi + psub;
         if (pl >= nvalid) pl = 0;                                 // clamp: results of out-of-range pixels are never stored
-        r = wr[pl];
+        const WarpRec& r = wr[pl];
+        int oa[4], ob[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { oa[k] = r.offa[k]; ob[k] = r.offb[k]; }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            ra[k] = ld_global16(ap + r.offa[k]);
-            rb[k] = ld_global16(bp + r.offb[k]);
+            ra[k] = ld_global16(ap + oa[k]);
+            rb[k] = ld_global16(bp + ob[k]);
         }
     };
-    auto finish = [&](int it, const uint4 (&ra)[4], const uint4 (&rb)[4], const WarpRec& r) {
+    auto finish = [&](int it, const uint4 (&ra)[4], const uint4 (&rb)[4]) {
         const int pl = it * ppi + psub;
         if (pl >= nvalid) return;
         const int x = x0 + pl;
+        WarpRec r;
+        {
+            const WarpRec& rs = wr[pl];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { r.wa[k] = rs.wa[k]; r.wb[k] = rs.wb[k]; }
+            r.ka = rs.ka; r.kb = rs.kb; r.inv_den = rs.inv_den; r.den = rs.den;
+        }
         float wa[N], wb[N], o[N];
 #pragma unroll
         for (int j = 0; j < N; ++j) { wa[j] = 0.0f; wb[j] = 0.0f; }
@@ -504,17 +552,17 @@ __global__ __launch_bounds__(ROWS * 64) void warp_blend_fat_kernel(demfi_view A0
         }
     };
     uint4 ra0[4], rb0[4], ra1[4], rb1[4];
-    WarpRec r0, r1;
-    issue(0, ra0, rb0, r0);
+    issue(0, ra0, rb0);
     for (int it = 0; it < lpp; it += 2) {                         // lpp is 8 (fp16) or 16 (fp32): always even
-        issue(it + 1, ra1, rb1, r1);
-        finish(it, ra0, rb0, r0);
-        if (it + 2 < lpp) issue(it + 2, ra0, rb0, r0);
-        finish(it + 1, ra1, rb1, r1);
+        issue(it + 1, ra1, rb1);
+        finish(it, ra0, rb0);
+        if (it + 2 < lpp) issue(it + 2, ra0, rb0);
+        finish(it + 1, ra1, rb1);
     }
-    __builtin_amdgcn_wave_barrier();                              // the records are rewritten for the next context
+    __builtin_amdgcn_wave_barrier();                              // the records are rewritten for the next tile / context
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    }
+    }                                                             // tile walk
+    }                                                             // contexts
 }
 
 // Thin (any strides) warp+blend, one thread per pixel, loops over C channels (C = 3 frames).
@@ -865,9 +913,11 @@ static int warp_blend_impl(const demfi_view* A, const float* fa, const demfi_vie
             ((int64_t)(H - 1) * B->sy + (int64_t)(W - 1) * B->sx + C) * elt >= ((int64_t)1 << 31))
             return demfi_set_error(DEMFI_ERR_ARG, "demfi_warp_blend: image spans >= 2^31 bytes (32-bit corner offsets)");
         // ROWS-row x 64-pixel tiles, 8 XCD bands of ceil(ntile / 8) tiles each
-        static const int var = getenv("DEMFI_WARP_VAR") ? atoi(getenv("DEMFI_WARP_VAR")) : 0;   // probe switch (tools/conv_probe.py warp)
+        static const int var = getenv("DEMFI_WARP_VAR") ? atoi(getenv("DEMFI_WARP_VAR")) : DEMFI_WARP_VAR_DEFAULT;   // probe switch (tools/conv_probe.py warp): bit 0 = non-temporal output stores, bit 1 = 8-row tiles
+        static const int wgs = getenv("DEMFI_WARP_WGS") ? atoi(getenv("DEMFI_WARP_WGS")) : DEMFI_WARP_WGS_DEFAULT;   // persistent workgroups per launch (multiple of 8; 0 = one tile per workgroup)
         const int rows = (var & 2) ? 8 : 4;
-        const unsigned nblk = 8u * (unsigned)((((W + 63) / 64) * ((H + rows - 1) / rows) + 7) / 8);
+        unsigned nblk = 8u * (unsigned)((((W + 63) / 64) * ((H + rows - 1) / rows) + 7) / 8);
+        if (wgs >= 8 && (unsigned)(wgs & ~7) < nblk) nblk = (unsigned)(wgs & ~7);
 #define DEMFI_WARP_LAUNCH(TT, R, N)                                                                                   \
         hipLaunchKernelGGL((warp_blend_fat_kernel<TT, R, N>), dim3(nblk), dim3(R * 64), 0, st, *A, fa, *B, fb, logit, t, *out, sh, H, W, \
                            occ_out, dbg_maps, wb)

@@ -113,8 +113,9 @@ class Plan:
         Ct, h, w = buf.shape
         return _view(buf.data_ptr() + c0 * h * w * 4, 1, w, h * w, sb, True)
 
-    def conv(self, seg, name, srcs, dsts, H, W, stride=1, batch=1, weight=None, bias=None):
-        """Append one convolution launch to segment list ``seg``.  H, W: OUTPUT size."""
+    def conv(self, seg, name, srcs, dsts, H, W, stride=1, batch=1, weight=None, bias=None, pack=None):
+        """Append one convolution launch to segment list ``seg``.  H, W: OUTPUT size.
+        pack: (NHWC view, [record channel of octet 0, 1, ...]) -- packed fp16 copy of a thin layer's outputs (demfi_conv.pack)."""
         if weight is None:
             weight = self.sd[name + '.weight']
             bias = self.sd[name + '.bias']
@@ -145,6 +146,12 @@ class Plan:
         bpk = np.zeros(cout_pad.value, np.float32)
         L.check(self.lib.demfi_conv_build(*args, packed.ctypes.data, C.byref(nbytes), bpk.ctypes.data, C.byref(cout_pad)),
                 'conv_build ' + name)
+        for g in range(4):
+            desc.pack_oct_ch[g] = -1
+        if pack is not None:
+            desc.pack = pack[0]
+            for g, chn in enumerate(pack[1]):
+                desc.pack_oct_ch[g] = chn
         desc.wpack = self._add_blob(packed)                 # offsets for now, rebased in _upload()
         desc.bias = self._add_blob(bpk.view(np.uint8))
         self._descs.append(desc)

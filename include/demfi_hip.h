@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DEMFI_ABI_VERSION 5
+#define DEMFI_ABI_VERSION 6
 
 enum demfi_dtype { DEMFI_F16 = 0, DEMFI_F32 = 1 };
 
@@ -142,6 +142,14 @@ typedef struct demfi_conv {
      * Dec_last2_2): device pointer to a demfi_u8_sink record read AT RUN TIME, so a captured hipGraph serves every
      * destination.  NULL = none. */
     const struct demfi_u8_sink* u8_sink;
+    /* optional PACKED COPY of thin outputs (ABI v6; thin epilogue of the narrow persistent kernel only): besides its planar fp32
+     * destination, octet o (o < 4) with pack_oct_ch[o] >= 0 also writes its channels, converted to the path dtype, as channels
+     * pack_oct_ch[o] .. of the NHWC record `pack` (a lane's group of up to 4 channels is one 8-byte store; the unused channels of
+     * the group are written as zeros) -- the record the next convolution stages with vector loads, i.e. what a
+     * demfi_pack_planes launch over these planes would have produced (replaces the per-recursion pack of the flow / occlusion
+     * deltas, DeMFInet.py:130-137 -> 800-812).  pack.ptr == NULL: none.  pack_oct_ch[o] must be a multiple of 4. */
+    demfi_view pack;
+    int32_t pack_oct_ch[4];
 } demfi_conv;
 
 /* uint8 egress fused into the last store: when `iter` equals the descriptor's u8_iter, segment

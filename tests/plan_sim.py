@@ -145,6 +145,12 @@ class PlanSim:
                              dv.sc, dv.sb, dv.is_f32, 0)
                 out = self.strided(dst, n, d.H, d.W, b)
                 out.copy_(v.to(out.dtype))
+                if d.pack.ptr is not None and o < 4 and d.pack_oct_ch[o] >= 0:
+                    # packed copy (demfi_conv.pack): the octet's channels + zeros up to the next multiple of 4, path dtype, NHWC
+                    n4 = (n + 3) // 4 * 4
+                    pv = L.View(d.pack.ptr + d.pack_oct_ch[o] * 2, d.pack.sx, d.pack.sy, d.pack.sc, d.pack.sb, 0, 0)
+                    pk = self.strided(pv, n4, d.H, d.W, b)
+                    pk.copy_(torch.cat([v, torch.zeros(n4 - n, d.H, d.W)], 0).to(pk.dtype))
 
     # ---- whole segments ---------------------------------------------------------------------------------
     def planes(self, ptr, n, H, W):

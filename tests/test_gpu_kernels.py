@@ -355,6 +355,43 @@ def test_narrow_persistent_conv_thin_outputs(case, H, W):
         c0 += n
 
 
+@pytest.mark.parametrize('dsts,pack_ch', [([(5, True)], [0]), ([(4, True), (1, True)], [0, 4]), ([(3, False), (5, True)], [-1, 8])])
+@pytest.mark.parametrize('H,W,batch', [(8, 32, 1), (37, 75, 2), (64, 96, 1)])
+def test_thin_outputs_with_packed_copy(dsts, pack_ch, H, W, batch):
+    """demfi_conv.pack (ABI v6): the thin epilogue also writes its planes as fp16 channels of an NHWC record -- exactly what a
+    demfi_pack_planes launch over the fp32 planes produces (the per-recursion pack of the flow / occlusion deltas,
+    DeMFInet.py:130-137 -> Mixer.conv_delta1, is gone from the plan).  Shapes: flow_occ.conv2 (5 channels straddling the lane
+    halves), dec3's plane launches (4 + 1 in two octets), an octet that is not packed; channels nobody writes keep their value."""
+    torch.manual_seed(23)
+    pl = Plan(H, W, torch.float16, DEV)
+    x = pl._fat(H, W, 32, batch)
+    x.copy_(torch.randn(x.shape, device=DEV))
+    rec = pl._fat(H, W, 16, batch)
+    outs, D, c0 = [], [], 0
+    for n, has_res in dsts:
+        o = torch.zeros((batch * n, H, W), dtype=torch.float32, device=DEV)
+        r = torch.randn((batch * n, H, W), dtype=torch.float32, device=DEV) if has_res else None
+        outs.append(o)
+        sb = n * H * W if batch > 1 else 0
+        D.append(_Dst(pl.tview(o, 0, sb=sb), range(c0, c0 + n), L.ACT_NONE, res=pl.tview(r, 0, sb=sb) if has_res else None))
+        c0 += n
+    wt = torch.randn(c0, 32, 3, 3) * (1.0 / (32 * 9) ** 0.5)
+    pl.conv([], 'thinpack', [pl.fsrc(x, 0)], D, H, W, batch=batch, weight=wt, bias=torch.randn(c0) * 0.1, pack=(pl.fview(rec), pack_ch))
+    pl._upload()
+    for rep in range(2):
+        rec.fill_(-3.0)
+        pl.launch_conv(0, _stream())
+    torch.cuda.synchronize()
+    exp = torch.full((batch, H, W, 16), -3.0, dtype=torch.float16)
+    for (n, _), o, chn in zip(dsts, outs, pack_ch):
+        if chn < 0:
+            continue
+        n4 = (n + 3) // 4 * 4
+        exp[..., chn:chn + n4] = 0.0
+        exp[..., chn:chn + n] = o.view(batch, n, H, W).permute(0, 2, 3, 1).half().cpu()    # the pack kernel's conversion of the stored planes
+    assert torch.equal(rec.cpu(), exp)
+
+
 @pytest.mark.parametrize('kh,kw', [(1, 5), (5, 1)])
 @pytest.mark.parametrize('H,W,batch', [(8, 32, 1), (37, 75, 2), (64, 96, 1), (100, 45, 1), (33, 8, 3)])
 def test_sep_gru_persistent_kernel(kh, kw, H, W, batch):
