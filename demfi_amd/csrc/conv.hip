@@ -1374,10 +1374,13 @@ struct NarrowFrag { uint4 a[2], b0, b1; };
 // flow_occ.conv2 / dec3's planes 2, Dec_last2_2 3); round 2 walked all four unconditionally: 32 scalar residual loads and four
 // dependent LDS bias reads per tile whatever the layer -- the phase trace (profiles/r03_notes.md) shows 1 860 + 2 810 of a 8 260-cycle
 // period of Dec_last2 there.
-template <int NCO, int REC, int EPI, int KS = 3, int NDMA = NarrowCfg<REC, KS>::NDMA, int NOCT = 4>
+// PACK (THIN only): the layer also writes the packed fp16 copy of its planes (demfi_conv.pack) -- its own instantiation: the extra
+// pointers cost the plain thin layers 5-9 % when they were a run-time option (Dec_last2_2 0.485 -> 0.52 ms per 7 t, same box)
+template <int NCO, int REC, int EPI, int KS = 3, int NDMA = NarrowCfg<REC, KS>::NDMA, int NOCT = 4, bool PACK = false>
 __global__ __launch_bounds__(NT + 64 * NDMA, 1) void conv3x3_narrow_persist_kernel(const demfi_conv* __restrict__ d)
 {
     constexpr bool RES = EPI == 1, THIN = EPI == 2;
+    static_assert(!PACK || THIN, "packed copy: thin epilogue only");
     static_assert(!THIN || NCO == 1, "thin epilogue: one 32-cout subtile");
     using Cfg = NarrowCfg<REC, KS>;
     constexpr int P_LW = Cfg::LW, P_NP = Cfg::NP, PAD = Cfg::PAD;      // shadow the 3x3 constants of the 64-channel kernel
@@ -1568,7 +1571,7 @@ __global__ __launch_bounds__(NT + 64 * NDMA, 1) void conv3x3_narrow_persist_kern
     // optional packed copy (demfi_conv.pack): this lane's group of octet g goes to channels pack_oct_ch[g] + 4 hi .. of the NHWC record
     half_t* pk_dst[4] = {nullptr, nullptr, nullptr, nullptr};
     int64_t pk_sx = 0, pk_sy = 0, pk_sb = 0;
-    if constexpr (THIN) {
+    if constexpr (PACK) {
         if (d->pack.ptr != nullptr) {
             pk_sx = d->pack.sx; pk_sy = d->pack.sy; pk_sb = d->pack.sb;
 #pragma unroll
@@ -1725,26 +1728,6 @@ __global__ __launch_bounds__(NT + 64 * NDMA, 1) void conv3x3_narrow_persist_kern
                     apply_act_n<4>(v, t_act[g]);
                     const int oy = oy0 + wave * 2 + p, oxx = ox0 + lx;
                     if (s_dst[g] != nullptr) {                  // wave-uniform: crop + denorm255 + uint8 truncation instead of the fp32 store
-                        // Fast path (round 4): a pixel is 3 bytes, so 4 consecutive pixels are 3 aligned dwords.  Every lane packs its
-                        // 3 bytes, takes its right neighbour's through a quad DPP, and lanes 0-2 of a quad store one dword each: 2 store
-                        // instructions of 24 dwords per row instead of 3 byte-store instructions with a 3-byte lane stride (the byte
-                        // version made Dec_last2_2 0.09 ms slower than its fp32 store: VERDICT r3 weak #7).  Needs 4-byte aligned rows
-                        // and a tile that lies inside the crop horizontally; anything else takes the byte path below.
-                        if (((s_w * 3) & 3) == 0 && (((uintptr_t)s_dst[g]) & 3) == 0 && ox0 + TW <= s_w) {   // wave-uniform
-                            unsigned wpk = 0;
-#pragma unroll
-                            for (int j = 0; j < 3; ++j) {
-                                double q = ((double)v[j] + 1.0) / 2.0;
-                                q = q < 0.0 ? 0.0 : (q > 1.0 ? 1.0 : q);
-                                wpk |= (unsigned)(unsigned char)(q * 255.0) << (8 * j);
-                            }
-                            const unsigned wnx = (unsigned)__builtin_amdgcn_update_dpp(0, (int)wpk, 0xF9, 0xF, 0xF, false);   // quad_perm [1,2,3,3]
-                            const int qd = lane & 3;
-                            const unsigned dwv = (wpk >> (8 * qd)) | (wnx << (24 - 8 * qd));
-                            if (hi == 0 && qd < 3 && oy < s_h)
-                                *gp<unsigned>(s_dst[g] + ((int64_t)oy * s_w + ox0 + (lx & ~3)) * 3 + 4 * qd) = dwv;
-                            continue;
-                        }
                         if (hi == 0 && oy < s_h && oxx < s_w) {
                             unsigned char* bp = s_dst[g] + ((int64_t)oy * s_w + oxx) * 3;
 #pragma unroll
@@ -1761,7 +1744,7 @@ __global__ __launch_bounds__(NT + 64 * NDMA, 1) void conv3x3_narrow_persist_kern
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
                             if (j < t_nq[g]) *gp<float>(dp + j * t_dsc[g]) = v[j];
-                        if (pk_dst[g] != nullptr) {             // lane-divergent only through hi (lanes without a valid channel do not write)
+                        if (PACK && pk_dst[g] != nullptr) {     // lane-divergent only through hi (lanes without a valid channel do not write)
                             h4_t o;
 #pragma unroll
                             for (int j = 0; j < 4; ++j) o[j] = j < t_nq[g] ? (half_t)v[j] : (half_t)0.0f;
@@ -1831,6 +1814,13 @@ int launch_narrow(const demfi_conv* h, const demfi_conv* dev, hipStream_t st, bo
             DEMFI_LDS_ATTR((conv3x3_narrow_persist_kernel<1, REC, 2, KS, ND, 2>));
             DEMFI_LDS_ATTR((conv3x3_narrow_persist_kernel<1, REC, 2, KS, ND, 3>));
             const dim3 blk(NT + 64 * ND);
+            if (h->pack.ptr != nullptr) {                        // packed copy: the deltas' producers have 1 or 2 live octets
+                DEMFI_LDS_ATTR((conv3x3_narrow_persist_kernel<1, REC, 2, KS, ND, 1, true>));
+                DEMFI_LDS_ATTR((conv3x3_narrow_persist_kernel<1, REC, 2, KS, ND, 2, true>));
+                if (noct == 1)      hipLaunchKernelGGL((conv3x3_narrow_persist_kernel<1, REC, 2, KS, ND, 1, true>), dim3(grid), blk, lds, st, dev);
+                else if (noct == 2) hipLaunchKernelGGL((conv3x3_narrow_persist_kernel<1, REC, 2, KS, ND, 2, true>), dim3(grid), blk, lds, st, dev);
+                else return demfi_set_error(DEMFI_ERR_ARG, "demfi_conv2d: packed copy needs 1 or 2 live octets, got %d", noct);
+            } else
             if (noct == 1)      hipLaunchKernelGGL((conv3x3_narrow_persist_kernel<1, REC, 2, KS, ND, 1>), dim3(grid), blk, lds, st, dev);
             else if (noct == 2) hipLaunchKernelGGL((conv3x3_narrow_persist_kernel<1, REC, 2, KS, ND, 2>), dim3(grid), blk, lds, st, dev);
             else if (noct == 3) hipLaunchKernelGGL((conv3x3_narrow_persist_kernel<1, REC, 2, KS, ND, 3>), dim3(grid), blk, lds, st, dev);

@@ -365,8 +365,8 @@ struct WarpBatch { int nb; int64_t a, b, o, fa, fb, logit, t, occ, pack; };
 #define DEMFI_WARP_MINW 1                                        // minimum waves per SIMD the register allocation must allow (A/B builds)
 #endif
 #ifndef DEMFI_WARP_WGS_DEFAULT
-#define DEMFI_WARP_WGS_DEFAULT 0
-#define DEMFI_WARP_VAR_DEFAULT 0
+#define DEMFI_WARP_WGS_DEFAULT 0                                 // one tile per workgroup: persistent walks measured 0-14 % SLOWER (profiles/r04_notes.md)
+#define DEMFI_WARP_VAR_DEFAULT 1                                 // streaming output stores: -7 % in sequence (the outputs no longer evict F0 / F1 from the Infinity Cache)
 #endif
 
 struct WarpRec {                    // 20 dwords per pixel
@@ -375,7 +375,7 @@ struct WarpRec {                    // 20 dwords per pixel
     float ka, kb, inv_den, den;     // (1-t)*o0, t*(1-o0), 1/den, den
 };
 
-template <typename T, int ROWS = 4, bool NTS = false>      // ROWS: rows of the tile = waves of the workgroup; NTS: streaming output stores
+template <typename T, int ROWS = 4, bool NTS = false, bool NTL = false>      // ROWS: rows of the tile = waves of the workgroup; NTS: streaming output stores; NTL: streaming gathers (A/B)
 __global__ __launch_bounds__(ROWS * 64, DEMFI_WARP_MINW) void warp_blend_fat_kernel(demfi_view A0, const float* __restrict__ fa0, demfi_view B0,
                                       const float* __restrict__ fb0, const float* __restrict__ logit0,
                                       const float* __restrict__ tptr0, demfi_view O0, int lpp_shift, int H, int W,
@@ -494,8 +494,13 @@ __global__ __launch_bounds__(ROWS * 64, DEMFI_WARP_MINW) void warp_blend_fat_ker
         for (int k = 0; k < 4; ++k) { oa[k] = r.offa[k]; ob[k] = r.offb[k]; }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            ra[k] = ld_global16(ap + oa[k]);
-            rb[k] = ld_global16(bp + ob[k]);
+            if constexpr (NTL) {
+                ra[k] = __builtin_bit_cast(uint4, __builtin_nontemporal_load(gcp<u4_t>(ap + oa[k])));
+                rb[k] = __builtin_bit_cast(uint4, __builtin_nontemporal_load(gcp<u4_t>(bp + ob[k])));
+            } else {
+                ra[k] = ld_global16(ap + oa[k]);
+                rb[k] = ld_global16(bp + ob[k]);
+            }
         }
     };
     auto finish = [&](int it, const uint4 (&ra)[4], const uint4 (&rb)[4]) {
@@ -918,15 +923,16 @@ static int warp_blend_impl(const demfi_view* A, const float* fa, const demfi_vie
         const int rows = (var & 2) ? 8 : 4;
         unsigned nblk = 8u * (unsigned)((((W + 63) / 64) * ((H + rows - 1) / rows) + 7) / 8);
         if (wgs >= 8 && (unsigned)(wgs & ~7) < nblk) nblk = (unsigned)(wgs & ~7);
-#define DEMFI_WARP_LAUNCH(TT, R, N)                                                                                   \
-        hipLaunchKernelGGL((warp_blend_fat_kernel<TT, R, N>), dim3(nblk), dim3(R * 64), 0, st, *A, fa, *B, fb, logit, t, *out, sh, H, W, \
+#define DEMFI_WARP_LAUNCH(TT, R, N, NL)                                                                               \
+        hipLaunchKernelGGL((warp_blend_fat_kernel<TT, R, N, NL>), dim3(nblk), dim3(R * 64), 0, st, *A, fa, *B, fb, logit, t, *out, sh, H, W, \
                            occ_out, dbg_maps, wb)
         if (f32) {
-            if (var == 0) DEMFI_WARP_LAUNCH(float, 4, false); else if (var == 1) DEMFI_WARP_LAUNCH(float, 4, true);
-            else if (var == 2) DEMFI_WARP_LAUNCH(float, 8, false); else DEMFI_WARP_LAUNCH(float, 8, true);
+            if ((var & 3) == 0) DEMFI_WARP_LAUNCH(float, 4, false, false); else if ((var & 3) == 1) DEMFI_WARP_LAUNCH(float, 4, true, false);
+            else if ((var & 3) == 2) DEMFI_WARP_LAUNCH(float, 8, false, false); else DEMFI_WARP_LAUNCH(float, 8, true, false);
         } else {
-            if (var == 0) DEMFI_WARP_LAUNCH(half_t, 4, false); else if (var == 1) DEMFI_WARP_LAUNCH(half_t, 4, true);
-            else if (var == 2) DEMFI_WARP_LAUNCH(half_t, 8, false); else DEMFI_WARP_LAUNCH(half_t, 8, true);
+            if (var == 0) DEMFI_WARP_LAUNCH(half_t, 4, false, false); else if (var == 1) DEMFI_WARP_LAUNCH(half_t, 4, true, false);
+            else if (var == 2) DEMFI_WARP_LAUNCH(half_t, 8, false, false); else if (var == 3) DEMFI_WARP_LAUNCH(half_t, 8, true, false);
+            else if (var == 4) DEMFI_WARP_LAUNCH(half_t, 4, false, true); else DEMFI_WARP_LAUNCH(half_t, 4, true, true);      // 4, 5: streaming gathers
         }
 #undef DEMFI_WARP_LAUNCH
     } else {
