@@ -2612,7 +2612,7 @@ static int launch_wstream(const demfi_conv* h, const demfi_conv* dev, hipStream_
 
 
 #ifdef DEMFI_ABLATION
-#include "conv_experiments.inc"        // regw and Z kernels: negative results kept for the next round, not in the product build
+#include "conv_exp_dacc.inc"          // the round-3 double-accumulator experiment (measured negative): ablation builds only
 #endif
 
 // epilogue of the persistent 3x3 kernels: ONE NHWC fp16 destination holding all NCO*32 channels (optional residual)
@@ -2819,27 +2819,16 @@ extern "C" int demfi_conv2d(const demfi_conv* h, const demfi_conv* dev, void* st
 #endif
         if (h->nco == 2) {
 #ifdef DEMFI_ABLATION
-            static const int w8sel = getenv("DEMFI_CONV_W8") ? atoi(getenv("DEMFI_CONV_W8")) : 0;
-            if (w8sel) return launch_w8(h, dev, st);
-            static const int zsel = getenv("DEMFI_CONV_Z") ? atoi(getenv("DEMFI_CONV_Z")) : 0;
-            if (zsel) return launch_z(h, dev, st);
             if (var == 5) return launch_persist<2>(h, dev, st);
-            if (var == 11) return launch_regw<1>(h, dev, st);
-            if (var == 12) return launch_regw<2>(h, dev, st);
-            if (var == 13) return launch_regw<3>(h, dev, st);
-            if (var == 14) return launch_regw<4>(h, dev, st);
-            if (var == 10) return launch_regw(h, dev, st);
-            if (var == 6) return launch_pipe(h, dev, st);
-            // DEMFI_PAIR: 1 skewed pair kernel, 2 unskewed (round-3 experiments), 4 the round-2 product (stores from the MFMA waves)
+            // DEMFI_PAIR: 4 the round-2 product (stores from the MFMA waves), 5 the round-3 double-accumulator experiment
             static const int pair = getenv("DEMFI_PAIR") ? atoi(getenv("DEMFI_PAIR")) : 0;
-            if (pair == 1 || pair == 2) return launch_pair(h, dev, st, pair == 1);
             if (pair == 4) return launch_persist<2>(h, dev, st);
 #endif
 #ifdef DEMFI_TRACE
             if (getenv("DEMFI_PAIR") && atoi(getenv("DEMFI_PAIR")) == 4) return launch_persist<2>(h, dev, st);   // phase trace of the 4-wave kernel
 #endif
 #ifdef DEMFI_ABLATION
-            if (pair == 5) return launch_dacc(h, dev, st);       // round-3 double-accumulator experiment (conv_experiments.inc): measured negative
+            if (pair == 5) return launch_dacc(h, dev, st);       // round-3 double-accumulator experiment (conv_exp_dacc.inc): measured negative
 #endif
             return launch_stg(h, dev, st);
         }

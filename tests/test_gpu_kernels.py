@@ -367,11 +367,12 @@ def test_thin_outputs_with_packed_copy(dsts, pack_ch, H, W, batch):
     x = pl._fat(H, W, 32, batch)
     x.copy_(torch.randn(x.shape, device=DEV))
     rec = pl._fat(H, W, 16, batch)
-    outs, D, c0 = [], [], 0
+    outs, ress, D, c0 = [], [], [], 0
     for n, has_res in dsts:
         o = torch.zeros((batch * n, H, W), dtype=torch.float32, device=DEV)
         r = torch.randn((batch * n, H, W), dtype=torch.float32, device=DEV) if has_res else None
         outs.append(o)
+        ress.append(r)                                   # the descriptor holds a raw pointer: the residual must stay alive
         sb = n * H * W if batch > 1 else 0
         D.append(_Dst(pl.tview(o, 0, sb=sb), range(c0, c0 + n), L.ACT_NONE, res=pl.tview(r, 0, sb=sb) if has_res else None))
         c0 += n
@@ -389,6 +390,7 @@ def test_thin_outputs_with_packed_copy(dsts, pack_ch, H, W, batch):
         n4 = (n + 3) // 4 * 4
         exp[..., chn:chn + n4] = 0.0
         exp[..., chn:chn + n] = o.view(batch, n, H, W).permute(0, 2, 3, 1).half().cpu()    # the pack kernel's conversion of the stored planes
+        assert torch.isfinite(o).all()
     assert torch.equal(rec.cpu(), exp)
 
 

@@ -13,6 +13,6 @@ head -8 $OUT/kernel_stats.csv | cut -c1-160
 rm -rf $OUT/stats
 DEMFI_NTRUNK=1 rocprofv3 --kernel-trace --output-format csv -d $OUT/seq -o s -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --profile-ops $OUT/ops_seq.txt > $OUT/bench_seq.json 2> $OUT/seq.err
 T=$(find $OUT/seq -name "*kernel_trace.csv" | head -1)
-python $GRAFT_REPO_ROOT/tools/trace_by_op.py $T $OUT/ops_seq.txt $OUT/seq_trace_by_op.md 1 2>&1 | tail -3
+python $GRAFT_REPO_ROOT/tools/trace_by_op.py $T $OUT/ops_seq.txt $OUT/seq_trace_by_op.md 1 $OUT/seq_trace_roofline.json 2>&1 | tail -3
 rm -rf $OUT/seq
 head -5 $OUT/seq_trace_by_op.md

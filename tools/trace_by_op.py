@@ -1,7 +1,7 @@
 """Map a rocprofv3 kernel trace of a SEQUENTIAL bench run (DEMFI_NTRUNK=1: the trunk of the next window does not overlap; plan
 order) back to the ops of the launch plan and average the true kernel durations per op.
 
-    python tools/trace_by_op.py <kernel_trace.csv> <ops.txt written by bench.py --profile-ops> [out.md] [passes per window]
+    python tools/trace_by_op.py <kernel_trace.csv> <ops.txt written by bench.py --profile-ops> [out.md] [passes per window] [roofline.json]
 
 The trace holds, per window, the trunk ops followed by `passes` per-t sequences: 1 for the batched plan (every launch
 covers the 7 time instants of the window; the default runner), 7 for one graph per time instant (DEMFI_TB=0 DEMFI_NCTX=1).  Output: per op (plan order) the kernel name, calls and mean / min duration --
@@ -72,6 +72,19 @@ def main():
         kn = kn.split('(anonymous namespace)::')[-1].split('(')[0][:44]
         out.write('| %s | %s | %s | %s | %d | %.1f | %.1f | %.1f |\n' % (o[0], o[1], o[2], kn, len(ds), sum(ds) / len(ds) / 1e3, min(ds) / 1e3,
                                                                   float(o[3]) * 1e3))
+
+
+    # the ten launches of bench.py's roofline object (D1 residual blocks): mean kernel duration in this trace, for roofline.frac_rocprof
+    if len(sys.argv) > 5:
+        import json
+        grp = [oi for oi, o in enumerate(ops) if o[1] == 'conv' and o[2].startswith('Decoder_res.') and acc[oi]]
+        if grp:
+            means = [sum(d for d, _ in acc[oi]) / len(acc[oi]) / 1e6 for oi in grp]
+            json.dump({'avg_launch_ms': round(sum(means) / len(means), 5), 'launches': len(grp), 'samples_per_launch': len(acc[grp[0]]),
+                       'no_residual_ms': round(sum(m for oi, m in zip(grp, means) if ops[oi][2].endswith('.conv1')) / max(1, sum(1 for oi in grp if ops[oi][2].endswith('.conv1'))), 5),
+                       'residual_ms': round(sum(m for oi, m in zip(grp, means) if ops[oi][2].endswith('.conv2')) / max(1, sum(1 for oi in grp if ops[oi][2].endswith('.conv2'))), 5),
+                       'source': 'rocprofv3 --kernel-trace of a sequential bench run (DEMFI_NTRUNK=1), tools/trace_by_op.py; another box than the live HIP-event numbers'},
+                      open(sys.argv[5], 'w'))
 
 
 if __name__ == '__main__':
