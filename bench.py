@@ -177,10 +177,12 @@ def load_rocprof_frac():
 def load_pmc_traffic():
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary (profiles/r02_pmc_traffic.json,
     written by tools/pmc_traffic.py on the GPU box: separate --pmc passes, 2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction)."""
-    path = os.path.join(ROOT, 'profiles', 'r03_pmc_traffic.json')
-    if not os.path.exists(path):
-        path = os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')
-    if not os.path.exists(path):
+    path = None
+    for r in ('r04', 'r03', 'r02'):
+        path = os.path.join(ROOT, 'profiles', r + '_pmc_traffic.json')
+        if os.path.exists(path):
+            break
+    if not path or not os.path.exists(path):
         return None
     with open(path) as f:
         return json.load(f)

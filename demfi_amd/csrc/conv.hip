@@ -1124,6 +1124,17 @@ __global__ __launch_bounds__(SG_NT, 1) void conv3x3_c64_stg_kernel(const demfi_c
             // acknowledgements of stores issued late in the phase
             if (have_prev) { stage_read(buf ^ 1); stage_store(pb, py, px); }
             if (t + t_step < t_end) issue_tile(t + t_step, buf ^ 1);
+#ifdef DEMFI_ABLATION
+            // experiment (DEMFI_KNOB bit 6; round 4): what would STREAMING the 72 KiB of weights per tile through the helpers cost (the
+            // design VERDICT r3 item 1 proposes to free LDS for a third tile buffer)?  The helpers re-issue the LDS-DMA of the resident
+            // weights every tile: the same bytes land on top of themselves, results stay correct, and the helper path carries the 72
+            // extra DMA instructions + 72 KiB of L2 -> LDS traffic per tile that a weight ring would add.  profiles/r04_notes.md section 6.
+            if (DEMFI_KNOB_BIT(64)) {
+                for (int i = dw; i < NTAPS * NKS * NCO; i += SG_NH)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + i * 64 + lane),
+                                                     (__attribute__((address_space(3))) void*)(wlds + i * 1024), 16, 0, 0);
+            }
+#endif
             TRACE_STAMP(wave, trk, 2);
             tile_coords(t, pb, py, px);
             have_prev = true;

@@ -1,7 +1,7 @@
 """GPU-box helper: rocprofv3 PMC passes (separate runs, --kernel-trace only) of the probes of the two roofline kernels and
-a JSON summary for bench.py (profiles/r03_pmc_traffic.json).
+a JSON summary for bench.py (profiles/<round>_pmc_traffic.json).
 
-    python tools/pmc_traffic.py <outdir>
+    python tools/pmc_traffic.py <outdir> [round tag, default r04]
 
 HBM bytes per launch = 2 x FETCH_SIZE x 1024 (gfx950: FETCH_SIZE counts 64 B per 128-B request, MI355X_MICROARCH.md "HBM")
 + WRITE_SIZE x 1024, per dispatch of the kernel.  The dominant conv is probed with and without the residual input (the D1
@@ -17,6 +17,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PASSES = {'fetch': 'FETCH_SIZE GRBM_GUI_ACTIVE', 'write': 'WRITE_SIZE TCC_HIT TCC_MISS',
           'mfma': 'SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA',
+          'ta': 'TA_TA_BUSY GRBM_GUI_ACTIVE SQ_WAVES',
           'lds': 'SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VMEM'}
 
 
@@ -56,7 +57,7 @@ def run_bench_pmc(outdir):
     """The same two passes over the BENCH itself (sequential: one per-t context, one trunk context): per-kernel HBM bytes with
     the network's own flows / activations and the cache state of the real launch sequence."""
     res = collections.defaultdict(dict)
-    for tag in ('fetch', 'write'):
+    for tag in ('fetch', 'write', 'ta'):
         d = os.path.join(outdir, 'bench', tag)
         os.makedirs(d, exist_ok=True)
         cmd = ['rocprofv3', '--pmc'] + PASSES[tag].split() + ['--kernel-trace', '--output-format', 'csv', '-d', d, '-o', 'r', '--',
@@ -79,12 +80,14 @@ def run_bench_pmc(outdir):
         if 'FETCH_SIZE' in v and 'WRITE_SIZE' in v:
             out[k] = {'hbm_bytes_per_launch': 2 * v['FETCH_SIZE'] * 1024 + v['WRITE_SIZE'] * 1024, 'fetch_KiB': v['FETCH_SIZE'],
                       'write_KiB': v['WRITE_SIZE'], 'dispatches': v['dispatches'],
-                      'l2_hit': v.get('TCC_HIT', 0) / max(1.0, v.get('TCC_HIT', 0) + v.get('TCC_MISS', 0))}
+                      'l2_hit': v.get('TCC_HIT', 0) / max(1.0, v.get('TCC_HIT', 0) + v.get('TCC_MISS', 0)),
+                      # texture-addresser busy fraction: TA_TA_BUSY summed over the 256 TAs / (GRBM_GUI_ACTIVE summed over 8 XCDs x 32 CUs)
+                      'ta_busy_frac': v.get('TA_TA_BUSY', 0) / max(1.0, v.get('GRBM_GUI_ACTIVE', 0) * 32)}
     return out
 
 
 def main():
-    outdir = sys.argv[1]
+    outdir = os.path.abspath(sys.argv[1])                       # rocprofv3 runs with cwd /tmp
     os.makedirs(outdir, exist_ok=True)
     summary = {}
     for case, env in (('c3x3', {'PROBE_DATA': 'relu'}), ('c3x3res', {'PROBE_DATA': 'relu'}), ('warp', {}), ('cfr', {})):
@@ -125,7 +128,7 @@ def main():
     if wk:
         out['warp_traffic_bytes_probe_white_noise'] = out.get('warp_traffic_bytes')
         out['warp_traffic_bytes'] = wk[0]['hbm_bytes_per_launch']             # the network's own flows, in sequence
-    json.dump(out, open(os.path.join(outdir, 'r03_pmc_traffic.json'), 'w'), indent=1)
+    json.dump(out, open(os.path.join(outdir, (sys.argv[2] if len(sys.argv) > 2 else 'r04') + '_pmc_traffic.json'), 'w'), indent=1)
     print(json.dumps({k: v for k, v in out.items() if k not in ('raw', 'in_network')}, indent=1))
     for k, v in sorted(innet.items(), key=lambda kv: -kv[1]['hbm_bytes_per_launch'])[:14]:
         print('%-52s %8.1f MB/launch  L2 hit %.2f  (%d launches)' % (k[:52], v['hbm_bytes_per_launch'] / 1e6, v['l2_hit'], v['dispatches']))
