@@ -1387,10 +1387,30 @@ struct NarrowFrag { uint4 a[2], b0, b1; };
 // period of Dec_last2 there.
 // PACK (THIN only): the layer also writes the packed fp16 copy of its planes (demfi_conv.pack) -- its own instantiation: the extra
 // pointers cost the plain thin layers 5-9 % when they were a run-time option (Dec_last2_2 0.485 -> 0.52 ms per 7 t, same box)
+// REGW (THIN, 3x3): the layer's weight fragments (9 taps x NKS k-steps, one 32-cout subtile: 18 / 36 x 4 registers) live in the MFMA
+// waves' REGISTERS for the whole launch instead of being re-read from LDS by every wave for every tile.  The thin layers' MFMA phase is
+// LDS-read bound (336 KiB of fragment reads per 8 x 32 tile of Dec_last2 for 36 MFMAs per wave: profiles/r03_notes.md section 4); the A
+// fragments are 43 % of those reads.  Round 4.
+#ifndef DEMFI_THIN_REGW
+#define DEMFI_THIN_REGW 1
+#endif
+#ifndef DEMFI_THIN_REGW_G128
+#define DEMFI_THIN_REGW_G128 6
+#endif
 template <int NCO, int REC, int EPI, int KS = 3, int NDMA = NarrowCfg<REC, KS>::NDMA, int NOCT = 4, bool PACK = false>
 __global__ __launch_bounds__(NT + 64 * NDMA, 1) void conv3x3_narrow_persist_kernel(const demfi_conv* __restrict__ d)
 {
     constexpr bool RES = EPI == 1, THIN = EPI == 2;
+    constexpr bool REGW = THIN && KS == 3 && NCO == 1 && DEMFI_THIN_REGW != 0;
+    // (kx, k-step) groups whose three ky fragments are register resident: all 6 of a 64-byte-record layer (18 fragments, 72 registers),
+    // 6 of the 12 of a 128-byte-record layer (all 36 = 144 registers spill in the 256-register budget of this 8-wave workgroup); the
+    // other groups keep reading the LDS copy
+    // Measured (profiles/r04_notes.md section 8, same box, alternating libraries): Dec_last2 (128-byte records, one live octet, 6 of 12 groups
+    // resident) 0.943 -> 0.901 ms; Dec_last2_2 (three octets, 4 groups) 0.471 -> 0.495 and flow_occ.conv2 (64-byte records, all 6 groups)
+    // 0.233 -> 0.250: SLOWER -- the thin layers are not bound by the A-fragment LDS reads, and the extra registers cost more than
+    // the reads save.  Enabled only where it paid.
+    constexpr int RG = (REGW && REC == 128 && NOCT == 1 && !PACK) ? DEMFI_THIN_REGW_G128 : 0;
+    constexpr bool WLDS = RG < (REC / 32) * 3 || !REGW;          // the LDS copy of the weights is (still) needed
     static_assert(!PACK || THIN, "packed copy: thin epilogue only");
     static_assert(!THIN || NCO == 1, "thin epilogue: one 32-cout subtile");
     using Cfg = NarrowCfg<REC, KS>;
@@ -1504,9 +1524,11 @@ __global__ __launch_bounds__(NT + 64 * NDMA, 1) void conv3x3_narrow_persist_kern
             }
         };
         const uint4* wsrc = (const uint4*)d->wpack;
-        for (int i = dw; i < NSTEP * NCO; i += NDMA)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + i * 64 + lane),
-                                             (__attribute__((address_space(3))) void*)(wlds + i * 1024), 16, 0, 0);
+        if constexpr (WLDS) {
+            for (int i = dw; i < NSTEP * NCO; i += NDMA)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + i * 64 + lane),
+                                                 (__attribute__((address_space(3))) void*)(wlds + i * 1024), 16, 0, 0);
+        }
         for (int k = 0; k < NBUF - 1 && k < n_tiles; ++k) issue_tile(k);
         for (int k = 0; k < n_tiles; ++k) {
             // tiles k+1 .. k+NBUF-2 (those that exist) may stay in flight; loads retire in order
@@ -1544,6 +1566,14 @@ __global__ __launch_bounds__(NT + 64 * NDMA, 1) void conv3x3_narrow_persist_kern
         boff[g] = col * REC + ((((g % NKS) * 2 + hi) ^ Cfg::swz(col)) << 4);
     }
     const char* const wl = wlds + lane * 16;
+    uint4 areg[RG > 0 ? RG * 3 : 1];                              // REGW: fragment (ky, group g < RG) = areg[g * 3 + ky], indexed by constants only
+    if constexpr (REGW) {
+        const char* wg = (const char*)d->wpack + lane * 16;
+        static_for<0, RG * 3>([&](auto I_) {
+            constexpr int i = decltype(I_)::value, g = i / 3, ky = i % 3, kx = g / NKS, ks = g % NKS;
+            areg[i] = ld_global16(wg + ((ky * 3 + kx) * NKS + ks) * 1024);
+        });
+    }
     // ---- THIN: per octet g (= accumulator quad g) the planar destination / residual of this lane's 4 channels -------
     // packed cout of accumulator element (g, j) of this lane: 8g + 4hi + j; valid when 4hi + j < oct_n[g]
     float* t_dst[4];
@@ -1648,48 +1678,54 @@ __global__ __launch_bounds__(NT + 64 * NDMA, 1) void conv3x3_narrow_persist_kern
             // (tap, k-step) at a time = 2 + NCO reads per 2*NCO MFMAs with a scheduling fence per step; the phase trace shows 3 400
             // cycles for the 36 MFMAs of the 64 -> 3 layers).  The next group's reads are interleaved 1:1 with this group's MFMAs.
             constexpr int NG = 3 * NKS;                         // groups: g = kx*NKS + ks
-            struct RowFragN { uint4 a[3][NCO]; uint4 b[4]; };
-            auto load_g = [&](RowFragN& f, int g) {
-                const int kx = g / NKS, ks = g % NKS;
+            struct RowFragN { uint4 a[3][NCO]; uint4 b[4]; };                   // groups g < RG: the A fragments are read straight from areg (a unused)
+            auto load_g = [&](RowFragN& f, auto G_) {
+                constexpr int g = decltype(G_)::value;
+                constexpr int kx = g / NKS, ks = g % NKS;
+                if constexpr (g >= RG) {
 #pragma unroll
-                for (int ky = 0; ky < 3; ++ky) {
+                    for (int ky = 0; ky < 3; ++ky) {
 #pragma unroll
-                    for (int s = 0; s < NCO; ++s) f.a[ky][s] = *(const uint4*)(wl + ((((ky * 3 + kx) * NKS + ks) * NCO) + s) * 1024);
+                        for (int s = 0; s < NCO; ++s) f.a[ky][s] = *(const uint4*)(wl + ((((ky * 3 + kx) * NKS + ks) * NCO) + s) * 1024);
+                    }
                 }
                 const char* p0 = tb + boff[kx * NKS + ks];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) f.b[r] = *(const uint4*)(p0 + r * (P_LW * REC));
             };
-            auto mma_g = [&](const RowFragN& f) {
-#pragma unroll
-                for (int ky = 0; ky < 3; ++ky) {
+            auto mma_g = [&](const RowFragN& f, auto G_) {
+                constexpr int g = decltype(G_)::value;
+                constexpr int kx = g / NKS, ks = g % NKS;
+                static_for<0, 3>([&](auto KY_) {
+                    constexpr int ky = decltype(KY_)::value;
 #pragma unroll
                     for (int s = 0; s < NCO; ++s) {
-                        Mma<half_t>::run(acc[s][0], f.a[ky][s], f.b[ky]);
-                        Mma<half_t>::run(acc[s][1], f.a[ky][s], f.b[ky + 1]);
+                        uint4 a;
+                        if constexpr (g < RG) a = areg[g * 3 + ky]; else a = f.a[ky][s];
+                        Mma<half_t>::run(acc[s][0], a, f.b[ky]);
+                        Mma<half_t>::run(acc[s][1], a, f.b[ky + 1]);
                     }
-                }
+                });
             };
-            auto groups = [&](bool loads) {
+            auto groups = [&](auto NR_) {                       // NR_: ds_reads of the group being prefetched to interleave with this group's MFMAs (0: none)
+                constexpr int nr = decltype(NR_)::value;
 #pragma unroll
                 for (int q = 0; q < 6 * NCO; ++q) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    if (loads) {
-                        if (NCO == 1 && q == 0) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);    // 7 reads between 6 MFMAs
-                        else if (q < 3 * NCO + 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                    }
+                    if constexpr (nr > 6 * NCO) { if (q == 0) __builtin_amdgcn_sched_group_barrier(0x100, nr - 6 * NCO + 1, 0); else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+                    else if (q < nr) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             };
             // fragments TWO groups ahead: a group is only 6*NCO MFMAs (192 cycles for NCO = 1), less than an LDS round trip under load
             RowFragN f[3];
-            load_g(f[0], 0);
-            if constexpr (NG > 1) load_g(f[1], 1);
+            load_g(f[0], std::integral_constant<int, 0>{});
+            if constexpr (NG > 1) load_g(f[1], std::integral_constant<int, 1>{});
             static_for<0, NG>([&](auto G_) {
                 constexpr int g = decltype(G_)::value;
-                if constexpr (g + 2 < NG) load_g(f[(g + 2) % 3], g + 2);
-                mma_g(f[g % 3]);
-                groups(g + 2 < NG);
+                if constexpr (g + 2 < NG) load_g(f[(g + 2) % 3], std::integral_constant<int, g + 2>{});
+                mma_g(f[g % 3], G_);
+                groups(std::integral_constant<int, (g + 2 < NG) ? (g + 2 < RG ? 4 : 3 * NCO + 4) : 0>{});
             });
         } else {
             auto load_step = [&](NarrowFrag& f, int g) {        // g = tap*NKS + ks
