@@ -156,7 +156,7 @@ __device__ __forceinline__ void apply_act_n(float (&v)[N], int act)
 // ---- epilogue shared by the general and the persistent kernel -------------------------------------------
 // acc[s][p][r]: pixel (oy0 + 2*wave + p, ox0 + lx), packed cout (cblk*NCO+s)*32 + 8*(r>>2) + 4*hi + (r&3).
 // 'smem' must be free for reuse (the caller has synchronised the workgroup after the last tile read).
-template <typename T, int NCO, bool BLOCK_SYNC>
+template <typename T, int NCO, bool BLOCK_SYNC, bool DIRECT = true>
 __device__ __forceinline__ void conv_epilogue(const demfi_conv* __restrict__ d, f16x_t (&acc)[NCO][2], char* smem,
                                               int wave, int lane, int cblk, int bimg, int oy0, int ox0, int H, int W)
 {
@@ -237,6 +237,9 @@ __device__ __forceinline__ void conv_epilogue(const demfi_conv* __restrict__ d, 
     });
 
     // ---- direct path (thin / planar / ragged destinations): straight from the accumulator layout ----------
+    // (DIRECT = false: every subtile of the layer takes the staged path -- the launch checks it -- and this generic per-octet code, two
+    //  thirds of the kernel's 77-188 KB of instructions, is not instantiated: round 4, instruction-cache footprint)
+    if constexpr (DIRECT)
     static_for<0, NCO * 4>([&](auto SG) {
         {
             constexpr int s = decltype(SG)::value >> 2;
@@ -318,7 +321,7 @@ __device__ __forceinline__ void conv_epilogue(const demfi_conv* __restrict__ d, 
 
 // second launch_bounds argument = minimum waves per SIMD: 2-3 resident workgroups per CU let one workgroup's
 // tile staging overlap another's MFMA phase.
-template <typename T, int NCO>
+template <typename T, int NCO, bool DIRECT = true>
 __global__ __launch_bounds__(NT, (NCO <= 1 ? 4 : (NCO == 2 ? 3 : 2))) void conv_kernel(const demfi_conv* __restrict__ d)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -499,7 +502,7 @@ __global__ __launch_bounds__(NT, (NCO <= 1 ? 4 : (NCO == 2 ? 3 : 2))) void conv_
     }
 
     // ---------------- epilogue --------------------------------------------------------------------------
-    conv_epilogue<T, NCO, true>(d, acc, smem, wave, lane, cblk, bimg, oy0, ox0, H, W);
+    conv_epilogue<T, NCO, true, DIRECT>(d, acc, smem, wave, lane, cblk, bimg, oy0, ox0, H, W);
 }
 
 
@@ -2729,10 +2732,18 @@ static bool persist_out_eligible(const demfi_conv* h, bool allow_tanh)
 template <typename T, int NCO>
 int launch(const demfi_conv* h, const demfi_conv* dev, hipStream_t st, size_t lds)
 {
-    DEMFI_LDS_ATTR((conv_kernel<T, NCO>));
     const int tiles = ((h->W + TW - 1) / TW) * ((h->H + TH - 1) / TH);
     dim3 grid(tiles, h->cout_pad / (32 * h->nco), h->batch);
-    hipLaunchKernelGGL((conv_kernel<T, NCO>), grid, dim3(NT), lds, st, dev);
+    bool all_staged = true;                                      // no subtile needs the direct (thin / planar / ragged) epilogue
+    for (int sb = 0; sb < h->cout_pad / 32; ++sb) all_staged = all_staged && h->sub_seg[sb] >= 0;
+    static const int nodirect = getenv("DEMFI_CONV_NODIRECT") ? atoi(getenv("DEMFI_CONV_NODIRECT")) : 1;      // A/B switch
+    if (all_staged && nodirect) {
+        DEMFI_LDS_ATTR((conv_kernel<T, NCO, false>));
+        hipLaunchKernelGGL((conv_kernel<T, NCO, false>), grid, dim3(NT), lds, st, dev);
+    } else {
+        DEMFI_LDS_ATTR((conv_kernel<T, NCO, true>));
+        hipLaunchKernelGGL((conv_kernel<T, NCO, true>), grid, dim3(NT), lds, st, dev);
+    }
     DEMFI_HIP_CHECK(hipGetLastError());
     return DEMFI_OK;
 }
