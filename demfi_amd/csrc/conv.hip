@@ -1394,6 +1394,26 @@ struct NarrowFrag { uint4 a[2], b0, b1; };
 // waves' REGISTERS for the whole launch instead of being re-read from LDS by every wave for every tile.  The thin layers' MFMA phase is
 // LDS-read bound (336 KiB of fragment reads per 8 x 32 tile of Dec_last2 for 36 MFMAs per wave: profiles/r03_notes.md section 4); the A
 // fragments are 43 % of those reads.  Round 4.
+// 4 x 4 transpose inside a quad of lanes (two rounds of DPP exchanges): in: a[j] = element j of this lane's row; out: a[k] = element
+// (this lane's index in its quad) of the row of quad lane k.  The thin epilogue uses it to turn "4 channels of one pixel" (the MFMA
+// accumulator layout) into "4 consecutive pixels of one channel" = one 16-byte access to a planar fp32 tensor.
+__device__ __forceinline__ void quad_transpose4(float (&a)[4], int lane)
+{
+    auto dpp = [](float v, auto CTRL) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), decltype(CTRL)::value, 0xF, 0xF, false));
+    };
+    const bool b0 = lane & 1, b1 = lane & 2;
+    float p[4], y[4], q[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) p[j] = dpp(a[j], std::integral_constant<int, 0xB1>{});       // quad_perm [1,0,3,2]: lane ^ 1
+    y[0] = b0 ? p[1] : a[0]; y[1] = b0 ? a[1] : p[0]; y[2] = b0 ? p[3] : a[2]; y[3] = b0 ? a[3] : p[2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) q[j] = dpp(y[j], std::integral_constant<int, 0x4E>{});       // quad_perm [2,3,0,1]: lane ^ 2
+    a[0] = b1 ? q[2] : y[0]; a[1] = b1 ? q[3] : y[1]; a[2] = b1 ? y[2] : q[0]; a[3] = b1 ? y[3] : q[1];
+}
+#ifndef DEMFI_THIN_VEC
+#define DEMFI_THIN_VEC 1                                         // 0: A/B builds without the quad-transposed 16-byte epilogue accesses
+#endif
 #ifndef DEMFI_THIN_REGW
 #define DEMFI_THIN_REGW 1
 #endif
@@ -1606,6 +1626,28 @@ __global__ __launch_bounds__(NT + 64 * NDMA, 1) void conv3x3_narrow_persist_kern
             t_rsb[g] = sg.res.sb;
         }
     }
+    // ---- THIN, vector accesses (round 4): after a 4 x 4 transpose inside each lane quad, lane (quad lane q4) holds channel 4 hi + q4 of
+    // its octet for the quad's 4 consecutive pixels: ONE 16-byte residual load and ONE 16-byte store per (octet, row) and lane instead
+    // of four 4-byte ones -- the thin epilogue is bound by the NUMBER of VMEM instructions its waves issue (phase trace: 4 300 cycles
+    // for the 36 accesses per tile and wave of Dec_last2_2).  Needs unit-stride, 16-byte aligned planes and a tile inside the image;
+    // tiles / layers that do not qualify (ragged edges, the parity views of dec3, an active uint8 sink) take the scalar accesses.
+    const int q4 = lx & 3;
+    float* t_dstq[4];
+    const float* t_resq[4];
+    bool tv_ok = THIN && DEMFI_THIN_VEC != 0;
+    if constexpr (THIN) {
+        auto al16 = [](const void* pp, int64_t a, int64_t b, int64_t c) { return (((uintptr_t)pp) & 15) == 0 && ((a | b | c) & 3) == 0; };
+#pragma unroll
+        for (int g = 0; g < NOCT; ++g) {
+            const demfi_seg& sg = d->segs[d->oct_seg[g]];
+            const int qq = min(q4, max(t_nq[g] - 1, 0));         // lanes past the last valid channel shadow it (loaded, never stored)
+            t_dstq[g] = t_dst[g] + qq * t_dsc[g];
+            t_resq[g] = t_res[g] + qq * t_rsc[g] * t_rmul[g];
+            if (t_on[g] > 0)
+                tv_ok = tv_ok && t_dsx[g] == 1 && al16(sg.dst.ptr, t_dsc[g], t_dsy[g], t_dsb[g]) &&
+                        (t_rmul[g] == 0 || (t_rsx[g] == 1 && al16(sg.res.ptr, t_rsc[g], t_rsy[g], t_rsb[g])));
+        }
+    }
     // optional uint8 sink (demfi_u8_sink, read at run time so that one captured graph serves every destination): octet g
     // = one 3-channel frame segment whose channels all sit in the hi == 0 lane's quad
     // Batch image b uses the record DEMFI_U8_SINK_STRIDE * b bytes behind it (the batched per-t plan: one record per context);
@@ -1639,7 +1681,26 @@ __global__ __launch_bounds__(NT + 64 * NDMA, 1) void conv3x3_narrow_persist_kern
         }
         u4_t rreg[NCO][2][2];
         float tr[4][2][4];                                      // THIN: residual [octet][row][j], prefetched like rreg
+        // vector accesses for this tile?  (wave-uniform; an active sink keeps the per-pixel layout for its byte stores)
+        bool tvec = tv_ok && ox0 + TW <= W;
         if constexpr (THIN) {
+#pragma unroll
+            for (int g = 0; g < NOCT; ++g) tvec = tvec && s_dst[g] == nullptr;
+        }
+        if constexpr (THIN) {
+            if (tvec) {
+#pragma unroll
+                for (int g = 0; g < NOCT; ++g) {
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) {                // [octet][row][pixel of the quad]: channel 4 hi + q4, 16 bytes
+                        const int oy = min(oy0 + wave * 2 + p, H - 1);
+                        const float* rp = t_resq[g] + (bimg * t_rsb[g] + (int64_t)oy * t_rsy[g] + ox0 + (lx & ~3)) * t_rmul[g];
+                        const f4_t rv = *gcp<f4_t>(rp);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) tr[g][p][j] = rv[j];
+                    }
+                }
+            } else {
 #pragma unroll
             for (int g = 0; g < NOCT; ++g) {
 #pragma unroll
@@ -1650,6 +1711,7 @@ __global__ __launch_bounds__(NT + 64 * NDMA, 1) void conv3x3_narrow_persist_kern
                     for (int j = 0; j < 4; ++j)                 // invalid j of this lane: re-read its first channel (value unused)
                         tr[g][p][j] = *gcp<float>(rp + (j < t_nq[g] ? j : 0) * t_rsc[g] * t_rmul[g]);
                 }
+            }
             }
         }
         if constexpr (RES) {
@@ -1765,6 +1827,69 @@ __global__ __launch_bounds__(NT + 64 * NDMA, 1) void conv3x3_narrow_persist_kern
             for (int g = 0; g < NOCT; ++g) {                    // retire the prefetch here (see the 64-channel kernel)
 #pragma unroll
                 for (int q = 0; q < 8; ++q) asm volatile("" : "+v"(tr[g][q >> 2][q & 3]));
+            }
+            TRACE_STAMP(wave, k, 4);                            // residual prefetch retired (vmcnt wait over)
+            if (tvec) {                                         // wave-uniform
+                // Vector accesses, all (octet, row) units as ONE straight-line block (independent chains: the lone MFMA wave of a SIMD has
+                // nothing else to hide VALU / DPP latency with): (acc + bias) of this lane's 4 channels -> quad transpose -> 4 pixels of
+                // channel 4 hi + q4, + the residual of those 4 pixels (same two roundings per value as the scalar order), activation, ONE
+                // 16-byte store.  The packed copy wants the per-pixel layout back: a second transpose.
+                float vv[NOCT][2][4];
+#pragma unroll
+                for (int g = 0; g < NOCT; ++g) {
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) vv[g][p][j] = acc[0][p][g * 4 + j] + t_bias[g][j];
+                    }
+                }
+#pragma unroll
+                for (int g = 0; g < NOCT; ++g) {
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) quad_transpose4(vv[g][p], lane);
+                }
+#pragma unroll
+                for (int g = 0; g < NOCT; ++g) {
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) vv[g][p][j] = vv[g][p][j] + tr[g][p][j];
+                    }
+                    apply_act_n<4>(vv[g][0], t_act[g]);
+                    apply_act_n<4>(vv[g][1], t_act[g]);
+                }
+#pragma unroll
+                for (int g = 0; g < NOCT; ++g) {
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) {
+                        const int oyv = oy0 + wave * 2 + p;
+                        if (oyv < H && q4 < t_nq[g]) {
+                            f4_t o;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) o[j] = vv[g][p][j];
+                            *gp<f4_t>(t_dstq[g] + bimg * t_dsb[g] + (int64_t)oyv * t_dsy[g] + ox0 + (lx & ~3)) = o;
+                        }
+                    }
+                }
+                if constexpr (PACK) {
+#pragma unroll
+                    for (int g = 0; g < NOCT; ++g) {
+                        if (pk_dst[g] == nullptr) continue;     // depends on hi only: uniform inside a lane quad (the DPP exchange stays inside quads)
+#pragma unroll
+                        for (int p = 0; p < 2; ++p) {
+                            quad_transpose4(vv[g][p], lane);    // lanes without a valid channel carry don't-care values: only j < t_nq is used
+                            const int oyv = oy0 + wave * 2 + p;
+                            if (oyv < H) {
+                                h4_t o;
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) o[j] = j < t_nq[g] ? (half_t)vv[g][p][j] : (half_t)0.0f;
+                                *gp<h4_t>(pk_dst[g] + bimg * pk_sb + (int64_t)oyv * pk_sy + (int64_t)(ox0 + lx) * pk_sx) = o;
+                            }
+                        }
+                    }
+                }
+                TRACE_STAMP(wave, k, 3);
+                continue;
             }
 #pragma unroll
             for (int g = 0; g < NOCT; ++g) {

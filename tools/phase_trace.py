@@ -60,8 +60,9 @@ def trace_plan_op(name, lib):
         if not t[..., 1].any():
             continue
         if w < 4:
-            print('  MFMA wave %d   wait at barrier %6.0f | MFMA phase %6.0f | epilogue %6.0f | to next barrier arrival %6.0f' %
-                  (w, (t[..., 1] - t[..., 0]).mean(), (t[..., 2] - t[..., 1]).mean(), (t[..., 3] - t[..., 2]).mean(), (nxt[..., 0] - t[..., 3]).mean()))
+            print('  MFMA wave %d   wait at barrier %6.0f | MFMA phase %6.0f | epilogue %6.0f (of which waiting for the prefetched residuals / earlier stores %6.0f) | to next barrier arrival %6.0f' %
+                  (w, (t[..., 1] - t[..., 0]).mean(), (t[..., 2] - t[..., 1]).mean(), (t[..., 3] - t[..., 2]).mean(),
+                   (t[..., 4] - t[..., 2]).mean() if t[..., 4].any() else float('nan'), (nxt[..., 0] - t[..., 3]).mean()))
         else:
             print('  DMA wave %d    landed -> released %6.0f | issue of the next tile(s) %6.0f | issued -> landed %6.0f' %
                   (w - 4, (t[..., 1] - t[..., 0]).mean(), (t[..., 2] - t[..., 1]).mean(), (nxt[..., 0] - t[..., 2]).mean()))
