@@ -983,6 +983,14 @@ __device__ __forceinline__ float sub_mix_hi(float c, unsigned a)
 #endif
     return d;
 }
+// Streaming (nt) hints of the staged-store kernel.  Bit 1 (default): the helper waves' output stores -- whole 128-byte lines of tensors
+// of hundreds of MB that the next launch re-reads from HBM anyway; without the hint the written lines compete with the input tiles for
+// the L2s and the Infinity Cache: residual launches -1.5..-2 %, the window -0.6 ms (profiles/r04_notes.md section 11).  Experiment
+// bits, both measured negative there: 2 = nt residual loads (+15 % on the residual launches), 4 = nt tile DMA.  The same hint on the
+// 16-byte-per-lane stores of the MFMA waves of the GRU / narrow / streamed-weight kernels is 1.8x / 1.1x / 1.02x SLOWER (partial lines).
+#ifndef DEMFI_STG_NT
+#define DEMFI_STG_NT 1
+#endif
 #ifndef DEMFI_STG_RES_AT
 #define DEMFI_STG_RES_AT 2                                       // k-loop third after which the residual loads are issued (-1: before barrier A)
 #endif
@@ -1065,7 +1073,7 @@ __global__ __launch_bounds__(SG_NT, 1) void conv3x3_c64_stg_kernel(const demfi_c
                     if (i >= P_NI) continue;                     // wave-uniform
                     const char* g = base + off[k];
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                                     (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+                                                     (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, (DEMFI_STG_NT & 4) ? 2 : 0);
                 }
             } else {
 #pragma unroll
@@ -1075,7 +1083,7 @@ __global__ __launch_bounds__(SG_NT, 1) void conv3x3_c64_stg_kernel(const demfi_c
                     const int iy = oy0 - 1 + (lyx[k] & 255), ix = ox0 - 1 + (lyx[k] >> 8);
                     const char* g = (lyx[k] != 0xffff && iy >= 0 && iy < H && ix >= 0 && ix < W) ? base + off[k] : zeros;
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                                     (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+                                                     (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, (DEMFI_STG_NT & 4) ? 2 : 0);
                 }
             }
         };
@@ -1101,7 +1109,10 @@ __global__ __launch_bounds__(SG_NT, 1) void conv3x3_c64_stg_kernel(const demfi_c
             char* const obase = (char*)(dstp + bimg * d_sb + oy0 * d_sy + ox0 * d_sx);      // wave-uniform
             if (oy0 + TH <= H && ox0 + TW <= W) {
 #pragma unroll
-                for (int k = 0; k < NCH; ++k) *gp<u4_t>(obase + doff[k]) = stage[k];
+                for (int k = 0; k < NCH; ++k) {
+                    if constexpr ((DEMFI_STG_NT & 1) != 0) __builtin_nontemporal_store(stage[k], gp<u4_t>(obase + doff[k]));
+                    else *gp<u4_t>(obase + doff[k]) = stage[k];
+                }
             } else {
 #pragma unroll
                 for (int k = 0; k < NCH; ++k) {
@@ -1206,7 +1217,10 @@ __global__ __launch_bounds__(SG_NT, 1) void conv3x3_c64_stg_kernel(const demfi_c
 #pragma unroll
                     for (int s = 0; s < NCO; ++s) {
 #pragma unroll
-                        for (int m2 = 0; m2 < 2; ++m2) rreg[s][p][m2] = *gcp<u4_t>(rp + s * 32 + m2 * 16);
+                        for (int m2 = 0; m2 < 2; ++m2) {
+                            if constexpr ((DEMFI_STG_NT & 2) != 0) rreg[s][p][m2] = __builtin_nontemporal_load(gcp<u4_t>(rp + s * 32 + m2 * 16));
+                            else rreg[s][p][m2] = *gcp<u4_t>(rp + s * 32 + m2 * 16);
+                        }
                     }
                 }
             }
