@@ -2563,7 +2563,12 @@ static int launch_sep(const demfi_conv* h, const demfi_conv* dev, hipStream_t st
 //   => per step: 8 MFMAs, 1-2 ds_read_b128, 1 global_load_dwordx4.
 // ======================================================================================================
 constexpr int WS_TH = 16;
-template <int KS> struct WsCfg {
+#ifndef DEMFI_WS_NW
+#define DEMFI_WS_NW 4                                            // waves of the streamed-weight kernel's workgroup: 4 (one per SIMD) or 8
+#endif
+template <int KS, int NW> struct WsCfg {
+    static constexpr int RPW = WS_TH / (NW / 2);                 // output rows (32x32 accumulators) per wave
+    static constexpr int BL = KS + RPW - 1;                      // input lines of a wave's rolling B window
     static constexpr int LH = WS_TH + KS - 1;                    // input lines of a tile
     static constexpr int LL = (TW + KS - 1 + 7) & ~7;            // records per line (TW + KS - 1 used)
     static constexpr int NI = LH * LL / 16;                      // DMA instructions per unit (16 records x 64 B each)
@@ -2571,24 +2576,25 @@ template <int KS> struct WsCfg {
     static constexpr int LDS_BYTES = 2 * UNIT_BYTES;
     static constexpr int NG = 2 * KS;                            // (kx, k-step) groups per unit
     static constexpr int NSTEP = NG * KS;
-    static constexpr int DEPTH = 2 * KS;                         // A prefetch distance in steps
-    static constexpr int NIW = (NI + 3) / 4;                     // DMA instructions per wave (the last one may not exist)
+    static constexpr int DEPTH = NW == 8 ? KS : 2 * KS;          // A prefetch distance in steps (8 waves: 256 registers per wave)
+    static constexpr int NIW = (NI + NW - 1) / NW;               // DMA instructions per wave (the last one may not exist)
     static constexpr int DMA_EVERY = 6;                          // one DMA instruction every so many steps
     static_assert(LH * LL % 16 == 0, "unit buffer must be a whole number of DMA instructions");
     static_assert(NIW * DMA_EVERY + DEPTH <= NSTEP, "the unit's DMA must be older than the last A fragment consumed in the unit");
     static_assert(NSTEP % DEPTH == 0, "static ring indices");
 };
 
-template <int KS>
-__global__ __launch_bounds__(NT, 1) void conv_wstream_c64_kernel(const demfi_conv* __restrict__ d)
+template <int KS, int NW>
+__global__ __launch_bounds__(64 * NW, 1) void conv_wstream_c64_kernel(const demfi_conv* __restrict__ d)
 {
-    using C = WsCfg<KS>;
+    using C = WsCfg<KS, NW>;
+    constexpr int RPW = C::RPW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hi = lane >> 5, lx = lane & 31;
-    const int cs = wave & 1, rh = wave >> 1;                    // cout half, row half
+    const int cs = wave & 1, rh = wave >> 1;                    // cout half, row group (RPW rows each)
     const int H = d->H, W = d->W;
     const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + WS_TH - 1) / WS_TH, tiles_img = tiles_x * tiles_y;
     const int total = tiles_img * d->batch;
@@ -2621,7 +2627,7 @@ __global__ __launch_bounds__(NT, 1) void conv_wstream_c64_kernel(const demfi_con
     int doff[C::NIW], dlc[C::NIW];
 #pragma unroll
     for (int j = 0; j < C::NIW; ++j) {
-        const int rec = (wave + 4 * j) * 16 + (lane >> 2);
+        const int rec = (wave + NW * j) * 16 + (lane >> 2);
         const int l = rec / C::LL, c = rec - l * C::LL;
         doff[j] = (int)(l * syb + c * sxb) + (((lane & 3) ^ ((c >> 2) & 3)) << 4);
         dlc[j] = l | (c << 8);
@@ -2631,7 +2637,7 @@ __global__ __launch_bounds__(NT, 1) void conv_wstream_c64_kernel(const demfi_con
 #pragma unroll
     for (int g = 0; g < C::NG; ++g) {
         const int col = lx + (g >> 1);
-        boff[g] = (rh * 8 * C::LL + col) * 64 + ((((g & 1) * 2 + hi) ^ ((col >> 2) & 3)) << 4);
+        boff[g] = (rh * RPW * C::LL + col) * 64 + ((((g & 1) * 2 + hi) ^ ((col >> 2) & 3)) << 4);
     }
 
     struct Unit { const char* src; const char* w; int iy0, ix0; bool interior; };
@@ -2652,7 +2658,7 @@ __global__ __launch_bounds__(NT, 1) void conv_wstream_c64_kernel(const demfi_con
     };
     auto dma_one = [&](auto J, const Unit& un, char* buf) {
         constexpr int j = decltype(J)::value;
-        const int i = wave + 4 * j;
+        const int i = wave + NW * j;
         if (i >= C::NI) return;                                  // wave-uniform
         const char* g = un.src + doff[j];
         if (!un.interior) {
@@ -2685,9 +2691,9 @@ __global__ __launch_bounds__(NT, 1) void conv_wstream_c64_kernel(const demfi_con
 #pragma unroll
     for (int qd = 0; qd < 4; ++qd) bq[qd] = *gcp<f4_t>(d->bias + cs * 32 + qd * 8 + hi * 4);
 
-    f16x_t acc[8];
+    f16x_t acc[RPW];
 #pragma unroll
-    for (int p = 0; p < 8; ++p) {
+    for (int p = 0; p < RPW; ++p) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[p][i] = 0.0f;
     }
@@ -2701,25 +2707,26 @@ __global__ __launch_bounds__(NT, 1) void conv_wstream_c64_kernel(const demfi_con
 
     for (int u = 0; u < n_units; ++u) {
         const bool has_next = u + 1 < n_units;
+        TRACE_STAMP(wave, u / upt, u % upt);                    // trace build: start of every unit (6 units per Ch_Reducer tile = the 6 stamp slots)
         const Unit nxt = unit_info(has_next ? u + 1 : 0);
         const char* const tb = smem + (u & 1) * C::UNIT_BYTES;
         char* const nb = smem + ((u + 1) & 1) * C::UNIT_BYTES;
-        uint4 B[2][KS + 7];
-        // the first group's 8 lines (the later groups' are read during the group before)
+        uint4 B[2][C::BL];
+        // the first group's RPW lines (the later groups' are read during the group before)
 #pragma unroll
-        for (int r = 0; r < 8; ++r) B[0][r] = *(const uint4*)(tb + boff[0] + r * (C::LL * 64));
+        for (int r = 0; r < RPW; ++r) B[0][r] = *(const uint4*)(tb + boff[0] + r * (C::LL * 64));
         __builtin_amdgcn_sched_barrier(0);
         static_for<0, C::NSTEP>([&](auto T_) {
             constexpr int t = decltype(T_)::value;
             constexpr int g = t / KS, ky = t % KS, gb = g & 1;
             const uint4 a = A[t % C::DEPTH];
-            // B: this group's next line, and the first 8 lines of the next group (one per step, two in the last)
-            if constexpr (ky + 8 < KS + 7) B[gb][ky + 8] = *(const uint4*)(tb + boff[g] + (ky + 8) * (C::LL * 64));
+            // B: this group's next line, and the first RPW lines of the next group (one per step; the rest in the last step)
+            if constexpr (ky + RPW < C::BL) B[gb][ky + RPW] = *(const uint4*)(tb + boff[g] + (ky + RPW) * (C::LL * 64));
             if constexpr (g + 1 < C::NG) {
-                B[gb ^ 1][ky] = *(const uint4*)(tb + boff[g + 1] + ky * (C::LL * 64));
+                if constexpr (ky < RPW) B[gb ^ 1][ky] = *(const uint4*)(tb + boff[g + 1] + ky * (C::LL * 64));
                 if constexpr (ky == KS - 1) {
 #pragma unroll
-                    for (int r = KS; r < 8; ++r) B[gb ^ 1][r] = *(const uint4*)(tb + boff[g + 1] + r * (C::LL * 64));
+                    for (int r = KS; r < RPW; ++r) B[gb ^ 1][r] = *(const uint4*)(tb + boff[g + 1] + r * (C::LL * 64));
                 }
             }
             // A: the fragment of step t + DEPTH (of the next unit at the end of this one)
@@ -2730,7 +2737,7 @@ __global__ __launch_bounds__(NT, 1) void conv_wstream_c64_kernel(const demfi_con
                 if (has_next) dma_one(std::integral_constant<int, t / C::DMA_EVERY>{}, nxt, nb);
             }
 #pragma unroll
-            for (int p = 0; p < 8; ++p) Mma<half_t>::run(acc[p], a, B[gb][ky + p]);
+            for (int p = 0; p < RPW; ++p) Mma<half_t>::run(acc[p], a, B[gb][ky + p]);
             __builtin_amdgcn_sched_barrier(0);
         });
         // every DMA instruction of the next unit is older than the DEPTH A loads still in flight
@@ -2743,8 +2750,8 @@ __global__ __launch_bounds__(NT, 1) void conv_wstream_c64_kernel(const demfi_con
             const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
             const int ox = tx * TW + lx;
 #pragma unroll
-            for (int p = 0; p < 8; ++p) {
-                const int oy = ty * WS_TH + rh * 8 + p;
+            for (int p = 0; p < RPW; ++p) {
+                const int oy = ty * WS_TH + rh * RPW + p;
 #pragma unroll
                 for (int m2 = 0; m2 < 2; ++m2) {
                     float v[8];
@@ -2791,10 +2798,11 @@ static bool wstream_eligible(const demfi_conv* h)
 
 static int launch_wstream(const demfi_conv* h, const demfi_conv* dev, hipStream_t st)
 {
-    DEMFI_LDS_ATTR((conv_wstream_c64_kernel<7>));
+    DEMFI_LDS_ATTR((conv_wstream_c64_kernel<7, DEMFI_WS_NW>));
     const int total = ((h->W + TW - 1) / TW) * ((h->H + WS_TH - 1) / WS_TH) * h->batch;
     const int grid = total >= 256 ? 256 : total;
-    hipLaunchKernelGGL(conv_wstream_c64_kernel<7>, dim3(grid), dim3(NT), (size_t)WsCfg<7>::LDS_BYTES, st, dev);
+    constexpr size_t lds = WsCfg<7, DEMFI_WS_NW>::LDS_BYTES;
+    hipLaunchKernelGGL((conv_wstream_c64_kernel<7, DEMFI_WS_NW>), dim3(grid), dim3(64 * DEMFI_WS_NW), lds, st, dev);
     DEMFI_HIP_CHECK(hipGetLastError());
     return DEMFI_OK;
 }

@@ -33,12 +33,20 @@ def main():
                         a = per[int(r['Dispatch_Id'])]
                         a[r['Counter_Name']] = a.get(r['Counter_Name'], 0.0) + float(r['Counter_Value'])
             ids = sorted(per)[-6:]
+            for f in glob.glob(d + '/**/*kernel_trace.csv', recursive=True):
+                dur = [(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) * 1e-3 for r in csv.DictReader(open(f)) if kname in r['Kernel_Name']]
+                if dur:
+                    acc['us'] = sum(dur[-6:]) / len(dur[-6:])
             for k in {c for i_ in ids for c in per[i_]}:
                 acc[k] = sum(per[i_].get(k, 0.0) for i_ in ids) / max(1, len(ids))
         w = max(1.0, acc['SQ_WAVES'])
         print('%s  (%s, %d waves per launch)' % (op, kname, w))
         print('   instructions per wave: VALU %.0f  SALU %.0f  VMEM %.0f  LDS %.0f  SMEM %.0f  MFMA %.0f' %
               tuple(acc[k] / w for k in ('SQ_INSTS_VALU', 'SQ_INSTS_SALU', 'SQ_INSTS_VMEM', 'SQ_INSTS_LDS', 'SQ_INSTS_SMEM', 'SQ_INSTS_MFMA')))
+        if acc['us']:
+            # SQ_WAVE_CYCLES counts in units of 4 cycles; every wave of these persistent kernels lives for the whole launch
+            print('   launch %.1f us under the counters; wave-cycles per wave x 4 / launch time = %.2f GHz shader clock; SQ busy cycles / time = %.2f GHz' %
+                  (acc['us'], 4 * acc['SQ_WAVE_CYCLES'] / w / acc['us'] * 1e-3, acc['SQ_BUSY_CYCLES'] / acc['us'] * 1e-3))
         wc = max(1.0, acc['SQ_WAVE_CYCLES'])
         print('   of the wave-cycles: waiting (any) %.2f, waiting for an instruction to issue %.2f, an instruction active %.2f '
               '(VALU %.2f VMEM %.2f LDS %.2f scalar %.2f)' % tuple(acc[k] / wc for k in ('SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY', 'SQ_ACTIVE_INST_ANY', 'SQ_ACTIVE_INST_VALU',

@@ -53,6 +53,15 @@ def trace_plan_op(name, lib):
     tr = buf.reshape(WGS, WAVES, TILES, STAMPS).astype(np.int64)
     lo, hi = 4, 20
     print('op %s : launch %.4f ms' % (name, e0.elapsed_time(e1)))
+    if name == 'Ch_Reducer':
+        # streamed-weight kernel: stamp i of tile k = start of its unit i (32 input channels: 98 steps x 8 MFMAs per wave of the 4-wave kernel)
+        per_tile = (tr[:, 0, hi, 0] - tr[:, 0, lo, 0]) / float(hi - lo)
+        units = np.diff(tr[:, :4, lo:hi, :], axis=-1)
+        tiles_per_wg = (7 * (736 // 16) * (1280 // 32)) / 256.0
+        print('  cycles per tile %.0f (min %.0f max %.0f over workgroups); per unit %.0f; implied shader clock %.2f GHz (tiles per workgroup %.1f)' %
+              (per_tile.mean(), per_tile.min(), per_tile.max(), units.mean(), per_tile.mean() * tiles_per_wg / (e0.elapsed_time(e1) * 1e6), tiles_per_wg))
+        print('  matrix-pipe floor of a unit: 784 MFMAs x 32 cycles = 25 088 cycles per wave -> pipe busy %.2f' % (25088.0 / units.mean()))
+        return
     period = (tr[:, 0, hi, 1] - tr[:, 0, lo, 1]) / float(hi - lo)
     print('  period (release to release, wave 0): mean %.0f cycles  (min %.0f max %.0f)' % (period.mean(), period.min(), period.max()))
     for w in range(WAVES):
