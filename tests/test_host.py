@@ -284,3 +284,56 @@ def test_rank_affinity_slices_a_numa_node_between_its_ranks():
     assert set(got[5][0]) <= set(node_cpus[1])
     even = [ra.affinity(r, 4, [None] * 4, {}, list(range(10))) for r in range(4)]
     assert [c for c, _ in even] == [[0, 1], [2, 3], [4, 5], [6, 7]] and all(n == -1 for _, n in even)
+
+
+def test_single_call_operators_take_the_reference_modules_keys(synthetic_sd):
+    """demfi_amd/ops.py: SepConvGRU / FGAC take the state_dict keys of the reference modules (DeMFInet.py:830-836, 369-380) and name the
+    missing ones; no kernel is launched here."""
+    from demfi_amd.ops import FGAC, SepConvGRU
+    g = SepConvGRU(64, 64, device='cpu').load_state_dict(synthetic_sd, prefix='Booster_Module.GB.')
+    assert sorted(g.sd) == sorted('conv%s%d.%s' % (a, i, p) for a in 'zrq' for i in (1, 2) for p in ('weight', 'bias'))
+    assert tuple(g.sd['convz1.weight'].shape) == (64, 128, 1, 5) and tuple(g.sd['convq2.weight'].shape) == (64, 128, 5, 1)
+    f = FGAC(device='cpu').load_state_dict(synthetic_sd, prefix='FAC_FB_Module.shared_FGAC.')
+    assert 'conv_source_k.weight' in f.sd and tuple(f.sd['w_gen.weight'].shape) == (64, 128, 3, 3)
+    with pytest.raises(KeyError, match='convr2.bias'):
+        SepConvGRU(device='cpu').load_state_dict({k: v for k, v in synthetic_sd.items() if not k.endswith('convr2.bias')}, prefix='Booster_Module.GB.')
+    with pytest.raises(RuntimeError):
+        FGAC(device='cpu')(torch.zeros(1, 64, 8, 8), torch.zeros(1, 64, 8, 8), torch.zeros(1, 2, 8, 8))
+    with pytest.raises(ValueError):
+        SepConvGRU(dtype=torch.bfloat16)
+
+
+def test_single_call_operator_plans_interpreted_on_the_cpu(synthetic_sd):
+    """The launch plans demfi_amd/ops.py builds (fused z|r weights, GRU epilogue wiring, FGAC's conv chain) interpreted by the CPU plan
+    interpreter agree with the oracle's sep_conv_gru / fgac: the host logic of the operators is right before a GPU sees it."""
+    from demfi_amd.ops import FGAC, SepConvGRU
+    torch.manual_seed(2)
+    B, H, W = 2, 12, 20
+    h, x = torch.tanh(torch.randn(B, 64, H, W)), torch.randn(B, 64, H, W)
+    g = SepConvGRU(64, 64, dtype=torch.float32, device='cpu').load_state_dict(synthetic_sd, prefix='Booster_Module.GB.')
+    pl, bufs, n = g._plan(B, H, W)
+    bufs['h0'].copy_(h.permute(0, 2, 3, 1))
+    bufs['x'].copy_(x.permute(0, 2, 3, 1))
+    sim = PlanSim(pl)
+    for i in range(n):
+        sim.conv(pl._descs[i])
+    assert (bufs['h2'].permute(0, 3, 1, 2) - O.sep_conv_gru(synthetic_sd, h, x)).abs().max() < 1e-5
+
+    name = 'FAC_FB_Module.shared_FGAC'
+    ref, src = torch.randn(B, 64, H, W), torch.randn(B, 64, H, W)
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing='ij')
+    flow = torch.stack([xs, ys])[None].repeat(B, 1, 1, 1) + torch.randn(B, 2, H, W) * 2.0
+    f = FGAC(dtype=torch.float32, device='cpu').load_state_dict(synthetic_sd, prefix=name + '.')
+    pl, bufs = f._plan(B, H, W)
+    bufs['ref'].copy_(ref.permute(0, 2, 3, 1))
+    bufs['source'].copy_(src.permute(0, 2, 3, 1))
+    sim = PlanSim(pl)
+    sim.conv(pl._descs[0])
+    bufs['sampled'].copy_(O.fgac_sample(bufs['ref_k'].permute(0, 3, 1, 2), flow).permute(0, 2, 3, 1))     # the gather kernel's role
+    for i in (1, 2, 3):
+        sim.conv(pl._descs[i])
+    want, w_want = O.fgac(synthetic_sd, name, ref, src, flow)
+    w = bufs['w'].view(B, 1, H, W)
+    assert (w - w_want).abs().max() < 1e-5
+    out = w * src + (1 - w) * bufs['e_s'].permute(0, 3, 1, 2)                                             # the gate kernel's role
+    assert (out - want).abs().max() < 1e-5
