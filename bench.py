@@ -338,8 +338,11 @@ def main():
                            'frac_rocprof': None, 'rocprof': None,
                            'timing': 'IN SEQUENCE: mean over 5 passes of the whole launch plan, HIP events on the launch stream between consecutive '
                                      'launches (includes the 5-8 us launch gap; reproduces the rocprofv3 in-sequence kernel durations of profiles/ within ~1 %)',
-                           'sustained_clock_note': 'in-kernel s_memtime trace (profiles/r03_notes.md): 1.7 GHz under this kernel, i.e. the dense-fp16 ceiling '
-                                                   'at the sustained clock is 2500 x 1.7 / 2.4 = 1771 TFLOP/s; frac is quoted against the 2.4 GHz peak',
+                           'sustained_clock_note': 'in-kernel s_memtime traces in the network (profiles/r04_notes.md sections 11-12): the clock falls as the matrix pipe fills -- 1.87 GHz at 0.47 busy '
+                                                   '(this kernel with residual), 1.65 GHz at 0.68 busy (without), 1.57 GHz at 0.83 busy (Ch_Reducer); '
+                                                   'back-to-back MFMAs from registers sustain 1460 TFLOP/s on random fp16 operands (tools/microbench/mfma_peak.hip, 2190 on zeros); '
+                                                   'frac is quoted against the 2.4 GHz datasheet peak as required',
+                           'frac_of_sustained_random_operand_peak': round(ach / 1460.0, 4) if a.dtype == 'fp16' else None,
                            'all_convs_TFLOPs': round(tot_conv_fl / (tot_conv_ms * 1e-3) / 1e12, 2),
                            'slowest_conv': '%s %.3f ms' % (dom[2], dom[3])}
         rp = load_rocprof_frac() if a.dtype == 'fp16' and (eng.H, eng.W) == (736, 1280) and nb == 7 else None
