@@ -1,0 +1,87 @@
+"""Seeded shape fuzz of the persistent convolution kernels on a real MI355X: the fixed cases of tests/test_gpu_kernels.py re-run at
+pseudo-random frame sizes (ragged tile edges in both directions, widths that are / are not multiples of 4 -- the 16-byte vector
+paths of the thin epilogue and their scalar fallbacks --, single-tile frames, more tiles than workgroups) and batch counts.  The
+checks are the ones of test_gpu_kernels.py (each kernel against a torch fp64 / fp32 convolution of the same operands); the seed is
+fixed, so a failure names a reproducible (case, H, W, batch)."""
+import random
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from demfi_amd import _lib as L                     # noqa: E402
+from tests import test_gpu_kernels as K             # noqa: E402
+
+_rng = random.Random(20260929)
+
+
+def _shapes(n, hmin, hmax, wmin, wmax):
+    out = []
+    for i in range(n):
+        H, W = _rng.randint(hmin, hmax), _rng.randint(wmin, wmax)
+        if i % 3 == 0:
+            W = (W + 3) & ~3                          # a third of the widths qualify for the 16-byte paths
+        out.append((H, W))
+    return out
+
+
+C64 = [(H, W, _rng.choice([L.ACT_RELU, L.ACT_NONE]), _rng.random() < 0.6) for H, W in _shapes(10, 8, 90, 8, 200)] + [(150, 470, L.ACT_RELU, True)]
+
+
+@pytest.mark.parametrize('H,W,act,res', C64)
+def test_fuzz_conv3x3_64_to_64(H, W, act, res):
+    """staged-store kernel (helper waves, nt output stores), with and without residual; the last case walks 304 tiles on 256 workgroups"""
+    K.test_conv_vs_torch((64, 64, 3, 3, 1, H, W, act, res), torch.float16)
+
+
+THIN = [(K.THIN_CASES[i % len(K.THIN_CASES)], H, W) for i, (H, W) in enumerate(_shapes(15, 8, 70, 8, 150))]
+
+
+@pytest.mark.parametrize('case,H,W', THIN)
+def test_fuzz_thin_outputs(case, H, W):
+    K.test_narrow_persistent_conv_thin_outputs(case, H, W)
+
+
+PACK = [(d, p, H, W, _rng.randint(1, 3)) for (d, p), (H, W) in
+        zip([([(5, True)], [0]), ([(4, True), (1, True)], [0, 4]), ([(3, False), (5, True)], [-1, 8])] * 2, _shapes(6, 8, 60, 8, 120))]
+
+
+@pytest.mark.parametrize('dsts,pack_ch,H,W,batch', PACK)
+def test_fuzz_thin_outputs_with_packed_copy(dsts, pack_ch, H, W, batch):
+    K.test_thin_outputs_with_packed_copy(dsts, pack_ch, H, W, batch)
+
+
+NARROW = [(K.NARROW_CASES[i % len(K.NARROW_CASES)], H, W, _rng.randint(1, 2)) for i, (H, W) in enumerate(_shapes(10, 8, 70, 8, 150))]
+
+
+@pytest.mark.parametrize('case,H,W,batch', NARROW)
+def test_fuzz_narrow_persistent_conv(case, H, W, batch):
+    K.test_narrow_persistent_conv(case, H, W, batch)
+
+
+GRU = [((1, 5) if i & 1 else (5, 1), H, W, _rng.randint(1, 3)) for i, (H, W) in enumerate(_shapes(8, 8, 80, 8, 120))]
+
+
+@pytest.mark.parametrize('k,H,W,batch', GRU)
+def test_fuzz_sep_gru(k, H, W, batch):
+    K.test_sep_gru_persistent_kernel(k[0], k[1], H, W, batch)
+
+
+WS = [(H, W, _rng.randint(1, 2), _rng.choice([L.ACT_TANH, L.ACT_NONE, L.ACT_RELU])) for H, W in _shapes(5, 16, 70, 32, 140)]
+
+
+@pytest.mark.parametrize('H,W,batch,act', WS)
+def test_fuzz_streamed_weight_conv(H, W, batch, act):
+    K.test_streamed_weight_conv_7x7_192_to_64(H, W, batch, act)
+
+
+GEN = [(_rng.choice([(96, 32, 3, 3), (224, 96, 1, 1), (128, 64, 4, 4), (64, 133, 3, 3), (48, 96, 5, 5), (32, 5, 3, 3)]), H, W) for H, W in _shapes(10, 1, 40, 1, 70)]
+
+
+@pytest.mark.parametrize('shape,H,W', GEN)
+def test_fuzz_general_kernel_small_frames(shape, H, W):
+    """the general kernel at the sizes the UNet's coarse levels see (down to 1 x 1 outputs)"""
+    cin, cout, kh, kw = shape
+    stride = 2 if kh == 4 else 1
+    K.test_conv_vs_torch((cin, cout, kh, kw, stride, H, W, L.ACT_RELU, kh == 1), torch.float16)
