@@ -85,3 +85,37 @@ def test_fuzz_general_kernel_small_frames(shape, H, W):
     cin, cout, kh, kw = shape
     stride = 2 if kh == 4 else 1
     K.test_conv_vs_torch((cin, cout, kh, kw, stride, H, W, L.ACT_RELU, kh == 1), torch.float16)
+
+
+# ------------------------------------------------------------------------------------------------------
+# whole network, fp32, against the oracle at pseudo-random frame sizes (multiples of 8: what the model itself needs), t and N
+# ------------------------------------------------------------------------------------------------------
+E2E = [(8 * _rng.randint(3, 14), 8 * _rng.randint(3, 22), _rng.randint(1, 3), _rng.choice([0.125, 0.3, 0.5, 0.625, 0.875]), 100 + i) for i in range(5)]
+
+
+@pytest.mark.parametrize('H,W,N,tv,seed', E2E)
+def test_fuzz_forward_fp32_vs_oracle(H, W, N, tv, seed):
+    """DeMFInet.forward on the HIP path vs oracle.forward (= DeMFInet.py:46-179 restated) at a size none of the fixtures has: every
+    Sharps_final frame within the north star's |dPSNR| <= 1e-3 dB against a common pseudo ground truth, flows / occlusion close."""
+    import numpy as np
+    from demfi_amd import DeMFInet, HyperParams, synthetic_state_dict, synthetic_window
+    from oracle import demfi_oracle as O
+    sd = synthetic_state_dict(0)
+    m = DeMFInet(HyperParams(), dtype=torch.float32)
+    m.load_state_dict(sd)
+    m = m.to(K.DEV).eval()
+    x = synthetic_window(H, W, seed)
+    t = torch.tensor([[tv]])
+    got = m(x.to(K.DEV), t.to(K.DEV), N)
+    with torch.no_grad():
+        ref = O.forward(sd, x, t, N)
+    gt = x[0, :, 1].numpy()
+    for it in range(N):
+        for i in range(3):
+            g, r = got[1][it][i][0].cpu().numpy(), ref[1][it][i][0].numpy()
+            assert np.isfinite(g).all()
+            assert abs(O.psnr(g, gt) - O.psnr(r, gt)) <= 1e-3, (H, W, N, tv, it, i)
+    for i in range(3):
+        assert abs(O.psnr(got[0][i][0].cpu().numpy(), gt) - O.psnr(ref[0][i][0].numpy(), gt)) <= 1e-3
+    assert np.median(np.abs(got[2][N][0].cpu().numpy() - ref[2][N][0].numpy())) < 2e-4
+    assert np.median(np.abs(got[3][N][0].cpu().numpy() - ref[3][N][0].numpy())) < 2e-5
