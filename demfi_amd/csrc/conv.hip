@@ -991,8 +991,11 @@ __device__ __forceinline__ float sub_mix_hi(float c, unsigned a)
 #ifndef DEMFI_STG_NT
 #define DEMFI_STG_NT 1
 #endif
+#ifndef DEMFI_STG_RES_AHEAD
+#define DEMFI_STG_RES_AHEAD 0                                    // 1: the residual of tile k+1 is fetched during tile k (two register sets: measured no better than 0 with an early issue point)
+#endif
 #ifndef DEMFI_STG_RES_AT
-#define DEMFI_STG_RES_AT 2                                       // k-loop third after which the residual loads are issued (-1: before barrier A)
+#define DEMFI_STG_RES_AT -1                                      // k-loop third after which the residual loads are issued (-1: before barrier A, at the head of the tile)
 #endif
 constexpr int SG_NH = 4;                                         // helper waves
 constexpr int SG_NT = NT + 64 * SG_NH;
@@ -1200,30 +1203,39 @@ __global__ __launch_bounds__(SG_NT, 1) void conv3x3_c64_stg_kernel(const demfi_c
 #pragma unroll
         for (int m2 = 0; m2 < 2; ++m2) soff[s][m2] = lx * 128 + (((s * 4 + m2 * 2 + hi) ^ ((lx >> 1) & 7)) << 4);
     }
-    int buf = 0;
-    for (int t = t_first; t < t_end; t += t_step, buf ^= 1) {
+    // Residual: issued in the MIDDLE of an MFMA phase (after a third of the k-loop).  At the head of the period the CU's memory pipe
+    // belongs to the helper waves' stores of the previous tile and to the DMA of the next one.  Round 4: the loads issued during tile k
+    // are those of tile k+1 (two register sets, the tile loop unrolled by two so that both are statically named): on the memory wall
+    // the residual variant sits on (4.85 TB/s) loads issued 4 000 cycles before their use were 1 100-2 300 cycles late; a whole period
+    // of lead takes that wait out of the epilogue (DEMFI_STG_RES_AHEAD 0: the tile's own residual, the round-3 schedule).
+    using ResRegs = u4_t[NCO][2][2];
+    constexpr bool AHEAD = RES && DEMFI_STG_RES_AHEAD != 0;
+    auto tile_body = [&](const int t, const int buf, ResRegs& rreg, ResRegs& rnext) {
         int bimg, oy0, ox0;
         tile_coords(t, bimg, oy0, ox0);
-        // Residual of this tile: issued in the MIDDLE of the MFMA phase (after a third of the k-loop).  At the head of the period the
-        // CU's memory pipe belongs to the helper waves' stores of the previous tile and to the DMA of the next one; loads issued
-        // here still have ~3 000 cycles to land before the epilogue, and do not queue in front of those.
-        u4_t rreg[NCO][2][2];
-        auto load_res = [&]() {
+        auto load_res_of = [&](ResRegs& rr, int tt) {
             if constexpr (RES) {
+                int rb, ry0, rx0;
+                tile_coords(tt, rb, ry0, rx0);
 #pragma unroll
                 for (int p = 0; p < 2; ++p) {
-                    const int oy = min(oy0 + wave * 2 + p, H - 1), oxx = min(ox0 + lx, W - 1);
-                    const half_t* rp = resp + bimg * r_sb + oy * r_sy + oxx * r_sx + ch0 + hi * 8;
+                    const int oy = min(ry0 + wave * 2 + p, H - 1), oxx = min(rx0 + lx, W - 1);
+                    const half_t* rp = resp + rb * r_sb + oy * r_sy + oxx * r_sx + ch0 + hi * 8;
 #pragma unroll
                     for (int s = 0; s < NCO; ++s) {
 #pragma unroll
                         for (int m2 = 0; m2 < 2; ++m2) {
-                            if constexpr ((DEMFI_STG_NT & 2) != 0) rreg[s][p][m2] = __builtin_nontemporal_load(gcp<u4_t>(rp + s * 32 + m2 * 16));
-                            else rreg[s][p][m2] = *gcp<u4_t>(rp + s * 32 + m2 * 16);
+                            if constexpr ((DEMFI_STG_NT & 2) != 0) rr[s][p][m2] = __builtin_nontemporal_load(gcp<u4_t>(rp + s * 32 + m2 * 16));
+                            else rr[s][p][m2] = *gcp<u4_t>(rp + s * 32 + m2 * 16);
                         }
                     }
                 }
             }
+        };
+        auto load_res = [&]() {
+            // no branch inside the MFMA phase: the last tile of the walk re-reads its own residual into the idle set
+            if constexpr (AHEAD) load_res_of(rnext, t + t_step < t_end ? t + t_step : t);
+            else load_res_of(rreg, t);
         };
         if constexpr (DEMFI_STG_RES_AT < 0) load_res();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the staged outputs of the previous tile are in LDS
@@ -1332,6 +1344,28 @@ __global__ __launch_bounds__(SG_NT, 1) void conv3x3_c64_stg_kernel(const demfi_c
         }
         TRACE_STAMP(wave, trk, 3);
         ++trk;
+    };
+    ResRegs r_even, r_odd;
+    if constexpr (AHEAD) {                                      // the first tile's residual (tile_body only fetches ahead)
+        int rb, ry0, rx0;
+        tile_coords(t_first, rb, ry0, rx0);
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int oy = min(ry0 + wave * 2 + p, H - 1), oxx = min(rx0 + lx, W - 1);
+            const half_t* rp = resp + rb * r_sb + oy * r_sy + oxx * r_sx + ch0 + hi * 8;
+#pragma unroll
+            for (int s = 0; s < NCO; ++s) {
+#pragma unroll
+                for (int m2 = 0; m2 < 2; ++m2) r_even[s][p][m2] = *gcp<u4_t>(rp + s * 32 + m2 * 16);
+            }
+        }
+    }
+    for (int t = t_first; t < t_end;) {
+        tile_body(t, 0, r_even, r_odd);
+        t += t_step;
+        if (t >= t_end) break;
+        tile_body(t, 1, r_odd, r_even);
+        t += t_step;
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the last tile is staged
     asm volatile("s_barrier" ::: "memory");                     // F
