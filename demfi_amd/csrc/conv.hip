@@ -1586,9 +1586,16 @@ __global__ __launch_bounds__(NT + 64 * NDMA, 1) void conv3x3_narrow_persist_kern
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
                 if (NDMA > 1 && (i % NDMA) != dw) continue;      // wave-uniform
-                const int sel = meta[i] >> 16;
-                const int iy = oy0 - PAD + (meta[i] & 255), ix = ox0 - PAD + ((meta[i] >> 8) & 255);
-                const bool ok = sel != 2 && (meta[i] & 0xffff) != 0xffff && (interior || (iy >= 0 && iy < H && ix >= 0 && ix < W));
+                // the lane's (line, column, piece) word is made opaque per tile: otherwise the compiler hoists the lane MASKS of the
+                // comparisons below out of the tile loop -- ~15 SGPR pairs per DMA instruction, 170-370 of them spilled to VGPR lanes and
+                // read back with v_readlane + wait states on every tile (round 4: .sgpr_spill_count of the thin instantiations)
+                int mt = meta[i];
+#if defined(__HIP_DEVICE_COMPILE__)
+                asm volatile("" : "+v"(mt));
+#endif
+                const int sel = mt >> 16;
+                const int iy = oy0 - PAD + (mt & 255), ix = ox0 - PAD + ((mt >> 8) & 255);
+                const bool ok = sel != 2 && (mt & 0xffff) != 0xffff && (interior || (iy >= 0 && iy < H && ix >= 0 && ix < W));
                 const char* g = ok ? (sel == 1 ? base1 : base0) + off[i] : zeros;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                                  (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
