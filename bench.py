@@ -188,11 +188,36 @@ def load_pmc_traffic():
         return json.load(f)
 
 
+def self_launch_argv(n, argv=None, port=None):
+    """The command a bare ``python bench.py --gpus N`` (N > 1, no WORLD_SIZE in the environment) re-executes itself as: one rank per
+    GPU under torch.distributed.run on 127.0.0.1 with a free port, the caller's own flags passed through unchanged."""
+    import socket
+    if port is None:
+        with socket.socket() as s:
+            s.bind(('127.0.0.1', 0))
+            port = s.getsockname()[1]
+    argv = list(sys.argv[1:] if argv is None else argv)
+    return [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+            '--master-port', str(port), os.path.abspath(__file__)] + argv
+
+
+def self_launch(n):
+    """Runs the N-rank job as a child process; rank 0's JSON line goes to this process's stdout, the return code is non-zero when
+    any rank failed (torch.distributed.run's own exit status)."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')        # dmabuf IPC: RCCL between processes needs it on this driver
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // n)))
+    return subprocess.call(self_launch_argv(n), env=env)
+
+
 def main():
     a = parse()
     rank = int(os.environ.get('RANK', 0))
     local = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
+    if 'WORLD_SIZE' not in os.environ and a.gpus > 1:
+        raise SystemExit(self_launch(a.gpus))                 # bare `python bench.py --gpus N`: one rank per GPU under torch.distributed.run
     if world != a.gpus:
         raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)' % (a.gpus, world))
     from demfi_amd import DeMFInet, HyperParams, synthetic_state_dict

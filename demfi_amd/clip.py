@@ -162,11 +162,11 @@ class _StreamedFrames:
 class ClipRunner:
     """x M interpolation of whole clips on this rank's GPU: frames in (host uint8 BGR), frames out (sink or files)."""
 
-    def __init__(self, model, height, width, n_tst=3, mfi=8, batch=4, world=1, rank=0, final_only=True, n_ctx=None, n_trunk=None):
+    def __init__(self, model, height, width, n_tst=3, mfi=8, batch=4, world=1, rank=0, final_only=True, n_ctx=None, n_trunk=None, auto=False):
         from .runner import WindowRunner
         # the clip pipeline delivers the LAST recursion's frames only (like test_custom, utils.py:1430-1434), so the decoder
         # passes that only produce the earlier recursions' frames need not run: same delivered bytes (WindowRunner.final_only)
-        self.runner = WindowRunner(model, height, width, n_tst, mfi, final_only=final_only, n_ctx=n_ctx, n_trunk=n_trunk)
+        self.runner = WindowRunner(model, height, width, n_tst, mfi, final_only=final_only, n_ctx=n_ctx, n_trunk=n_trunk, auto=auto)
         self.h, self.w, self.mfi, self.batch = height, width, mfi, batch
         self.world, self.rank = world, rank
         self.ts = t_schedule(mfi)
@@ -307,6 +307,9 @@ def main(argv=None):
     ap.add_argument('--batch', type=int, default=4)
     ap.add_argument('--ext', default='.png')
     ap.add_argument('--all-recursions', action='store_true', help='compute every Sharps_final entry (default: the last one only, which is all that is written)')
+    ap.add_argument('--n-ctx', type=int, default=None, help='per-t contexts per launch sequence (default: fixed rule, 7 at x8); must divide M-1')
+    ap.add_argument('--n-trunk', type=int, default=None, help='trunk buffer sets = windows in flight (default: 3 if they fit half of the GPU memory, else 2)')
+    ap.add_argument('--auto', action='store_true', help='size n_ctx / n_trunk from the FREE memory of the GPU (shared or smaller GPUs)')
     a = ap.parse_args(argv)
     from . import DeMFInet, HyperParams, synthetic_state_dict
     from .weights import load_checkpoint
@@ -342,7 +345,7 @@ def main(argv=None):
         cr = runners.get((h, w))
         if cr is None:
             cr = runners[(h, w)] = ClipRunner(model, h, w, a.n_tst, a.mfi, batch=a.batch, world=world, rank=rank,
-                                              final_only=not a.all_recursions)
+                                              final_only=not a.all_recursions, n_ctx=a.n_ctx, n_trunk=a.n_trunk, auto=a.auto)
         nw, nf = cr.run_folder(path, os.path.join(out_root, scene + '_sharply_interpolated_x' + str(a.mfi)), pool=pool, ext=a.ext)
         tot_w += nw
         tot_f += nf

@@ -2849,10 +2849,6 @@ static int launch_wstream(const demfi_conv* h, const demfi_conv* dev, hipStream_
 }
 
 
-#ifdef DEMFI_ABLATION
-#include "conv_exp_dacc.inc"          // the round-3 double-accumulator experiment (measured negative): ablation builds only
-#endif
-
 // epilogue of the persistent 3x3 kernels: ONE NHWC fp16 destination holding all NCO*32 channels (optional residual)
 static bool persist_out_eligible(const demfi_conv* h, bool allow_tanh = false);
 
@@ -3066,15 +3062,13 @@ extern "C" int demfi_conv2d(const demfi_conv* h, const demfi_conv* dev, void* st
         if (h->nco == 2) {
 #ifdef DEMFI_ABLATION
             if (var == 5) return launch_persist<2>(h, dev, st);
-            // DEMFI_PAIR: 4 the round-2 product (stores from the MFMA waves), 5 the round-3 double-accumulator experiment
+            // DEMFI_PAIR: 4 the round-2 product (stores from the MFMA waves); the round-3 double-accumulator experiment (5) was deleted
+            // in round 5 (measured negative, profiles/r03_notes.md; git history: conv_exp_dacc.inc)
             static const int pair = getenv("DEMFI_PAIR") ? atoi(getenv("DEMFI_PAIR")) : 0;
             if (pair == 4) return launch_persist<2>(h, dev, st);
 #endif
 #ifdef DEMFI_TRACE
             if (getenv("DEMFI_PAIR") && atoi(getenv("DEMFI_PAIR")) == 4) return launch_persist<2>(h, dev, st);   // phase trace of the 4-wave kernel
-#endif
-#ifdef DEMFI_ABLATION
-            if (pair == 5) return launch_dacc(h, dev, st);       // round-3 double-accumulator experiment (conv_exp_dacc.inc): measured negative
 #endif
             return launch_stg(h, dev, st);
         }

@@ -66,14 +66,23 @@ class DeMFInet(nn.Module):
     def engine(self, H, W, num_update, n_ctx=1, n_trunk=1, exact_ctx=False):
         """Engine for a frame size (built on first use: weight repack + buffer allocation).  n_ctx: independent per-t
         buffer sets (WindowRunner batches / overlaps the time instants of a window over them); exact_ctx: the batched plan
-        covers ALL per-t contexts of an engine, so a cached engine with more of them does not do."""
+        covers ALL per-t contexts of an engine, so a cached engine with more of them does not do.  Two cache slots per
+        (H, W, dtype): the plain one (forward() / WindowRunner, grown on demand) and ONE engine for forward()'s same-window batches
+        (replaced when the batch size changes) -- a batched forward() never evicts the engine a WindowRunner holds."""
         from .engine import Engine
         if not torch.cuda.is_available():
             raise RuntimeError('demfi_amd.DeMFInet.forward needs an MI355X: the forward path is HIP-only '
                                '(no CPU fallback)')
         key = (H, W, self.path_dtype)
         eng = self._engines.get(key)
+        if exact_ctx:
+            if eng is not None and eng.N >= num_update and eng.n_ctx == n_ctx:
+                return eng                                         # a runner-shaped engine with exactly this many contexts
+            key = key + ('batch',)
+            eng = self._engines.get(key)
         if eng is None or eng.N < num_update or eng.n_ctx < n_ctx or eng.n_trunk < n_trunk or (exact_ctx and eng.n_ctx != n_ctx):
+            self._engines.pop(key, None)                           # release the old workspace before the new one is allocated
+            del eng
             sd = {k: v.detach() for k, v in self.state_dict().items()}
             eng = Engine(sd, H, W, self.path_dtype, self.device, max(num_update, 3), self.hp, n_ctx=n_ctx, n_trunk=n_trunk)
             self._engines[key] = eng
@@ -98,8 +107,11 @@ class DeMFInet(nn.Module):
             raise RuntimeError('demfi_amd.DeMFInet: input on %s, model built for %s (args.gpu)' % (x.device, self.device))
 
     @torch.no_grad()
-    def forward(self, x, t_value, num_update=None, is_training=None, clone_outputs=True):
-        """x [B,3,4,H,W] fp32 in [-1,1], frame order (B0,B1,B-1,B2); t_value [B,1] in (0,1)."""
+    def forward(self, x, t_value, num_update=None, is_training=None, clone_outputs=True, same_window=None):
+        """x [B,3,4,H,W] fp32 in [-1,1], frame order (B0,B1,B-1,B2); t_value [B,1] in (0,1).
+        same_window (B >= 2): the items are ONE window at B time instants (what a x M caller stacks) -> trunk once + the batched
+        per-t plan.  None = detect it from the layout only (a stride-0 ``expand`` along the batch: no device sync, no read of the
+        input); True = the caller says so (equal copies); False = never.  Results are bit-identical either way."""
         if is_training:
             raise NotImplementedError('training branch (DeMFInet.py:170-172) is outside the inference hot path')
         if self.hp.visualization_flag:
@@ -109,7 +121,7 @@ class DeMFInet(nn.Module):
         B, _, _, H, W = x.shape
         stream = torch.cuda.current_stream(x.device).cuda_stream
         outs = []
-        if 2 <= B <= 8 and (x.stride(0) == 0 or all(torch.equal(x[b], x[0]) for b in range(1, B))):
+        if 2 <= B <= 8 and (same_window if same_window is not None else x.stride(0) == 0):
             # A batch whose items are the SAME window at different t (what a x M caller stacks, main.py:1121-1178): the batch
             # dimension maps onto the batched per-t plan -- trunk once, every convolution of the per-t segment once over
             # batch x B (demfi_forward_tb).  Bit-identical to B separate calls (tests/test_gpu_e2e.py).  Items with different

@@ -112,7 +112,9 @@ class SepConvGRU(_Operator):
         st = self._stream()
         for i in range(n):
             pl.launch_conv(i, st, 'SepConvGRU launch %d' % i)
-        return bufs['h2'].permute(0, 3, 1, 2).to(h.dtype)
+        # an OWNED tensor like the reference nn.Module returns: a view of the cached per-shape plan buffer would be overwritten by the
+        # next forward() on the same shape
+        return bufs['h2'].permute(0, 3, 1, 2).to(h.dtype, copy=True)
 
 
 class FGAC(_Operator):
@@ -170,8 +172,8 @@ class FGAC(_Operator):
         for b in range(B):
             vs, ve, vo = pl.fview(bufs['source'], b=b), pl.fview(bufs['e_s'], b=b), pl.fview(bufs['out'], b=b)
             L.check(lib.demfi_gate_blend(bufs['w'][b].data_ptr(), C.byref(vs), C.byref(ve), C.byref(vo), self.nf, H, W, st), 'gate_blend')
-        out = bufs['out'].permute(0, 3, 1, 2).to(ref.dtype)
-        w_sr = bufs['w'].view(B, 1, H, W).to(ref.dtype)
+        out = bufs['out'].permute(0, 3, 1, 2).to(ref.dtype, copy=True)      # owned (not views of the cached plan buffers)
+        w_sr = bufs['w'].view(B, 1, H, W).to(ref.dtype, copy=True)
         # visualisation by-product (DeMFInet.py:455-462), not on the network's path: mean |out - source| min-max normalised per image
         diff = (out.float() - source.float()).abs().mean(1, keepdim=True)
         flat = diff.view(B, -1)

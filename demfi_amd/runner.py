@@ -44,7 +44,7 @@ class WindowRunner:
         self.tb = bool(use_graph and mfi > 2 and os.environ.get('DEMFI_TB', '1') != '0')
         # a runner built earlier on this model for the same frame size fixed the engine's shape: take it over (batched mode) instead
         # of probing the memory again -- a second runner (bench.py's final_only one) must not force a second multi-GB engine
-        cached = getattr(model, '_engines', {}).get((H, W, model.path_dtype)) if self.tb else None
+        cached = getattr(model, '_engines', {}).get((H, W, model.path_dtype)) if self.tb else None     # the plain slot only: never forward()'s batch engine
         if cached is not None and cached.n_ctx <= 1:     # a plain forward()'s engine says nothing about a runner's configuration
             cached = None
         how = 'explicit' if (n_ctx is not None or n_trunk is not None) else None
@@ -74,12 +74,14 @@ class WindowRunner:
             if n_ctx is None:
                 # FIXED default, a function of the arguments only: all time instants of a window in one launch sequence when
                 # M-1 <= 8 (7 at x8), else the largest divisor of M-1 that is <= 8 (5 at x16); three trunk sets (a third window in
-                # flight: +0.7 % at 720p) when their workspace stays below 144 GB = half of an MI355X's HBM, two otherwise.  Engine creation fails loudly when the
+                # flight: +0.7 % at 720p) when their workspace stays below half of the device's memory (144 GB on an MI355X), two otherwise.  Engine creation fails loudly when the
                 # workspace does not fit the GPU -- nothing is silently scaled down.
                 how = how or 'fixed default'
                 n_ctx = max(d for d in range(1, min(8, mfi - 1) + 1) if (mfi - 1) % d == 0)
                 if n_trunk is None:
-                    n_trunk = 3 if 0 < lib.demfi_workspace_bytes(H, W, max(n_tst, 3), dt, 3, n_ctx) <= 144 * 10 ** 9 else 2
+                    # half of THIS device's memory (144 GB on an MI355X): a function of the arguments and the part, not of co-tenants
+                    half = (torch.cuda.get_device_properties(model.device).total_memory // 2) if torch.cuda.is_available() else 144 * 10 ** 9
+                    n_trunk = 3 if 0 < lib.demfi_workspace_bytes(H, W, max(n_tst, 3), dt, 3, n_ctx) <= half else 2
             elif n_ctx > 1 and (mfi - 1) % n_ctx:
                 raise ValueError('WindowRunner: n_ctx=%d must divide M-1=%d for the batched per-t plan' % (n_ctx, mfi - 1))
             self.n_ctx = int(n_ctx)

@@ -36,11 +36,44 @@ def synthetic_state_dict(seed=0, hp=None, gain=1.0, bias_std=0.02, dtype=torch.f
     return sd
 
 
+def _numpy_scalar_globals():
+    """What a reference checkpoint holds besides tensors: SaveManager stores the best / last metrics and loss meters next to
+    ``state_dict_Model`` (/root/reference/main.py:262-271) as ``numpy.float64`` scalars, which unpickle through
+    ``numpy.core.multiarray.scalar`` + ``numpy.dtype``.  Allow-listing exactly those keeps ``weights_only=True`` (no arbitrary
+    code from a downloaded .pt) while genuine reference files load."""
+    import numpy as np
+    out = [np.dtype, np.ndarray]
+    for mod in ('numpy._core.multiarray', 'numpy.core.multiarray'):
+        try:
+            m = __import__(mod, fromlist=['scalar'])
+            out += [m.scalar, m._reconstruct]
+        except (ImportError, AttributeError):
+            pass
+    for name in ('float64', 'float32', 'float16', 'int64', 'int32', 'uint8', 'bool_'):
+        out.append(type(np.dtype(getattr(np, name))))       # numpy >= 1.25: per-type dtype classes (numpy.dtypes.Float64DType ...)
+        out.append(getattr(np, name))
+    seen, uniq = set(), []
+    for g in out:
+        if id(g) not in seen:
+            seen.add(id(g))
+            uniq.append(g)
+    return uniq
+
+
+def _safe_load(path):
+    try:
+        with torch.serialization.safe_globals(_numpy_scalar_globals()):
+            return torch.load(path, map_location='cpu', weights_only=True)
+    except Exception as e:                                      # pickle.UnpicklingError and friends
+        raise ValueError('%s: cannot be read with weights_only=True (%s). Re-save it as {"state_dict_Model": model.state_dict()} '
+                         'or a bare state_dict of tensors.' % (path, str(e).splitlines()[0])) from e
+
+
 def load_checkpoint(path, key='state_dict_Model'):
     """state_dict of a reference checkpoint file: ``torch.load(path)['state_dict_Model']`` (/root/reference/utils.py:95-103,
     main.py:316, 351); a bare state_dict file and ``module.``-prefixed (DataParallel) keys are accepted too.  Tensors come
     back as fp32 CPU tensors, ready for ``DeMFInet.load_state_dict`` (which checks the 260 keys / shapes strictly)."""
-    ck = torch.load(path, map_location='cpu')
+    ck = _safe_load(path)
     sd = ck[key] if isinstance(ck, dict) and key in ck else ck
     if not isinstance(sd, dict) or not sd:
         raise ValueError('%s: no state_dict (expected a dict with %r or a bare state_dict)' % (path, key))

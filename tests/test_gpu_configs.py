@@ -22,6 +22,7 @@ from demfi_amd import DeMFInet, HyperParams, synthetic_state_dict, synthetic_win
 from demfi_amd import _lib as L                                                       # noqa: E402
 from demfi_amd.harness import pad_forward_crop, t_schedule                            # noqa: E402
 from oracle import demfi_oracle as O                                                  # noqa: E402
+from tests.conftest import record_fp16_margin                                         # noqa: E402
 
 DEV = 'cuda:0'
 
@@ -103,19 +104,21 @@ def test_config2_720p_fp16_n3_psnr_bounds(oracle_720p_n5):
         exp = ref[1][2][i][0].numpy()
         ps, dps = O.psnr(got, exp), O.psnr(got, gt) - O.psnr(exp, gt)
         print('720p fp16 N=3 frame %d: PSNR vs fp32 oracle %.2f dB, dPSNR vs pseudo-GT %+.4f dB' % (i, ps, dps))
+        record_fp16_margin('config2_720p_seed1_t0.5', i, ps, dps, size='736x1280', n_tst=3, t=0.5, seed=1)
         assert np.isfinite(got).all()
         assert ps >= 44.0 and abs(dps) <= 5e-3, (i, ps, dps)
     del m
     torch.cuda.empty_cache()
 
 
-def test_config2_720p_fp16_vs_oracle_second_window_t_eighth():
-    """Second DIRECT fp16-vs-oracle point at full size (the t = 0.5 test above was the only one; the 3 x 3
-    gate below compares fp16 with this repo's fp32 HIP path): another window (seed 2) at the first time instant of a x8
-    schedule, t = 1/8, one more ~36 s oracle run at N_tst = 3.  Same gate, margin printed."""
+@pytest.mark.parametrize('seed,tv', [(2, 0.125), (3, 0.875)])
+def test_config2_720p_fp16_vs_oracle_other_windows_schedule_ends(seed, tv):
+    """More DIRECT fp16-vs-oracle points at full size (the t = 0.5 test above was the only one; the
+    3 x 3 gate below compares fp16 with this repo's fp32 HIP path): other windows at BOTH ends of a x8 schedule -- (seed 2, t = 1/8)
+    and (seed 3, t = 7/8) -- one ~36 s oracle run at N_tst = 3 each.  Same gate; the margins go to gpurun_out/fp16_margins.json."""
     torch.set_num_threads(min(os.cpu_count() or 1, 32))
-    x = synthetic_window(736, 1280, 2)
-    t = torch.tensor([[0.125]])
+    x = synthetic_window(736, 1280, seed)
+    t = torch.tensor([[tv]])
     with torch.no_grad():
         ref = O.forward(synthetic_state_dict(0), x, t, 3)
     m = _model(torch.float16)
@@ -125,8 +128,9 @@ def test_config2_720p_fp16_vs_oracle_second_window_t_eighth():
         got = fin[2][i][0].cpu().numpy()
         exp = ref[1][2][i][0].numpy()
         ps, dps = O.psnr(got, exp), O.psnr(got, gt) - O.psnr(exp, gt)
-        print('720p fp16 N=3 seed 2 t=1/8 frame %d: PSNR vs fp32 oracle %.2f dB (margin %.2f dB over the 44 dB gate), dPSNR vs pseudo-GT %+.4f dB'
-              % (i, ps, ps - 44.0, dps))
+        print('720p fp16 N=3 seed %d t=%g frame %d: PSNR vs fp32 oracle %.2f dB (margin %.2f dB over the 44 dB gate), dPSNR vs pseudo-GT %+.4f dB'
+              % (seed, tv, i, ps, ps - 44.0, dps))
+        record_fp16_margin('config2_720p_seed%d_t%g' % (seed, tv), i, ps, dps, size='736x1280', n_tst=3, t=tv, seed=seed)
         assert np.isfinite(got).all()
         assert ps >= 44.0 and abs(dps) <= 5e-3, (i, ps, dps)
     del m
@@ -250,6 +254,7 @@ def test_config5_1080p_x16_runner_properties_and_psnr():
     gt = xs[0][0, :, 0].cpu().numpy()
     ps, dps = O.psnr(got, exp), O.psnr(got, gt) - O.psnr(exp, gt)
     print('1080p x16 fp16 t=9/16: PSNR vs fp32 oracle %.2f dB, dPSNR vs pseudo-GT %+.4f dB' % (ps, dps))
+    record_fp16_margin('config5_1080p_x16_seed50_t9/16', 2, ps, dps, size='1088x1920', n_tst=3, t=9 / 16, seed=50)
     assert ps >= 44.0 and abs(dps) <= 5e-3
 
 

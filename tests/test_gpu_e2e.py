@@ -114,9 +114,15 @@ def test_batch_of_same_window_runs_the_batched_plan_bit_identically(dtype):
     H, W, N, B = 64, 96, 2, 3
     x1 = synthetic_window(H, W, 21).to(DEV)
     t = torch.tensor([[0.125], [0.5], [0.875]], device=DEV)
-    for xb in (x1.expand(B, -1, -1, -1, -1), x1.repeat(B, 1, 1, 1, 1)):          # a stride-0 view and a materialised copy
-        d1, fin, flows, occs, ov = m(xb, t, N)
-        assert m._engines[(H, W, dtype)].n_ctx == B
+    # a stride-0 view is detected from the layout alone (no device sync, no read of the input); a materialised copy needs the
+    # caller's word (same_window=True); without it the items run as distinct windows -- same results, B trunks
+    for xb, kw in ((x1.expand(B, -1, -1, -1, -1), {}), (x1.repeat(B, 1, 1, 1, 1), {'same_window': True}), (x1.repeat(B, 1, 1, 1, 1), {})):
+        m._engines.pop((H, W, dtype, 'batch'), None)
+        d1, fin, flows, occs, ov = m(xb, t, N, **kw)
+        batched = (H, W, dtype, 'batch') in m._engines
+        assert batched == (xb.stride(0) == 0 or bool(kw))
+        if batched:
+            assert m._engines[(H, W, dtype, 'batch')].n_ctx == B
         assert tuple(fin[N - 1][2].shape) == (B, 3, H, W) and tuple(ov.shape) == (B, 3, H, W)
         for b in range(B):
             s = m(x1, t[b:b + 1], N)

@@ -36,8 +36,17 @@ def test_sep_conv_gru_matches_the_oracle(sd, dtype, B, H, W):
     assert (got.cpu() - want).abs().max() < TOL[dtype]
     # a second call on the cached plan, other data: no state left behind
     h2 = torch.tanh(torch.randn(B, 64, H, W)).half().float()
+    keep = got.clone()
     got2 = op(h2.to(DEV), x.to(DEV))
     assert (got2.cpu() - O.sep_conv_gru(sd, h2, x)).abs().max() < TOL[dtype]
+    # results are OWNED tensors (the reference nn.Module returns fresh ones): the second call on the cached plan must not
+    # overwrite the first result, whatever the input dtype
+    assert got.data_ptr() != got2.data_ptr() and torch.equal(got, keep)
+    if dtype == torch.float16:
+        g16a = op(h.to(DEV).half(), x.to(DEV).half())
+        k16 = g16a.clone()
+        g16b = op(h2.to(DEV).half(), x.to(DEV).half())
+        assert g16a.dtype == torch.float16 and torch.equal(g16a, k16) and not torch.equal(g16a, g16b)
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.float16])
@@ -64,6 +73,10 @@ def test_fgac_matches_the_oracle(sd, dtype, B, H, W):
     d = (d / d.max(1, keepdim=True)[0]).view(B, 1, H, W)
     assert (diff.cpu() - d).abs().max() < 50 * TOL[dtype]      # min-max normalisation divides by a small range
     assert float(diff.min()) == 0.0 and abs(float(diff.max()) - 1.0) < 1e-6
+    # owned results: a second call (other data) leaves the first call's tensors alone
+    ko, kw = out.clone(), w.clone()
+    out2, w2, _ = op(src.to(DEV), ref.to(DEV), flow.to(DEV))
+    assert torch.equal(out, ko) and torch.equal(w, kw) and not torch.equal(out, out2)
 
 
 def test_operators_reject_what_the_reference_modules_would():

@@ -16,3 +16,5 @@ T=$(find $OUT/seq -name "*kernel_trace.csv" | head -1)
 python $GRAFT_REPO_ROOT/tools/trace_by_op.py $T $OUT/ops_seq.txt $OUT/seq_trace_by_op.md 1 $OUT/seq_trace_roofline.json 2>&1 | tail -3
 rm -rf $OUT/seq
 head -5 $OUT/seq_trace_by_op.md
+# fp16-vs-oracle margins recorded by tests/test_gpu_configs.py (run `pytest tests/test_gpu_configs.py -m gpu` in the same gpurun call)
+[ -f $GRAFT_REPO_ROOT/gpurun_out/fp16_margins.json ] && cp $GRAFT_REPO_ROOT/gpurun_out/fp16_margins.json $OUT/fp16_margins.json
