@@ -166,7 +166,7 @@ def load_rocprof_frac():
     """roofline.frac of the same ten launches from the committed rocprofv3 kernel trace of a sequential bench run
     (profiles/r04_seq_trace_roofline.json, written by tools/trace_by_op.py on the GPU box) so that the two timings -- HIP events
     measured live in this run, rocprofv3 kernel durations measured on the box that produced the committed trace -- sit side by side."""
-    for r in ('r04', 'r03'):
+    for r in ('r05', 'r04', 'r03'):
         path = os.path.join(ROOT, 'profiles', r + '_seq_trace_roofline.json')
         if os.path.exists(path):
             with open(path) as f:
@@ -178,7 +178,7 @@ def load_pmc_traffic():
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary (profiles/r02_pmc_traffic.json,
     written by tools/pmc_traffic.py on the GPU box: separate --pmc passes, 2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction)."""
     path = None
-    for r in ('r04', 'r03', 'r02'):
+    for r in ('r05', 'r04', 'r03', 'r02'):
         path = os.path.join(ROOT, 'profiles', r + '_pmc_traffic.json')
         if os.path.exists(path):
             break
@@ -324,9 +324,10 @@ def main():
         prof = eng.profile(a.n_tst, isolated=False, batched=runner.tb)
         per_t = sum(p[3] for p in prof if p[0] != 'trunk') / nb
         trunk = sum(p[3] for p in prof if p[0] == 'trunk')
-        convs = [p for p in prof if p[1] == 'conv']
+        convs = [p for p in prof if p[1] in ('conv', 'resblock')]              # resblock (round 5): conv1 -> ReLU -> conv2 + identity in ONE launch
         dom = max(convs, key=lambda p: p[3])
         grp = [p for p in convs if p[2].startswith('Decoder_res.')]          # D1 residual blocks: 3x3 64->64, batch 3
+        fused = bool(grp) and all(p[1] == 'resblock' for p in grp)
         g_ms = sum(p[3] for p in grp) / len(grp)
         g_fl = 2.0 * sum(p[4] for p in grp) / len(grp)
         tot_conv_ms = sum(p[3] for p in convs)
@@ -334,14 +335,15 @@ def main():
         peak = MFMA_PEAK_TF[a.dtype]
         ach = g_fl / (g_ms * 1e-3) / 1e12
         pmc = load_pmc_traffic() if a.dtype == 'fp16' and (eng.H, eng.W) == (736, 1280) else None
-        kname = runner.engine.dominant_kernel_name() if hasattr(runner.engine, 'dominant_kernel_name') else \
-            ('conv3x3_c64_stg_kernel' if a.dtype == 'fp16' else 'conv_kernel<float,2>')
+        kname = 'resblock3x3_c64_kernel' if fused else ('conv3x3_c64_stg_kernel' if a.dtype == 'fp16' else 'conv_kernel<float,2>')
         # The kernel is co-bound: arithmetic intensity 288 (no residual) / 192 flop/B (residual) sits below the chip balance
         # point of 312, so both ceilings are reported per variant.  Algorithmic bytes (every tensor once):
         # input + output (+ residual) = 2 (3) x H x W x 64 ch x 2 B per image.
         img_bytes = eng.H * eng.W * 64 * 2
         variants = {}
-        for key, sel, ntens in (('no_residual', '.conv1', 2), ('residual', '.conv2', 3)):
+        # fused residual block: the intermediate stays in LDS and the identity comes from the input tile, so the algorithmic bytes of a
+        # launch are input + output only (2 tensors for 2 convolutions: 576 flop/B -- MFMA-bound, well above the chip balance of 312)
+        for key, sel, ntens in ((('fused_block', '', 2),) if fused else (('no_residual', '.conv1', 2), ('residual', '.conv2', 3))):
             g2 = [p for p in grp if p[2].endswith(sel)]
             v_ms = sum(p[3] for p in g2) / len(g2)
             v_fl = 2.0 * sum(p[4] for p in g2) / len(g2)
@@ -349,15 +351,17 @@ def main():
             variants[key] = {'launches': len(g2), 'avg_launch_ms': round(v_ms, 4), 'TFLOPs': round(v_fl / v_ms / 1e9, 1),
                              'frac_mfma': round(v_fl / v_ms / 1e9 / peak, 4), 'algorithmic_bytes': v_by,
                              'GBs': round(v_by / v_ms / 1e6, 1), 'frac_hbm': round(v_by / v_ms / 1e6 / HBM_PEAK_GBS, 4)}
-        out['roofline'] = {'kernel': '%s: D1 residual blocks, 3x3 64->64, batch 3 x %d time instants per launch (%d launches per %d frames)' % (kname, nb, len(grp), nb),
-                           'bound': 'mfma', 'co_bound': 'mfma+hbm', 'achieved': round(ach, 2), 'peak': peak,
+        out['roofline'] = {'kernel': '%s: D1 residual blocks%s, 3x3 64->64, batch 3 x %d time instants per launch (%d launches per %d frames)' %
+                                     (kname, ' (conv1 -> ReLU -> conv2 + identity fused: 2 convolutions per launch)' if fused else '', nb, len(grp), nb),
+                           'bound': 'mfma', 'co_bound': None if fused else 'mfma+hbm', 'achieved': round(ach, 2), 'peak': peak,
                            'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
                            'variants': variants,
                            # HBM bytes per launch from rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE, gfx950 correction), read from
                            # the committed summary (profiles/r02_pmc_traffic.json; per batch-3 image group: x nb for a launch of the batched plan)
-                           'traffic': (pmc.get('dominant_traffic_bytes_b21') if nb == 7 and pmc.get('dominant_traffic_bytes_b21')
-                                       else pmc.get('dominant_traffic_bytes') * nb) if pmc else None,
-                           'algorithmic_bytes': pmc.get('dominant_algorithmic_bytes') * nb if pmc else None,
+                           'traffic': ((pmc.get('resblock_traffic_bytes_b21') if nb == 7 else None) if fused else
+                                       (pmc.get('dominant_traffic_bytes_b21') if nb == 7 and pmc.get('dominant_traffic_bytes_b21')
+                                        else pmc.get('dominant_traffic_bytes') * nb)) if pmc else None,
+                           'algorithmic_bytes': (2.0 * img_bytes * 3 * nb) if fused else (pmc.get('dominant_algorithmic_bytes') * nb if pmc else None),
                            'traffic_source': pmc.get('source') if pmc else None,
                            'avg_launch_ms': round(g_ms, 4), 'flop_per_launch': g_fl,
                            'frac_rocprof': None, 'rocprof': None,
@@ -371,6 +375,8 @@ def main():
                            'all_convs_TFLOPs': round(tot_conv_fl / (tot_conv_ms * 1e-3) / 1e12, 2),
                            'slowest_conv': '%s %.3f ms' % (dom[2], dom[3])}
         rp = load_rocprof_frac() if a.dtype == 'fp16' and (eng.H, eng.W) == (736, 1280) and nb == 7 else None
+        if rp and bool(rp.get('fused')) != fused:               # a committed trace of the other kernel says nothing about this run
+            rp = None
         if rp:
             out['roofline']['frac_rocprof'] = round(g_fl / (rp['avg_launch_ms'] * 1e-3) / 1e12 / peak, 4)
             out['roofline']['rocprof'] = rp

@@ -780,6 +780,35 @@ struct Builder {
         simple(seg, DEMFI_OP_PACK, "pack", op);
     }
 
+    // Round 5: the two launches conv() has just appended (conv1 -> ReLU -> t, conv2 + identity) become ONE launch of the fused
+    // residual-block kernel when the pair qualifies (fp16 plan, 3x3 64 -> 64, persistent-kernel packing): the intermediate stays in
+    // LDS, the scratch buffer t is not touched.  Both descriptors are kept as they are (the plan interpreter of the CPU tests and
+    // the A/B switch DEMFI_RESBLOCK=0 run them one after the other).
+    void fuse_resblock(OpList& seg, const std::string& name)
+    {
+        static const bool on = !(getenv("DEMFI_RESBLOCK") && atoi(getenv("DEMFI_RESBLOCK")) == 0);
+        if (status < 0 || !on || seg.size() < 2) return;
+        const demfi_op o2 = seg[seg.size() - 1], o1 = seg[seg.size() - 2];
+        if (o1.kind != DEMFI_OP_CONV || o2.kind != DEMFI_OP_CONV) return;
+        demfi_conv h1 = c->descs[o1.conv], h2 = c->descs[o2.conv];
+        if (dry) {                                               // sizing pass: the blobs are not placed yet
+            static const char some = 0;
+            h1.wpack = h2.wpack = h1.zero_page = h2.zero_page = &some;
+            h1.bias = h2.bias = (const float*)&some;
+        }
+        if (!demfi_resblock_eligible(&h1, &h2)) return;
+        demfi_op op;
+        memset(&op, 0, sizeof(op));
+        op.kind = DEMFI_OP_RESBLOCK;
+        op.conv = o1.conv;
+        op.nch = o2.conv;
+        op.macs = o1.macs + o2.macs;
+        strncpy(op.name, name.c_str(), sizeof(op.name) - 1);
+        seg.pop_back();
+        seg.pop_back();
+        seg.push_back(op);
+    }
+
     // x_{k+1} = x_k + conv2(relu(conv1(x_k))) ping-ponging between buffers a and b (t = scratch); returns the result buffer
     const Tensor* resblocks(OpList& seg, const std::string& prefix, int n, const Tensor& a, const Tensor& t, const Tensor& b,
                             int H, int W, int batch)
@@ -790,6 +819,7 @@ struct Builder {
             conv(seg, p + ".conv1", {fsrc(*cur, 0)}, {D(fview(t), range(0, 64), DEMFI_ACT_RELU)}, H, W, 1, batch);
             conv(seg, p + ".conv2", {fsrc(t, 0)}, {D(fview(*other), range(0, 64), DEMFI_ACT_NONE, DEMFI_MODE_STORE, fview(*cur))},
                  H, W, 1, batch);
+            fuse_resblock(seg, p);
             std::swap(cur, other);
         }
         return cur;
@@ -1502,6 +1532,10 @@ extern "C" int demfi_run_op(demfi_ctx* c, const demfi_op* op, void* stream)
     case DEMFI_OP_CONV:
         if (op->conv < 0 || op->conv >= (int)c->descs.size()) return demfi_set_error(DEMFI_ERR_ARG, "demfi_run_op: descriptor index");
         return demfi_conv2d(&c->descs[op->conv], (const demfi_conv*)(c->base + c->desc_off) + op->conv, stream);
+    case DEMFI_OP_RESBLOCK:
+        if (op->conv < 0 || op->conv >= (int)c->descs.size() || op->nch < 0 || op->nch >= (int)c->descs.size())
+            return demfi_set_error(DEMFI_ERR_ARG, "demfi_run_op: descriptor index");
+        return demfi_resblock3x3_c64(&c->descs[op->conv], &c->descs[op->nch], stream);
     case DEMFI_OP_PACK:
         if (op->bt.nb > 1)
             return demfi_pack_planes_batched((const float* const*)op->p, op->nch, op->o.ptr, c->dtype, op->o.sx, H, W, &op->bt, stream);

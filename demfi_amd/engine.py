@@ -187,9 +187,14 @@ class Plan:
     def launch_conv(self, i, stream, what='conv'):
         L.check(self.lib.demfi_conv2d(C.byref(self._descs[i]), self.desc_dev.data_ptr() + i * self._desc_sz, stream), what)
 
+    def launch_resblock(self, i1, i2, stream, what='resblock'):
+        """Descriptors i1 (conv1 -> ReLU) and i2 (conv2 + identity) as ONE launch of the fused residual-block kernel."""
+        L.check(self.lib.demfi_resblock3x3_c64(C.byref(self._descs[i1]), C.byref(self._descs[i2]), stream), what)
+
 
 SEG_TRUNK, SEG_HEAD, SEG_ITER, SEG_TB_HEAD, SEG_TB_ITER = 0, 1, 2, 3, 4
-KIND_NAME = {0: 'conv', 1: 'pack', 2: 's2d', 3: 'overlay', 4: 'fgac', 5: 'gate', 6: 'cfr', 7: 'warp', 8: 'fgac_window', 9: 'avg_pool'}
+KIND_NAME = {0: 'conv', 1: 'pack', 2: 's2d', 3: 'overlay', 4: 'fgac', 5: 'gate', 6: 'cfr', 7: 'warp', 8: 'fgac_window', 9: 'avg_pool',
+             10: 'resblock'}        # resblock: ONE launch for conv1 -> ReLU -> conv2 + identity (op.conv / op.nch = the two descriptors)
 
 
 class Engine:

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DEMFI_ABI_VERSION 6
+#define DEMFI_ABI_VERSION 7
 
 enum demfi_dtype { DEMFI_F16 = 0, DEMFI_F32 = 1 };
 
@@ -193,6 +193,18 @@ int64_t demfi_conv_lds_bytes(const demfi_conv* host_desc);
 /* host_desc: descriptor in host memory (grid sizing / validation); dev_desc: the same bytes in device
  * memory (the kernel reads it through the scalar cache). */
 int demfi_conv2d(const demfi_conv* host_desc, const demfi_conv* dev_desc, void* stream);
+
+/* Fused residual block (ABI v7): y = x + conv2(relu(conv1(x))) in ONE launch -- ResBlock2D_3D / ResBlock2D (DeMFInet.py:524-563)
+ * as the FAC-FB encoder (341-344), D1 (95-101: Conv3d(1,3,3) == batch 3) and D2 (158-160) use them.  h1 / h2: HOST descriptors of
+ * the two 3x3 64 -> 64 fp16 convolutions exactly as demfi_conv_build makes them for demfi_conv2d (conv1: ReLU, no residual, writing
+ * the intermediate; conv2: no activation, residual == conv1's input, reading the intermediate); the kernel takes the input view,
+ * both packed weight sets / biases and conv2's destination from them (its arguments travel by value: no device descriptors) and
+ * never touches the intermediate buffer: the intermediate lives in LDS (rounded to fp16 like the stored one, so conv1's half is
+ * bit-identical to the two-launch form; conv2 accumulates onto bias + identity instead of adding the identity last: one fp32
+ * rounding apart).  demfi_resblock_eligible: 1 when the pair is such a block (then demfi_resblock3x3_c64 == the two demfi_conv2d
+ * launches), else 0. */
+int demfi_resblock_eligible(const demfi_conv* h1, const demfi_conv* h2);
+int demfi_resblock3x3_c64(const demfi_conv* h1, const demfi_conv* h2, void* stream);
 
 /* pixel_reshuffle(cat(B0,B1,B-1,B2), 2) (DeMFInet.py:234-235, 290-316): x fp32 [3,4,H,W] (C,T order of the
  * module input, batch 1) -> fat NHWC [H/2, W/2, 48], channel = (frame*3 + c)*4 + ry*2 + rx. */
@@ -374,7 +386,8 @@ typedef struct demfi_hparams {           /* DeMFInet.py:17-21, 32, 42, 326, 328;
 
 enum demfi_op_kind {
     DEMFI_OP_CONV = 0, DEMFI_OP_PACK = 1, DEMFI_OP_S2D = 2, DEMFI_OP_OVERLAY = 3, DEMFI_OP_FGAC = 4, DEMFI_OP_GATE = 5,
-    DEMFI_OP_CFR = 6, DEMFI_OP_WARP = 7, DEMFI_OP_FGAC_WINDOW = 8, DEMFI_OP_AVG_POOL = 9
+    DEMFI_OP_CFR = 6, DEMFI_OP_WARP = 7, DEMFI_OP_FGAC_WINDOW = 8, DEMFI_OP_AVG_POOL = 9,
+    DEMFI_OP_RESBLOCK = 10      /* fused residual block: conv = descriptor of conv1, nch = descriptor of conv2 (demfi_resblock3x3_c64) */
 };
 enum demfi_segment { DEMFI_SEG_TRUNK = 0, DEMFI_SEG_T_HEAD = 1, DEMFI_SEG_ITER = 2,     /* TRUNK: ops 0, 1 = s2d, overlay (the prologue demfi_ingest_u8 replaces) */
                      DEMFI_SEG_TB_HEAD = 3, DEMFI_SEG_TB_ITER = 4 };                     /* the batched per-t plan of demfi_forward_tb (context index ignored) */
@@ -382,8 +395,8 @@ enum demfi_segment { DEMFI_SEG_TRUNK = 0, DEMFI_SEG_T_HEAD = 1, DEMFI_SEG_ITER =
 /* One launch of the plan (introspection for tests / per-launch profiling; pointers are already bound). */
 typedef struct demfi_op {
     int32_t kind;           /* demfi_op_kind                                                             */
-    int32_t conv;           /* CONV: descriptor index (demfi_ctx_conv_desc); FGAC_WINDOW: rr; AVG_POOL: sr */
-    int32_t nch;            /* PACK: channels (multiple of 8); WARP / FGAC / GATE: C                     */
+    int32_t conv;           /* CONV: descriptor index (demfi_ctx_conv_desc); FGAC_WINDOW: rr; AVG_POOL: sr; RESBLOCK: conv1's descriptor */
+    int32_t nch;            /* PACK: channels (multiple of 8); WARP / FGAC / GATE: C; RESBLOCK: conv2's descriptor */
     int32_t _pad;           /* FGAC_WINDOW: index map (0 reference code, 1 pixel-centred)                */
     int64_t macs;           /* CONV: algorithmic multiply-accumulates of the launch                      */
     demfi_view a, b, o;     /* WARP: A, B, out; FGAC: src, -, out; GATE: source, e, out; PACK: o = dst     */

@@ -186,6 +186,9 @@ class PlanSim:
             k = op.kind
             if k == 0:
                 self.conv(e.conv_desc(op.conv))
+            elif k == 10:                                                  # fused residual block == its two convolutions in turn
+                self.conv(e.conv_desc(op.conv))
+                self.conv(e.conv_desc(op.nch))
             elif k == 1:                                                   # pack planar fp32 planes -> NHWC slice
                 dst = self.strided(op.o, op.nch, H, W)
                 for c in range(op.nch):

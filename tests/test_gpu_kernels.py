@@ -96,6 +96,62 @@ def test_conv_vs_torch(case, dtype):
     assert err < tol * max(1.0, ref.abs().max().item()), (case, err)
 
 
+RESBLOCK_CASES = [
+    # H, W, batch: strips are 30 output columns wide, steps 16 rows high
+    (16, 30, 1),        # one item: opening step + one step
+    (16, 32, 1),        # a second strip with 2 useful columns
+    (37, 75, 2),        # ragged last strip / last step, two images
+    (48, 64, 3),        # three full steps per strip: the carried lines across steps
+    (133, 530, 1),      # 18 strips x 9 steps: several items per workgroup, chains broken at workgroup boundaries
+    (200, 1280, 2),     # 43 strips x 13 steps x 2 = 1118 items on 256 workgroups (XCD bands, chains that start mid-strip)
+]
+
+
+@pytest.mark.parametrize('case', RESBLOCK_CASES)
+def test_fused_resblock_vs_two_launches_and_torch(case):
+    """Round 5: y = x + conv2(relu(conv1(x))) (ResBlock2D / ResBlock2D_3D, DeMFInet.py:524-563) in ONE launch with the intermediate in
+    LDS, against (i) the two demfi_conv2d launches it replaces -- conv1's half is bit-identical (same MFMA order, same fp16 rounding
+    of the intermediate), conv2 accumulates onto bias + identity instead of adding the identity last, i.e. at most one fp16 ulp
+    apart -- and (ii) an fp64 torch reference of the block that rounds the intermediate to fp16 like both forms do.  The scratch
+    buffer of the two-launch form must stay untouched by the fused launch."""
+    H, W, B = case
+    torch.manual_seed(H * 7 + W)
+    pl = Plan(H, W, torch.float16, DEV)
+    x, t, y2, y1 = (pl._fat(H, W, 64, B) for _ in range(4))
+    x.copy_(torch.randn(x.shape, device=DEV))
+    w1 = torch.randn(64, 64, 3, 3) * (1.0 / 24.0)
+    w2 = torch.randn(64, 64, 3, 3) * (1.0 / 24.0)
+    b1, b2 = torch.randn(64) * 0.1, torch.randn(64) * 0.1
+    seg = []
+    pl.conv(seg, 'conv1', [pl.fsrc(x, 0)], [_Dst(pl.fview(t), range(64), L.ACT_RELU)], H, W, batch=B, weight=w1, bias=b1)
+    pl.conv(seg, 'conv2', [pl.fsrc(t, 0)], [_Dst(pl.fview(y2), range(64), L.ACT_NONE, res=pl.fview(x))], H, W, batch=B, weight=w2, bias=b2)
+    # the same block writing to y1 through the fused kernel
+    pl.conv(seg, 'conv2f', [pl.fsrc(t, 0)], [_Dst(pl.fview(y1), range(64), L.ACT_NONE, res=pl.fview(x))], H, W, batch=B, weight=w2, bias=b2)
+    pl._upload()
+    assert pl.lib.demfi_resblock_eligible(C.byref(pl._descs[0]), C.byref(pl._descs[2])) == 1
+    assert pl.lib.demfi_resblock_eligible(C.byref(pl._descs[1]), C.byref(pl._descs[2])) == 0      # not a block: no ReLU / wrong chaining
+    pl.launch_resblock(0, 2, _stream())
+    torch.cuda.synchronize()
+    assert float(t.abs().max()) == 0.0                         # the intermediate never went to memory
+    pl.launch_conv(0, _stream())
+    pl.launch_conv(1, _stream())
+    torch.cuda.synchronize()
+    got, two = y1.float().cpu(), y2.float().cpu()
+    assert torch.isfinite(got).all()
+    # (ii) fp64 reference with the fp16 intermediate
+    xin = x.permute(0, 3, 1, 2).double().cpu()
+    m = torch.relu(torch.nn.functional.conv2d(xin, w1.half().double(), b1.double(), padding=1)).half().double()
+    ref = torch.nn.functional.conv2d(m, w2.half().double(), b2.double(), padding=1) + xin
+    err = (got.permute(0, 3, 1, 2).double() - ref).abs().max().item()
+    assert err < 4e-3 * max(1.0, ref.abs().max().item()), (case, err)
+    # (i) the two-launch form: the same fp32 sum up to its summation order (|terms| ~ 4: a few 1e-6), i.e. the same fp16 value or its
+    # neighbour where the sum sits on a rounding boundary
+    d = (got - two).abs()
+    ulp = torch.ldexp(torch.ones(()), torch.frexp(torch.maximum(two.abs(), torch.tensor(2.0 ** -14)))[1] - 1 - 10)   # fp16 spacing at |two|
+    assert float(((d - 4e-6).clamp(min=0) / ulp).max()) <= 1.0, (case, float((d / ulp).max()))
+    assert float((d > 0).float().mean()) < 0.05               # and almost everywhere identical
+
+
 def test_persistent_conv_needs_its_cout_order():
     """The 64-channel 3x3 layers of the persistent kernel are packed in a permuted cout order (demfi_conv.cout_perm, set by
     demfi_conv_build): a descriptor of that shape without the flag, or a flagged one the kernel cannot take (no zero page),

@@ -42,7 +42,7 @@ def test_library_exports_every_declared_symbol():
     lib = L.load()
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.demfi_abi_version() == L.ABI_VERSION == 6
+    assert lib.demfi_abi_version() == L.ABI_VERSION == 7
     assert C.sizeof(L.Batch) == 8 + 4 * 8 + 32 * 8
     assert C.sizeof(L.View) == 48 and C.sizeof(L.Piece) == 64 and C.sizeof(L.Chunk) == 24 and C.sizeof(L.Seg) == 168
 
@@ -238,7 +238,7 @@ def test_batched_per_t_plan_equals_per_context_plans(synthetic_sd, dtype):
     # pointers of context 0 + one byte stride per pointer, 0 for window-level buffers); fat warp and plane packs NC launches
     from demfi_amd.engine import SEG_HEAD, SEG_TB_HEAD, SEG_TB_ITER
     one, tb = eng.ops(SEG_HEAD), eng.ops(SEG_TB_HEAD)
-    n_single = sum(1 for o in one if o.kind == 0 or o.kind == 6)
+    n_single = sum(1 for o in one if o.kind in (0, 6, 10))        # convolutions, fused residual blocks, CFR
     assert len(tb) == n_single + NC * (len(one) - n_single)
     cfr = [o for o in tb if o.kind == 6]
     assert len(cfr) == 1 and cfr[0].bt.nb == NC and cfr[0].bt.p[0] == 0 and cfr[0].bt.p[3] > 0 and cfr[0].bt.t > 0   # flows shared, outputs strided

@@ -106,6 +106,38 @@ def main():
         ms = e0.elapsed_time(e1) / reps
         print('%-24s %8.4f ms  %7.1f TFLOP/s' % (nm, ms, fl / ms / 1e9))
     lib = L.load()
+    if case in ('resblock', 'all'):
+        # y = x + conv2(relu(conv1(x))): the fused kernel (round 5) against the two staged-store launches it replaces, alternating
+        pr = Plan(H, W, dtype, DEV)
+        x, t, y = (pr._fat(H, W, 64, B3) for _ in range(3))
+        if os.environ.get('PROBE_DATA') == 'zero':
+            x.zero_()
+        elif os.environ.get('PROBE_DATA') == 'relu':
+            x.copy_(torch.relu(torch.randn(x.shape, device=DEV) * 0.5))
+        else:
+            x.copy_(torch.randn(x.shape, device=DEV) * 0.5)
+        pr.conv([], 'c1', [pr.fsrc(x, 0)], [_Dst(pr.fview(t), range(64), L.ACT_RELU)], H, W, batch=B3, weight=torch.randn(64, 64, 3, 3) / 24.0,
+                bias=torch.zeros(64))
+        pr.conv([], 'c2', [pr.fsrc(t, 0)], [_Dst(pr.fview(y), range(64), L.ACT_NONE, res=pr.fview(x))], H, W, batch=B3,
+                weight=torch.randn(64, 64, 3, 3) / 24.0, bias=torch.zeros(64))
+        pr._upload()
+        fl = 2 * 2.0 * 64 * 64 * 9 * H * W * B3
+
+        def timed(fn):
+            for _ in range(3):
+                fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            e1.synchronize()
+            return e0.elapsed_time(e1) / reps
+        for rnd in range(2):
+            ms2 = timed(lambda: (pr.launch_conv(0, st), pr.launch_conv(1, st)))
+            ms1 = timed(lambda: pr.launch_resblock(0, 1, st))
+            print('resblock b%d round %d: two launches %8.4f ms %7.1f TFLOP/s | fused %8.4f ms %7.1f TFLOP/s (%+.1f %%)'
+                  % (B3, rnd, ms2, fl / ms2 / 1e9, ms1, fl / ms1 / 1e9, 100.0 * (ms1 / ms2 - 1.0)))
     if case in ('warp', 'all'):
         esz = 2 if dtype == torch.float16 else 4
         A = torch.randn(H, W, 64, device=DEV).to(dtype)

@@ -77,10 +77,11 @@ def main():
     # the ten launches of bench.py's roofline object (D1 residual blocks): mean kernel duration in this trace, for roofline.frac_rocprof
     if len(sys.argv) > 5:
         import json
-        grp = [oi for oi, o in enumerate(ops) if o[1] == 'conv' and o[2].startswith('Decoder_res.') and acc[oi]]
+        grp = [oi for oi, o in enumerate(ops) if o[1] in ('conv', 'resblock') and o[2].startswith('Decoder_res.') and acc[oi]]
         if grp:
             means = [sum(d for d, _ in acc[oi]) / len(acc[oi]) / 1e6 for oi in grp]
             json.dump({'avg_launch_ms': round(sum(means) / len(means), 5), 'launches': len(grp), 'samples_per_launch': len(acc[grp[0]]),
+                       'fused': all(ops[oi][1] == 'resblock' for oi in grp),      # round 5: one launch per residual block (2 convolutions)
                        'no_residual_ms': round(sum(m for oi, m in zip(grp, means) if ops[oi][2].endswith('.conv1')) / max(1, sum(1 for oi in grp if ops[oi][2].endswith('.conv1'))), 5),
                        'residual_ms': round(sum(m for oi, m in zip(grp, means) if ops[oi][2].endswith('.conv2')) / max(1, sum(1 for oi in grp if ops[oi][2].endswith('.conv2'))), 5),
                        'source': 'rocprofv3 --kernel-trace of a sequential bench run (DEMFI_NTRUNK=1), tools/trace_by_op.py; another box than the live HIP-event numbers'},
