@@ -384,9 +384,12 @@ __global__ __launch_bounds__(RB_NTHREADS, 1) void resblock3x3_c64_kernel(const R
         asm volatile("s_barrier" ::: "memory");                 // B: the helpers hold the previous outputs in registers
         RB_STAMP(wave, trk, 3);
         {
-            // conv1 epilogue (ORIGINAL)
+            // conv1 epilogue: ReLU, fp16 -> M lines (rows 14, 15 also to the carry slot the NEXT step reads); the accumulators then
+            // restart at bias2 + identity (the row's identity is read from the input window before its conversions are issued).  A
+            // lone wave issues one VALU instruction per ~10 cycles (tools/microbench/valu_rate.hip), so the epilogue is its instruction
+            // count: conv2's zero padding -- M is zero outside the image -- is therefore not a mask on every value but a second pass
+            // that zeroes the few lines / columns concerned, on the ~9 % of the steps that touch the image border.
             const bool edge = row0 + 1 < 0 || row0 + RB_R + 1 > H || x0 - 1 < 0 || x0 + 31 > W;
-            const unsigned colm = (unsigned)(x0 + col_x) < (unsigned)W ? 0xffffffffu : 0u;
             f16x_t c2;
             if (!pro) {
 #pragma unroll
@@ -400,8 +403,6 @@ __global__ __launch_bounds__(RB_NTHREADS, 1) void resblock3x3_c64_kernel(const R
             char* const crow = smem + RB_C_OFF + (cp ^ 1) * 2 * RB_ML;
             rb_for<0, 8>([&](auto P) {
                 constexpr int p = decltype(P)::value;
-                const int y = row0 + 1 + rh * 8 + p;
-                const unsigned m = (edge && !((unsigned)y < (unsigned)H)) ? 0u : (edge ? colm : 0xffffffffu);
                 u4_t idr[2];
                 if (!pro) {
                     idr[0] = *(const u4_t*)(tin + p * RB_IN_LS + ioff[0]);
@@ -417,8 +418,7 @@ __global__ __launch_bounds__(RB_NTHREADS, 1) void resblock3x3_c64_kernel(const R
                     }
                     const h8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
                     o = __builtin_elementwise_max(o, z);
-                    u4_t ob = __builtin_bit_cast(u4_t, o);
-                    ob &= m;
+                    const u4_t ob = __builtin_bit_cast(u4_t, o);
                     if (!pro) *(u4_t*)(mrow + p * RB_ML + soff[m2]) = ob;
                     if (p >= 6 && rh == 1) *(u4_t*)(crow + (p - 6) * RB_ML + soff[m2]) = ob;
                 }
@@ -436,6 +436,22 @@ __global__ __launch_bounds__(RB_NTHREADS, 1) void resblock3x3_c64_kernel(const R
                     }
                 }
             });
+            if (edge) {
+                // LDS operations of one wave complete in order: these zeros land on top of the values this lane has just written
+                const bool col_out = !((unsigned)(x0 + col_x) < (unsigned)W);
+                const u4_t zz = {0u, 0u, 0u, 0u};
+                rb_for<0, 8>([&](auto P) {
+                    constexpr int p = decltype(P)::value;
+                    const bool row_out = !((unsigned)(row0 + 1 + rh * 8 + p) < (unsigned)H);
+                    if (row_out || col_out) {
+#pragma unroll
+                        for (int m2 = 0; m2 < 2; ++m2) {
+                            if (!pro) *(u4_t*)(mrow + p * RB_ML + soff[m2]) = zz;
+                            if (p >= 6 && rh == 1) *(u4_t*)(crow + (p - 6) * RB_ML + soff[m2]) = zz;
+                        }
+                    }
+                });
+            }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         RB_STAMP(wave, trk, 4);
