@@ -46,7 +46,7 @@ constexpr int RB_NH = 4;                                         // helper waves
 constexpr int RB_NTHREADS = 256 + 64 * RB_NH;
 constexpr int RB_NIW = (RB_IN_NI + RB_NH - 1) / RB_NH;           // 20 DMA instructions per helper (the last may not exist)
 #ifndef DEMFI_RB_DEPTH
-#define DEMFI_RB_DEPTH 6                                         // A prefetch distance in steps of 8 MFMAs
+#define DEMFI_RB_DEPTH 4                                         // A prefetch distance in steps of 8 MFMAs (6: 14 registers spilled at the 256-register limit)
 #endif
 constexpr int RB_DEPTH = DEMFI_RB_DEPTH;
 constexpr int RB_NSTEP = 36;                                     // (kx, k-step) groups x ky
@@ -273,7 +273,9 @@ __global__ __launch_bounds__(RB_NTHREADS, 1) void resblock3x3_c64_kernel(const R
     }
     auto boff = [&](auto G) {
         constexpr int g = decltype(G)::value;
-        return boff0[g >> 2] ^ ((g & 3) << 5);
+        int b = boff0[g >> 2];
+        asm volatile("" : "+v"(b));                              // computed where it is used (1 VALU): hoisted out of the step loops the twelve values are spilled
+        return b ^ ((g & 3) << 5);
     };
     int soff[2], ioff[2];
 #pragma unroll
@@ -375,7 +377,33 @@ __global__ __launch_bounds__(RB_NTHREADS, 1) void resblock3x3_c64_kernel(const R
 #pragma unroll
                 for (int j = 0; j < 4; ++j) c1[g * 4 + j] = q[j];
             }
-            conv_phase(line_in, w1, pro ? w1 : w2, std::true_type{}, c1);
+            if (!pro) conv_phase(line_in, w1, w2, std::true_type{}, c1);
+            else {
+                // the other seven accumulators are dead here; say so (an empty asm "defines" them), or the allocator carries their old
+                // values through this path in scratch
+                asm volatile("" : "=v"(acc[1]), "=v"(acc[2]), "=v"(acc[3]), "=v"(acc[4]), "=v"(acc[5]), "=v"(acc[6]), "=v"(acc[7]));
+                // chain-opening step: only the two carried lines (block rows 14, 15) are wanted -- wave (cs, rh) computes row 14 + rh
+                // with ONE accumulator: 36 x (A fragment + MFMA) instead of 36 x 8 MFMAs (18 700 -> ~7 000 cycles per chain)
+                const char* const tp = smem + (14 + rh) * RB_IN_LS;
+                uint4 Bc[3], Bn[3];
+                rb_for<0, 3>([&](auto L) { Bc[decltype(L)::value] = *(const uint4*)(tp + decltype(L)::value * RB_IN_LS + boff(std::integral_constant<int, 0>{})); });
+                rb_for<0, 12>([&](auto G) {
+                    constexpr int g = decltype(G)::value;
+                    if constexpr (g + 1 < 12) {
+                        const int o = boff(std::integral_constant<int, g + 1>{});
+                        rb_for<0, 3>([&](auto L) { Bn[decltype(L)::value] = *(const uint4*)(tp + decltype(L)::value * RB_IN_LS + o); });
+                    }
+                    rb_for<0, 3>([&](auto KY) {
+                        constexpr int t = 3 * g + decltype(KY)::value;
+                        const uint4 av = A[t % RB_DEPTH];
+                        A[t % RB_DEPTH] = a_load(w1, std::integral_constant<int, (t + RB_DEPTH) % RB_NSTEP>{});
+                        if constexpr (t == 0) rb_mma_c(acc[0], av, Bc[0], c1);
+                        else rb_mma(acc[0], av, Bc[decltype(KY)::value]);
+                    });
+                    rb_for<0, 3>([&](auto L) { Bc[decltype(L)::value] = Bn[decltype(L)::value]; });
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            }
         }
 #if defined(DEMFI_TRACE) && defined(__HIP_DEVICE_COMPILE__)
         asm volatile("" ::"v"(acc[0]), "v"(acc[1]), "v"(acc[2]), "v"(acc[3]), "v"(acc[4]), "v"(acc[5]), "v"(acc[6]), "v"(acc[7]));
@@ -390,6 +418,24 @@ __global__ __launch_bounds__(RB_NTHREADS, 1) void resblock3x3_c64_kernel(const R
             // count: conv2's zero padding -- M is zero outside the image -- is therefore not a mask on every value but a second pass
             // that zeroes the few lines / columns concerned, on the ~9 % of the steps that touch the image border.
             const bool edge = row0 + 1 < 0 || row0 + RB_R + 1 > H || x0 - 1 < 0 || x0 + 31 > W;
+            if (pro) {                                           // the opening step's single row -> carry line rh of the slot the next step reads
+                const bool ok = (unsigned)(row0 + 15 + rh) < (unsigned)H && (unsigned)(x0 + col_x) < (unsigned)W;
+                char* const cr = smem + RB_C_OFF + (cp ^ 1) * 2 * RB_ML + rh * RB_ML;
+#pragma unroll
+                for (int m2 = 0; m2 < 2; ++m2) {
+                    h8_t o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        o[j] = (half_t)acc[0][(2 * m2) * 4 + j];
+                        o[4 + j] = (half_t)acc[0][(2 * m2 + 1) * 4 + j];
+                    }
+                    const h8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
+                    o = __builtin_elementwise_max(o, z);
+                    u4_t ob = __builtin_bit_cast(u4_t, o);
+                    ob &= ok ? 0xffffffffu : 0u;
+                    *(u4_t*)(cr + soff[m2]) = ob;
+                }
+            }
             f16x_t c2;
             if (!pro) {
 #pragma unroll
@@ -403,11 +449,10 @@ __global__ __launch_bounds__(RB_NTHREADS, 1) void resblock3x3_c64_kernel(const R
             char* const crow = smem + RB_C_OFF + (cp ^ 1) * 2 * RB_ML;
             rb_for<0, 8>([&](auto P) {
                 constexpr int p = decltype(P)::value;
+                if (pro) return;                                 // per row (see the note on basic blocks above the kernel's epilogue)
                 u4_t idr[2];
-                if (!pro) {
-                    idr[0] = *(const u4_t*)(tin + p * RB_IN_LS + ioff[0]);
-                    idr[1] = *(const u4_t*)(tin + p * RB_IN_LS + ioff[1]);
-                }
+                idr[0] = *(const u4_t*)(tin + p * RB_IN_LS + ioff[0]);
+                idr[1] = *(const u4_t*)(tin + p * RB_IN_LS + ioff[1]);
 #pragma unroll
                 for (int m2 = 0; m2 < 2; ++m2) {
                     h8_t o;
@@ -419,10 +464,10 @@ __global__ __launch_bounds__(RB_NTHREADS, 1) void resblock3x3_c64_kernel(const R
                     const h8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
                     o = __builtin_elementwise_max(o, z);
                     const u4_t ob = __builtin_bit_cast(u4_t, o);
-                    if (!pro) *(u4_t*)(mrow + p * RB_ML + soff[m2]) = ob;
+                    *(u4_t*)(mrow + p * RB_ML + soff[m2]) = ob;
                     if (p >= 6 && rh == 1) *(u4_t*)(crow + (p - 6) * RB_ML + soff[m2]) = ob;
                 }
-                if (!pro) {
+                {
 #pragma unroll
                     for (int m2 = 0; m2 < 2; ++m2) {
                         const u4_t r = idr[m2];
@@ -436,7 +481,7 @@ __global__ __launch_bounds__(RB_NTHREADS, 1) void resblock3x3_c64_kernel(const R
                     }
                 }
             });
-            if (edge) {
+            if (edge && !pro) {
                 // LDS operations of one wave complete in order: these zeros land on top of the values this lane has just written
                 const bool col_out = !((unsigned)(x0 + col_x) < (unsigned)W);
                 const u4_t zz = {0u, 0u, 0u, 0u};
@@ -446,7 +491,7 @@ __global__ __launch_bounds__(RB_NTHREADS, 1) void resblock3x3_c64_kernel(const R
                     if (row_out || col_out) {
 #pragma unroll
                         for (int m2 = 0; m2 < 2; ++m2) {
-                            if (!pro) *(u4_t*)(mrow + p * RB_ML + soff[m2]) = zz;
+                            *(u4_t*)(mrow + p * RB_ML + soff[m2]) = zz;
                             if (p >= 6 && rh == 1) *(u4_t*)(crow + (p - 6) * RB_ML + soff[m2]) = zz;
                         }
                     }
