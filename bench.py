@@ -387,18 +387,25 @@ def main():
                                                           'into a register ring, 8 accumulators per wave)' % nb,
                                                 'avg_launch_ms': round(c_ms, 4), 'TFLOPs': round(c_fl / c_ms / 1e9, 1), 'frac_mfma': round(c_fl / c_ms / 1e9 / peak, 4)}
         wb = [p for p in prof if p[1] == 'warp_fat']
-        wb_ms = sum(p[3] for p in wb) / len(wb)
+        # round 5: ONE launch covers the nb time instants (one grid slice per context): per-time-instant figures = launch / contexts
+        wb_ms = sum(p[3] for p in wb) / sum(p[5] for p in wb)
+        wb_halves = {('Ft (sources: trunk features F0 / F1, shared by the time instants of a window)' if i == 0 else
+                      'rF (sources: the refined features of this time instant, fresh from HBM)'): round(p[3] / p[5], 4)
+                     for i, p in enumerate(wb[:2])} if len(wb) == 2 else None
         esz = 2 if a.dtype == 'fp16' else 4
         # FAC + warp kernel of the north star: Ft = Eq.(2) blend of the two backward-warped trunk feature maps.  In the batched plan ONE
         # launch covers the nb time instants of a window with the contexts innermost per tile, so its algorithmic bytes are: F0 and
         # F1 once (2 C e B/px) + per time instant the output (C e) and the two flows + logit (20 B/px).  Per-t launches: 3 C e + 20.
         wb_nb = 1                                                # the fat warp runs one launch per time instant (batched it was slower: profiles/r03_notes.md)
         wb_bytes = (2 * 64 * esz + wb_nb * (64 * esz + 20)) * eng.H * eng.W
-        out['roofline_hbm'] = {'kernel': 'warp_blend_fat C=64 (bwarp x2 + Eq.2 blend), in-network flows, %d time instants per launch' % wb_nb, 'bound': 'hbm',
+        out['roofline_hbm'] = {'kernel': 'warp_blend_fat C=64 (bwarp x2 + Eq.2 blend), in-network flows; achieved / avg_launch_ms / bytes_per_launch are PER TIME INSTANT (%d per launch)' % wb[0][5], 'bound': 'hbm',
                                'achieved': round(wb_bytes / (wb_ms * 1e-3) / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                                'frac': round(wb_bytes / (wb_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                'traffic': pmc.get('warp_traffic_bytes') if pmc else None,
                                'avg_launch_ms': round(wb_ms, 4), 'bytes_per_launch': wb_bytes,
+                               'launches': len(wb), 'time_instants_per_launch': wb[0][5],
+                               'ms_per_time_instant_by_warp': wb_halves,
+                               'frac_by_warp': {k: round(wb_bytes / (v * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) for k, v in wb_halves.items()} if wb_halves else None,
                                'streaming_ceiling_note': 'tools/microbench/hbm_mix (profiles/r03_hbm_mix.txt): a plain streaming kernel with this read : write mix '
                                                          '(3 : 1) reaches 4.7 TB/s at 2 048 workgroups and 5.9 TB/s at its best grid (512, non-temporal, 4 lines in '
                                                          'flight per thread); read-only 7.1, write-only 6.6: 0.60 of 8 TB/s is above what most grids of a COPY reach',
@@ -414,6 +421,11 @@ def main():
                                                   'achieved': round(fg_bytes / (fg_ms * 1e-3) / 1e9, 1), 'frac': round(fg_bytes / (fg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                                   'traffic': next((v.get('hbm_bytes_per_launch') for k, v in (pmc or {}).get('in_network', {}).items()
                                                                    if 'fgac_gather' in k), None)}
+            # the source of this gather is cache-resident: by the PMC bytes the launch is a write stream, far below the
+            # write-only ceiling -- the honest figure beside the upper-bound one
+            tr = out['roofline_hbm']['fgac_gather']['traffic']
+            if tr:
+                out['roofline_hbm']['fgac_gather']['frac_by_pmc_traffic'] = round(tr / (fg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         cfr = [p for p in prof if p[1] == 'cfr']
         out['breakdown_ms'] = {'trunk_once_per_window': round(trunk, 2), 'per_t': round(per_t, 2),
                                'time_instants_per_launch_sequence': nb,
@@ -424,7 +436,7 @@ def main():
             with open(a.profile_ops, 'w') as f:
                 for p in prof:
                     tf = 2.0 * p[4] / (p[3] * 1e-3) / 1e12 if p[4] else 0.0
-                    f.write('%-7s %-10s %-48s %9.4f ms %8.1f TFLOP/s\n' % (p[0], p[1], p[2], p[3], tf))
+                    f.write('%-7s %-10s %-48s %9.4f ms %8.1f TFLOP/s nb=%d\n' % (p[0], p[1], p[2], p[3], tf, p[5]))
         if world == 1 and runner.tb:
             # the same K steps for a consumer of the LAST recursion's frames only (what the reference's test / test_custom write,
             # utils.py:1430-1434): the warp + D2 tail of recursions 0..N-2 feeds nothing else and is not run.  Reported beside

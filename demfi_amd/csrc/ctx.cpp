@@ -750,8 +750,14 @@ struct Builder {
         // and warp_thin 37 -> 35 us per time instant.  The fat warp and the plane packs stay one launch per context: batched they
         // were SLOWER (pack 23 -> 31 us per context; fat warp with the contexts innermost per tile 85 -> 73 / 90 us: the gathered
         // neighbourhoods of a tile do not survive in the 4 MB L2 across seven time instants with these incoherent flows).
-        const bool one_launch = kind == DEMFI_OP_CFR || (kind == DEMFI_OP_WARP && op.nch == 3);
+        // Round 5: the fat warps too, as ONE launch with one grid slice per context (demfi_batch._pad = 1): the same tiles in the same
+        // order as tb launches, without their launch gaps and tails (a launch is ~80 us; DEMFI_WARP_TB=0: one launch per context,
+        // 2: contexts innermost per tile, the round-3 form that was slower for the rF warps)
+        static const int warp_tb = getenv("DEMFI_WARP_TB") ? atoi(getenv("DEMFI_WARP_TB")) : 1;
+        const bool fat_warp = kind == DEMFI_OP_WARP && op.nch != 3 && warp_tb != 0;
+        const bool one_launch = kind == DEMFI_OP_CFR || (kind == DEMFI_OP_WARP && op.nch == 3) || fat_warp;
         if (one_launch) {
+            op.bt._pad = fat_warp && warp_tb == 1 ? 1 : 0;
             auto stride = [&](const void* p) { const int64_t cs = ctx_stride_of(p); return cs > 0 ? cs : (int64_t)0; };
             op.bt.nb = tb;
             op.bt.a = stride(op.a.ptr); op.bt.b = stride(op.b.ptr); op.bt.o = stride(op.o.ptr); op.bt.t = stride(op.t);

@@ -360,7 +360,7 @@ __device__ __forceinline__ void store16(char* p, const float* v)
 // with ONE lane per pixel, parks them in a wave-private LDS record, and then walks the pixels LPP lanes at a time
 // (16 bytes of channels per lane): broadcast LDS reads, 8 unconditional 16-byte gathers, FMA accumulation.
 // Byte strides between the per-t contexts of a batched launch (demfi_batch): context q uses pointer + q * stride.
-struct WarpBatch { int nb; int64_t a, b, o, fa, fb, logit, t, occ, pack; };
+struct WarpBatch { int nb; int outer; int64_t a, b, o, fa, fb, logit, t, occ, pack; };     // outer: context = blockIdx.y (one launch, contexts one after the other) instead of the innermost loop of a tile
 #ifndef DEMFI_WARP_MINW
 #define DEMFI_WARP_MINW 1                                        // minimum waves per SIMD the register allocation must allow (A/B builds)
 #endif
@@ -415,7 +415,8 @@ __global__ __launch_bounds__(ROWS * 64, DEMFI_WARP_MINW) void warp_blend_fat_ker
     // Batched launch (bt.nb > 1): the per-t contexts are the INNERMOST loop of the tile -- the source rows the seven time instants of
     // a window gather from are the same neighbourhood of F0 / F1 (flow_t scales with t), so after the first context they come
     // from L1 / the XCD's L2 and the features are fetched from HBM once per window instead of once per time instant.
-    for (int q = 0; q < bt.nb; ++q) {
+    const int q_lo = bt.outer ? (int)blockIdx.y : 0, q_hi = bt.outer ? (int)blockIdx.y + 1 : bt.nb;
+    for (int q = q_lo; q < q_hi; ++q) {
     demfi_view A = A0, B = B0, O = O0;
     A.ptr = bofs((char*)A0.ptr, q * bt.a); B.ptr = bofs((char*)B0.ptr, q * bt.b); O.ptr = bofs((char*)O0.ptr, q * bt.o);
     const float* __restrict__ fa = bofs(fa0, q * bt.fa);
@@ -897,8 +898,9 @@ static int warp_blend_impl(const demfi_view* A, const float* fa, const demfi_vie
 {
     if (!A || !B || !out || !A->ptr || !B->ptr || !out->ptr || !fa || !fb || !logit || !t || C <= 0 || H <= 0 || W <= 0)
         return demfi_set_error(DEMFI_ERR_ARG, "demfi_warp_blend: bad args");
-    WarpBatch wb = {1, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    WarpBatch wb = {1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (bt && bt->nb > 1) {
+        wb.outer = bt->_pad == 1 ? 1 : 0;
         if (dbg_maps) return demfi_set_error(DEMFI_ERR_ARG, "demfi_warp_blend_batched: no debug maps in a batched launch");
         wb.nb = bt->nb; wb.a = bt->a; wb.b = bt->b; wb.o = bt->o; wb.fa = bt->p[0]; wb.fb = bt->p[1]; wb.logit = bt->p[2]; wb.t = bt->t;
         wb.occ = bt->p[3]; wb.pack = bt->p[4];
@@ -924,7 +926,7 @@ static int warp_blend_impl(const demfi_view* A, const float* fa, const demfi_vie
         unsigned nblk = 8u * (unsigned)((((W + 63) / 64) * ((H + rows - 1) / rows) + 7) / 8);
         if (wgs >= 8 && (unsigned)(wgs & ~7) < nblk) nblk = (unsigned)(wgs & ~7);
 #define DEMFI_WARP_LAUNCH(TT, R, N, NL)                                                                               \
-        hipLaunchKernelGGL((warp_blend_fat_kernel<TT, R, N, NL>), dim3(nblk), dim3(R * 64), 0, st, *A, fa, *B, fb, logit, t, *out, sh, H, W, \
+        hipLaunchKernelGGL((warp_blend_fat_kernel<TT, R, N, NL>), dim3(nblk, wb.outer ? wb.nb : 1), dim3(R * 64), 0, st, *A, fa, *B, fb, logit, t, *out, sh, H, W, \
                            occ_out, dbg_maps, wb)
         if (f32) {
             if ((var & 3) == 0) DEMFI_WARP_LAUNCH(float, 4, false, false); else if ((var & 3) == 1) DEMFI_WARP_LAUNCH(float, 4, true, false);

@@ -396,7 +396,7 @@ class Engine:
         after op with an event between consecutive launches, so every kernel sees the cache state the real pipeline leaves it
         (a kernel timed in a loop of its own re-reads inputs that the 256 MB Infinity Cache kept from the previous repetition:
         warp_blend looked 25 % faster that way).  ``isolated=True`` is that per-op loop (kernel tuning only).
-        Returns a list of (segment, op kind, name, ms, macs)."""
+        Returns a list of (segment, op kind, name, ms, macs, contexts in the launch)."""
         stream = torch.cuda.current_stream(self.device)
         h = stream.cuda_stream
         if batched:                                           # the batched per-t plan: every launch covers all n_ctx contexts
@@ -433,7 +433,7 @@ class Engine:
             kind = KIND_NAME.get(op.kind, str(op.kind))
             if kind == 'warp':
                 kind = 'warp_fat' if op.nch == 64 else 'warp_thin'
-            out.append((sname, kind, op.name.decode(), t / reps, int(op.macs)))
+            out.append((sname, kind, op.name.decode(), t / reps, int(op.macs), max(1, int(op.bt.nb))))   # [5]: per-t contexts covered by a batched point-wise launch
         return out
 
     def n_launches(self, n_updates):

@@ -256,7 +256,8 @@ int demfi_warp_blend_pack(const demfi_view* A, const float* fa, const demfi_view
  * contexts are the INNERMOST loop of a tile, so F0 / F1 are fetched from HBM once per window instead of once per t. */
 typedef struct demfi_batch {
     int32_t nb;            /* contexts in the launch; 0 or 1 = a plain launch                                              */
-    int32_t _pad;
+    int32_t _pad;          /* fat warp only: 0 = the contexts are the innermost loop of a tile, 1 = one grid slice per context (the
+                              same work as nb launches without their gaps and tails; round 5)                                  */
     int64_t a, b, o;       /* byte strides of the op's A / B / out views                                                   */
     int64_t t;             /* ... of the device time instant                                                               */
     int64_t p[32];         /* ... of the op's pointer arguments, in demfi_op.p order                                       */

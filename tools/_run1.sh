@@ -1,6 +1,5 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r05b
-timeout 900 python -m pytest tests/test_gpu_kernels.py -m gpu -q -k "resblock" 2>&1 | tail -5 | tee gpurun_out/r05b/test_resblock.txt
-DEMFI_HIP_LIB=$PWD/demfi_amd/csrc/libdemfi_hip_trace.so PROBE_B=21 timeout 300 python tools/rb_trace.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r05b/rb_trace_b21.txt
-PROBE_B=21 PROBE_DATA=relu timeout 300 python tools/conv_probe.py resblock 20 2>&1 | tail -2 | tee gpurun_out/r05b/probe_b21.txt
-DEMFI_AB_ROUNDS=1 bash tools/ab_ops.sh gpurun_out/r05b/ab "DEMFI_RESBLOCK=0" "" 2>&1 | tee gpurun_out/r05b/ab.txt
+mkdir -p gpurun_out/r05c
+timeout 1200 python -m pytest tests/test_gpu_e2e.py tests/test_gpu_kernels.py -m gpu -x -q 2>&1 | tail -4 | tee gpurun_out/r05c/tests.txt
+timeout 900 python -m pytest tests/test_gpu_configs.py -m gpu -x -q -k "batched_equals_module or benched_path" 2>&1 | tail -4 | tee -a gpurun_out/r05c/tests.txt
+DEMFI_AB_ROUNDS=2 bash tools/ab_ops.sh gpurun_out/r05c/ab "DEMFI_WARP_TB=0" "DEMFI_WARP_TB=1" "DEMFI_WARP_TB=2" 2>&1 | tee gpurun_out/r05c/ab.txt

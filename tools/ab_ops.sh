@@ -20,7 +20,7 @@ try:
     for l in open(ops):
         f = l.split()
         if len(f) >= 4:
-            acc[f[2] if f[1] in ('conv', 'resblock') else f[1]].append(float(f[3]))
+            acc[f[2] if f[1] in ('conv', 'resblock') else f[1]].append(float(f[3]) / (float(f[7][3:]) if len(f) > 7 and f[1] == 'warp_fat' else 1.0))
             segsum[f[0]] += float(f[3])
 except OSError:
     pass
