@@ -14,6 +14,7 @@
 #include "common.h"
 #include <algorithm>
 #include <map>
+#include <set>
 #include <string>
 #include <stdlib.h>
 #include <string.h>
@@ -265,7 +266,12 @@ struct Tensor {
     int d[4] = {0, 0, 0, 0};   // fat: B,h,w,C; thin: C,h,w,1; raw: n,1,1,1
     int64_t bytes = 0;
     int64_t cstride = 0;       // per-t buffers: bytes between the copies of consecutive per-t contexts (tensor-major layout), 0 = trunk buffer
+    int id = 0;                // > 0: index into demfi_ctx::id_cstride; views built from the tensor carry it in demfi_view._pad while the plan is built
 };
+
+// Liveness plan of one buffer set (round 5, the workspace arena): the big activation buffers whose first access in the launch
+// sequence is a write share ONE arena; off = byte offset of the buffer's footprint inside the arena, size = arena bytes.
+struct ArenaPlan { std::map<std::string, int64_t> off; int64_t size = 0; bool on = false; };
 
 struct Weight { std::vector<float> data; std::vector<int64_t> shape; };
 
@@ -285,6 +291,8 @@ struct demfi_ctx {
     int64_t w_region = 0, w_bytes = 0, desc_off = 0, zero_off = 0, total = 0, n_descs = 0;
     std::vector<BufSet> tr_bufs;                       // [trunk]
     std::vector<std::vector<BufSet>> t_bufs;           // [trunk][c]
+    std::vector<int64_t> id_cstride;                   // tensor id -> context stride in bytes (0: trunk buffer); [0] unused
+    ArenaPlan arena_t, arena_tr;                       // liveness plans of the per-t / trunk buffer sets (empty: every buffer has its own memory)
     // after bind
     bool bound = false, on_host = false;
     char* base = nullptr;
@@ -380,26 +388,39 @@ struct Layout {
     demfi_ctx* c;
     int64_t cur;
     int rep = 0;               // > 0: per-t buffers, `rep` copies of every buffer back to back (copy q at off + q * cstride)
+    const ArenaPlan* plan = nullptr;   // buffers named in it live at arena_base + their planned offset
+    int64_t arena_base = 0;
     int64_t take(int64_t bytes) { const int64_t o = cur; cur = (cur + bytes + 255) & ~255ll; return o; }
-    void place(Tensor& t)
+    static int64_t footprint(const Tensor& t, int rep) { return rep > 0 ? ((t.bytes + 15) & ~15ll) * rep : t.bytes; }
+    void place(Tensor& t, const char* n)
     {
-        if (rep > 0) { t.cstride = (t.bytes + 15) & ~15ll; t.off = take(t.cstride * rep); }
-        else t.off = take(t.bytes);
+        if (rep > 0) t.cstride = (t.bytes + 15) & ~15ll;
+        const int64_t fp = footprint(t, rep);
+        auto it = plan && plan->on ? plan->off.find(n) : std::map<std::string, int64_t>::const_iterator();
+        if (plan && plan->on && it != plan->off.end()) t.off = arena_base + it->second;
+        else t.off = take(fp);
+        t.id = (int)c->id_cstride.size();
+        c->id_cstride.push_back(t.cstride);
+    }
+    void begin_set(const ArenaPlan* pl)
+    {
+        plan = pl;
+        if (pl && pl->on) arena_base = take(pl->size);
     }
     void fat(BufSet& s, const char* n, int h, int w, int ch, int b = 1)
     {
         Tensor t; t.kind = 0; t.d[0] = b; t.d[1] = h; t.d[2] = w; t.d[3] = ch;
-        t.bytes = (int64_t)b * h * w * ch * esz_of(c); place(t); s[n] = t;
+        t.bytes = (int64_t)b * h * w * ch * esz_of(c); place(t, n); s[n] = t;
     }
     void thin(BufSet& s, const char* n, int ch, int h, int w)
     {
         Tensor t; t.kind = 1; t.d[0] = ch; t.d[1] = h; t.d[2] = w; t.d[3] = 1;
-        t.bytes = (int64_t)ch * h * w * 4; place(t); s[n] = t;
+        t.bytes = (int64_t)ch * h * w * 4; place(t, n); s[n] = t;
     }
     void raw(BufSet& s, const char* n, int64_t bytes)
     {
         Tensor t; t.kind = 2; t.d[0] = (int)(bytes / 8); t.d[1] = t.d[2] = t.d[3] = 1;
-        t.bytes = bytes; place(t); s[n] = t;
+        t.bytes = bytes; place(t, n); s[n] = t;
     }
 };
 
@@ -499,13 +520,17 @@ void compute_layout(demfi_ctx* c, int64_t w_bytes, int64_t n_descs)
     c->desc_off = L.take(n_descs * (int64_t)sizeof(demfi_conv));
     c->tr_bufs.assign(c->n_trunk, BufSet());
     c->t_bufs.assign(c->n_trunk, std::vector<BufSet>(c->n_ctx));
+    c->id_cstride.assign(1, 0);
     for (int k = 0; k < c->n_trunk; ++k) {
+        L.begin_set(&c->arena_tr);
         alloc_trunk(L, c->tr_bufs[k]);
         // tensor-major: the n_ctx copies of a per-t buffer are contiguous, so a convolution over "batch x n_ctx" addresses
         // all of them with one batch stride (demfi_forward_tb)
         L.rep = c->n_ctx;
+        L.begin_set(&c->arena_t);
         alloc_t(L, c->t_bufs[k][0]);
         L.rep = 0;
+        L.begin_set(nullptr);
         for (int q = 1; q < c->n_ctx; ++q) {
             c->t_bufs[k][q] = c->t_bufs[k][0];
             for (auto& kv : c->t_bufs[k][q]) kv.second.off += q * kv.second.cstride;
@@ -551,11 +576,19 @@ struct Builder {
             if (off >= kv.second.off && off < kv.second.off + kv.second.bytes) return 0;
         return -1;
     }
+    // context stride of a view: by the id of the tensor it was built from (buffers of the arena share addresses, so an address does
+    // not name a buffer any more); raw pointers (thin planes: never in the arena) by address
+    int64_t view_stride(const demfi_view& v) const
+    {
+        if (v._pad > 0 && v._pad < (int)c->id_cstride.size()) return c->id_cstride[v._pad];
+        return ctx_stride_of(v.ptr);
+    }
     // view of a convolution of the batched plan: the conv runs with batch nb * tb, image index = q * nb + f
     bool tb_view(demfi_view& v, int nb, const char* name)
     {
         if (!v.ptr) return true;
-        const int64_t cs = ctx_stride_of(v.ptr), elt = v.is_f32 ? 4 : 2;
+        const int64_t cs = view_stride(v), elt = v.is_f32 ? 4 : 2;
+        v._pad = 0;
         if (cs < 0) { status = demfi_set_error(DEMFI_ERR_ARG, "%s: view outside the context's buffers in the batched plan", name); return false; }
         if (cs == 0) {                                           // trunk buffer: the same image for every context
             if (nb != 1 && v.sb != 0) { status = demfi_set_error(DEMFI_ERR_ARG, "%s: batched trunk view in a batch-%d layer", name, nb); return false; }
@@ -583,7 +616,7 @@ struct Builder {
         if (nch < 0) nch = Ct - c0;
         Src s;
         s.v = {ptr(t) + ((int64_t)c0 + (b < 0 ? 0 : (int64_t)b * h * w * Ct)) * esz, Ct, (int64_t)w * Ct, 1,
-               b < 0 ? (int64_t)h * w * Ct : 0, f32 ? 1 : 0, 0};
+               b < 0 ? (int64_t)h * w * Ct : 0, f32 ? 1 : 0, t.id};
         s.fat = 1; s.up = up; s.cin = range(cin0, cin0 + nch);
         return s;
     }
@@ -592,7 +625,7 @@ struct Builder {
     {
         const int h = t.d[1], w = t.d[2], Ct = t.d[3];
         Src s;
-        s.v = {ptr(t) + (int64_t)b * h * w * Ct * esz, Ct, (int64_t)w * Ct, 1, 0, f32 ? 1 : 0, 0};
+        s.v = {ptr(t) + (int64_t)b * h * w * Ct * esz, Ct, (int64_t)w * Ct, 1, 0, f32 ? 1 : 0, t.id};
         s.fat = 1; s.up = 0; s.cin = cin;
         return s;
     }
@@ -600,12 +633,12 @@ struct Builder {
     {
         const int h = t.d[1], w = t.d[2], Ct = t.d[3];
         return {ptr(t) + ((int64_t)c0 + (b < 0 ? 0 : (int64_t)b * h * w * Ct)) * esz, Ct, (int64_t)w * Ct, 1,
-                b < 0 ? (int64_t)h * w * Ct : 0, f32 ? 1 : 0, 0};
+                b < 0 ? (int64_t)h * w * Ct : 0, f32 ? 1 : 0, t.id};
     }
     demfi_view tview(const Tensor& t, int c0 = 0, int64_t sb = 0) const
     {
         const int h = t.d[1], w = t.d[2];
-        return {ptr(t) + (int64_t)c0 * h * w * 4, 1, w, (int64_t)h * w, sb, 1, 0};
+        return {ptr(t) + (int64_t)c0 * h * w * 4, 1, w, (int64_t)h * w, sb, 1, t.id};
     }
     const float* plane(const Tensor& t, int ch) const { return (const float*)(ptr(t) + (int64_t)ch * t.d[1] * t.d[2] * 4); }
     static Dst D(demfi_view v, std::vector<int32_t> couts, int act = DEMFI_ACT_NONE, int mode = DEMFI_MODE_STORE,
@@ -665,6 +698,9 @@ struct Builder {
             for (auto& x : cd) if (!tb_view(x.dst, batch, name.c_str()) || !tb_view(x.res, batch, name.c_str()) || !tb_view(x.aux, batch, name.c_str())) return;
             batch *= tb;
         }
+        pack_v._pad = 0;                                         // the tensor ids are the builder's business, not the descriptors'
+        for (auto& x : cs) x.v._pad = 0;
+        for (auto& x : cd) x.dst._pad = x.res._pad = x.aux._pad = 0;
         // the packed blob of a call site depends on its channel maps only (not on buffer addresses): per-t contexts and
         // the two FGAC directions share one copy
         std::string sig = name + "|";
@@ -743,6 +779,8 @@ struct Builder {
     {
         op.kind = kind;
         strncpy(op.name, name, sizeof(op.name) - 1);
+        const int64_t cs_a = op.a.ptr ? view_stride(op.a) : -1, cs_b = op.b.ptr ? view_stride(op.b) : -1, cs_o = op.o.ptr ? view_stride(op.o) : -1;
+        op.a._pad = op.b._pad = op.o._pad = 0;
         if (tb <= 1) { seg.push_back(op); return; }
         // batched plan.  CFR and the thin (3-channel) warps: ONE launch for all tb per-t contexts (ABI v5, demfi_batch): the pointers
         // are those of context 0, every pointer gets the byte stride of the buffer it lies in (per-t buffers: their context stride;
@@ -760,16 +798,16 @@ struct Builder {
             op.bt._pad = fat_warp && warp_tb == 1 ? 1 : 0;
             auto stride = [&](const void* p) { const int64_t cs = ctx_stride_of(p); return cs > 0 ? cs : (int64_t)0; };
             op.bt.nb = tb;
-            op.bt.a = stride(op.a.ptr); op.bt.b = stride(op.b.ptr); op.bt.o = stride(op.o.ptr); op.bt.t = stride(op.t);
+            op.bt.a = cs_a > 0 ? cs_a : 0; op.bt.b = cs_b > 0 ? cs_b : 0; op.bt.o = cs_o > 0 ? cs_o : 0; op.bt.t = stride(op.t);
             for (int i = 0; i < 32; ++i) op.bt.p[i] = stride(op.p[i]);
             seg.push_back(op);
             return;
         }
         for (int q = 0; q < tb; ++q) {                          // one launch per context, pointers rebased
             demfi_op o = op;
-            o.a.ptr = (void*)tb_ptr(op.a.ptr, q);
-            o.b.ptr = (void*)tb_ptr(op.b.ptr, q);
-            o.o.ptr = (void*)tb_ptr(op.o.ptr, q);
+            if (op.a.ptr && cs_a > 0) o.a.ptr = (char*)op.a.ptr + q * cs_a;
+            if (op.b.ptr && cs_b > 0) o.b.ptr = (char*)op.b.ptr + q * cs_b;
+            if (op.o.ptr && cs_o > 0) o.o.ptr = (char*)op.o.ptr + q * cs_o;
             for (int i = 0; i < 32; ++i) o.p[i] = tb_ptr(op.p[i], q);
             o.t = tb_ptr(op.t, q);
             seg.push_back(o);
@@ -1247,6 +1285,143 @@ int run_builder(demfi_ctx* c, bool dry)
     return b.status;
 }
 
+// ---- workspace arena (round 5) -----------------------------------------------------------------------------------
+// Every pointer an op reads / writes (write = true).  The scratch buffer between the two convolutions of a fused residual block is
+// not touched by the fused launch.
+void op_accesses(const demfi_ctx* c, const demfi_op& op, std::vector<std::pair<const void*, bool>>& out)
+{
+    auto rd = [&](const void* p) { if (p) out.push_back({p, false}); };
+    auto wr = [&](const void* p) { if (p) out.push_back({p, true}); };
+    auto conv_in = [&](const demfi_conv& d) { for (int i = 0; i < d.n_pieces; ++i) rd(d.pieces[i].v.ptr); };
+    auto conv_out = [&](const demfi_conv& d) {
+        for (int i = 0; i < d.n_segs; ++i) { rd(d.segs[i].res.ptr); rd(d.segs[i].aux.ptr); wr(d.segs[i].dst.ptr); }
+        wr(d.pack.ptr);
+    };
+    switch (op.kind) {
+    case DEMFI_OP_CONV: conv_in(c->descs[op.conv]); conv_out(c->descs[op.conv]); break;
+    case DEMFI_OP_RESBLOCK: conv_in(c->descs[op.conv]); conv_out(c->descs[op.nch]); break;
+    case DEMFI_OP_PACK: for (int i = 0; i < 32; ++i) rd(op.p[i]); wr(op.o.ptr); break;
+    case DEMFI_OP_S2D: case DEMFI_OP_OVERLAY: rd(op.p[0]); wr(op.p[1]); break;
+    case DEMFI_OP_FGAC: rd(op.a.ptr); rd(op.p[0]); wr(op.o.ptr); break;
+    case DEMFI_OP_FGAC_WINDOW: rd(op.a.ptr); rd(op.b.ptr); rd(op.p[0]); wr(op.o.ptr); break;
+    case DEMFI_OP_AVG_POOL: rd(op.a.ptr); wr(op.o.ptr); break;
+    case DEMFI_OP_GATE: rd(op.p[0]); rd(op.a.ptr); rd(op.b.ptr); wr(op.o.ptr); break;
+    case DEMFI_OP_CFR: rd(op.p[0]); rd(op.p[1]); rd(op.p[2]); wr(op.p[2]); wr(op.p[3]); rd(op.t); break;
+    case DEMFI_OP_WARP: rd(op.a.ptr); rd(op.b.ptr); rd(op.p[0]); rd(op.p[1]); rd(op.p[2]); rd(op.t); wr(op.o.ptr); wr(op.p[3]); wr(op.p[4]); break;
+    default: break;
+    }
+}
+
+// Liveness plan of one buffer set from its launch sequence (built on the UNALIASED layout of the sizing pass, where an address
+// names one buffer).  Candidates: the buffers in `allow` whose first access is a write by an op of `seq` and which no op of
+// `foreign` (another segment) touches; a candidate lives from its first to its last access (buffers that carry state from one
+// recursion to the next are accessed in several: their interval spans them).  Everything else keeps memory of its own: inputs,
+// outputs the host reads, buffers that rely on the zero-filled workspace (the CFR accumulator, zero-padded records).  Footprints
+// (all n_ctx copies of a buffer: the tensor-major layout stays) are packed first-fit, largest first.
+// does op (re)write EVERY element of tensor t (all images, all channels)?  Then whatever t held before is dead: its live range
+// may end at the previous access and a new one starts here (per-recursion scratch is alive only inside each recursion).
+bool op_overwrites(const demfi_ctx* c, const demfi_op& op, const Tensor& t, int64_t t_addr)
+{
+    if (t.kind != 0) return false;
+    auto conv_full = [&](const demfi_conv& d) {
+        if (d.H != t.d[1] || d.W != t.d[2] || d.batch != t.d[0]) return false;
+        for (int sg = 0; sg < d.n_segs; ++sg) {
+            const demfi_seg& g = d.segs[sg];
+            if ((int64_t)(intptr_t)g.dst.ptr != t_addr || g.mode != DEMFI_MODE_STORE && g.mode != DEMFI_MODE_MUL && g.mode != DEMFI_MODE_GRU) continue;
+            if (g.scale != 1 || g.dst.sc != 1 || g.dst.sx != t.d[3]) continue;
+            int n = 0;
+            for (int o = 0; o < d.cout_pad / 8; ++o) if (d.oct_seg[o] == sg) n += d.oct_n[o];
+            if (n == t.d[3]) return true;
+        }
+        return false;
+    };
+    if (op.kind == DEMFI_OP_CONV) return conv_full(c->descs[op.conv]);
+    if (op.kind == DEMFI_OP_RESBLOCK) return conv_full(c->descs[op.nch]);
+    if (op.kind == DEMFI_OP_PACK) return (int64_t)(intptr_t)op.o.ptr == t_addr && op.nch == t.d[3] && t.d[0] == 1;
+    return false;
+}
+
+ArenaPlan plan_arena(const demfi_ctx* c, const BufSet& set, int rep, const std::vector<const OpList*>& seq,
+                     const std::vector<const OpList*>& foreign, const std::vector<std::string>& allow)
+{
+    struct Iv { std::string name; int64_t size; std::vector<std::pair<int, int>> live; bool ok = true; int64_t off = -1; };
+    std::vector<Iv> iv;
+    const char* only = getenv("DEMFI_ARENA_ONLY");              // debugging: restrict the arena to the named buffers ("a,b,c")
+    for (const auto& n : allow) {
+        if (only && (std::string(",") + only + ",").find("," + n + ",") == std::string::npos) continue;
+        auto it = set.find(n);
+        if (it != set.end()) iv.push_back({n, (Layout::footprint(it->second, rep) + 255) & ~255ll});
+    }
+    auto find = [&](const void* p) -> Iv* {
+        const int64_t a = (int64_t)(intptr_t)p;                  // sizing pass: base == nullptr, pointers are offsets
+        for (auto& x : iv) {
+            const Tensor& t = set.find(x.name)->second;
+            if (a >= t.off && a < t.off + t.bytes) return &x;
+        }
+        return nullptr;
+    };
+    std::vector<std::pair<const void*, bool>> acc;
+    int idx = 0;
+    for (const OpList* ops : seq)
+        for (const demfi_op& op : *ops) {
+            acc.clear();
+            op_accesses(c, op, acc);
+            for (int pass = 0; pass < 2; ++pass)                 // an op's reads come before its writes
+                for (auto& a : acc) {
+                    if ((int)a.second != pass) continue;
+                    Iv* x = find(a.first);
+                    if (!x) continue;
+                    const Tensor& t = set.find(x->name)->second;
+                    if (x->live.empty()) {
+                        if (!a.second) x->ok = false;             // read before any write: it relies on what the workspace held
+                        x->live.push_back({idx, idx});
+                    } else if (a.second && x->live.back().second < idx && op_overwrites(c, op, t, t.off)) {
+                        x->live.push_back({idx, idx});            // everything it held is replaced: a new live range
+                    } else x->live.back().second = idx;
+                }
+            ++idx;
+        }
+    for (const OpList* ops : foreign)
+        for (const demfi_op& op : *ops) {
+            acc.clear();
+            op_accesses(c, op, acc);
+            for (auto& a : acc) if (Iv* x = find(a.first)) x->ok = false;
+        }
+    ArenaPlan pl;
+    std::vector<Iv*> todo;
+    for (auto& x : iv) {
+        if (x.live.empty()) { pl.off[x.name] = 0; continue; }    // never touched (the scratch of fused residual blocks): no memory
+        if (x.ok) todo.push_back(&x);
+    }
+    std::sort(todo.begin(), todo.end(), [](const Iv* a, const Iv* b) { return a->size != b->size ? a->size > b->size : a->live[0].first < b->live[0].first; });
+    auto together = [](const Iv* a, const Iv* b) {
+        for (auto& p : a->live) for (auto& q : b->live) if (!(p.second < q.first || q.second < p.first)) return true;
+        return false;
+    };
+    std::vector<Iv*> placed;
+    for (Iv* x : todo) {
+        std::vector<std::pair<int64_t, int64_t>> busy;           // address ranges of placed buffers alive at the same time
+        for (Iv* y : placed) if (together(x, y)) busy.push_back({y->off, y->off + y->size});
+        std::sort(busy.begin(), busy.end());
+        int64_t o = 0;
+        for (auto& b : busy) { if (o + x->size <= b.first) break; o = std::max(o, b.second); }
+        x->off = o;
+        placed.push_back(x);
+        pl.off[x->name] = o;
+        pl.size = std::max(pl.size, o + x->size);
+    }
+    if (getenv("DEMFI_ARENA_DEBUG"))
+        for (auto& x : iv) {
+            fprintf(stderr, "   %-8s ok=%d off=%8.1f MB size=%7.1f MB live", x.name.c_str(), (int)x.ok, x.off / 1e6, x.size / 1e6);
+            for (auto& p : x.live) fprintf(stderr, " [%d,%d]", p.first, p.second);
+            fprintf(stderr, "\n");
+        }
+    pl.size = std::max<int64_t>(pl.size, 256);                   // never-touched members point at the arena's first bytes
+    pl.on = !placed.empty();
+    if (!pl.on) pl.off.clear();
+    return pl;
+}
+
 int run_ops(demfi_ctx* c, const OpList& ops, void* stream)
 {
     for (const demfi_op& op : ops) {
@@ -1316,6 +1491,29 @@ extern "C" int demfi_ctx_create(int H, int W, int max_updates, int dtype, const 
     compute_layout(c, 0, 0);
     int st = run_builder(c, true);
     if (st < 0) { delete c; return st; }
+    // the workspace arena: buffers of a set that are never alive together share memory (DEMFI_ARENA=0: one region per buffer,
+    // the layout of rounds 1-4; results are bit-identical either way)
+    static const bool arena_on = !(getenv("DEMFI_ARENA") && atoi(getenv("DEMFI_ARENA")) == 0);
+    if (arena_on) {
+        std::vector<const OpList*> per_t = {&c->head_ops[0][0]}, tr = {&c->tr_ops[0]}, none;
+        for (int it = 0; it < c->N; ++it) per_t.push_back(&c->iter_ops[0][0][it]);
+        std::vector<const OpList*> per_t_all = per_t;
+        if (c->n_ctx > 1) { per_t_all.push_back(&c->tb_head_ops[0]); for (int it = 0; it < c->N; ++it) per_t_all.push_back(&c->tb_iter_ops[0][it]); }
+        const ArenaPlan pt = plan_arena(c, c->t_bufs[0][0], c->n_ctx, per_t, none,
+                                        {"Ft", "u1", "u2", "u3", "d0", "d1", "d2", "rF", "dec_a", "dec_t", "dec_b", "frec0", "frec1", "re1", "rd64", "de1",
+                                         "bl1", "xb", "zb", "rh", "h1", "fo1", "g_a", "g_t", "g_b", "g_p2", "misc16", "ref16", "agg16", "ref32", "agg3s"});
+        const ArenaPlan ptr_ = plan_arena(c, c->tr_bufs[0], 0, tr, per_t_all,
+                                          {"s2d", "f1", "x0", "grow", "gffcat", "g0", "g1", "up", "enc_a", "enc_t", "enc_b", "rk", "skk", "rkp", "skp",
+                                           "smp", "E", "wg"});
+        c->arena_t = pt;
+        c->arena_tr = ptr_;
+        if (getenv("DEMFI_ARENA_DEBUG")) {
+            for (auto* pl : {&c->arena_t, &c->arena_tr}) {
+                fprintf(stderr, "arena %s: %.1f MB\n", pl == &c->arena_t ? "per-t (all contexts)" : "trunk", pl->size / 1e6);
+                for (auto& kv : pl->off) fprintf(stderr, "   %-8s at %.1f MB\n", kv.first.c_str(), kv.second / 1e6);
+            }
+        }
+    }
     compute_layout(c, c->blob_fill, (int64_t)c->descs.size());
     c->descs.clear();
     *out = c;

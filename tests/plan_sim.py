@@ -186,9 +186,23 @@ class PlanSim:
             k = op.kind
             if k == 0:
                 self.conv(e.conv_desc(op.conv))
-            elif k == 10:                                                  # fused residual block == its two convolutions in turn
-                self.conv(e.conv_desc(op.conv))
-                self.conv(e.conv_desc(op.nch))
+            elif k == 10:
+                # fused residual block == its two convolutions in turn, with the intermediate in PRIVATE memory: the fused kernel
+                # keeps it in LDS and never touches the plan's scratch buffer, whose memory the workspace arena (round 5) may have
+                # handed to a buffer that is alive right now
+                d1 = L.Conv.from_buffer_copy(bytes(e.conv_desc(op.conv)))
+                d2 = L.Conv.from_buffer_copy(bytes(e.conv_desc(op.nch)))
+                sg = d1.segs[d1.sub_seg[0]]
+                assert d2.pieces[0].v.ptr == sg.dst.ptr and sg.dst.sx == 64 and sg.dst.sy == d1.W * 64
+                tmp = torch.zeros(d1.batch * d1.H * d1.W * 64 + 64, dtype=torch.float32 if d1.dtype == L.F32 else torch.float16)
+                self.reg.append((tmp.data_ptr(), tmp.numel() * tmp.element_size(), tmp))
+                sg.dst.ptr = tmp.data_ptr()
+                sg.dst.sb = d1.H * d1.W * 64
+                d2.pieces[0].v.ptr = tmp.data_ptr()
+                d2.pieces[0].v.sb = d1.H * d1.W * 64
+                self.conv(d1)
+                self.conv(d2)
+                self.reg.pop()
             elif k == 1:                                                   # pack planar fp32 planes -> NHWC slice
                 dst = self.strided(op.o, op.nch, H, W)
                 for c in range(op.nch):

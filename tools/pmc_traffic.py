@@ -39,7 +39,7 @@ def run(case, outdir, env=None):
                 acc[k][r['Counter_Name']] += float(r['Counter_Value'])
                 disp[k].add(r['Dispatch_Id'])
             for k, v in acc.items():
-                if 'persist' in k or 'c64_stg' in k or 'warp_blend_fat' in k or 'cfr_' in k:
+                if 'persist' in k or 'c64_stg' in k or 'warp_blend_fat' in k or 'cfr_' in k or 'resblock3x3' in k:
                     n = len(disp[k])
                     res.setdefault(k, {}).update({c: x / n for c, x in v.items()})
                     res[k]['dispatches'] = n
@@ -120,6 +120,19 @@ def main():
         out['dominant_algorithmic_bytes_b21'] = 7 * (723.5e6 + 1085.2e6) / 2
         out['dominant_mfma_busy_frac_b21'] = cb[0].get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / max(1.0, cb[0].get('GRBM_GUI_ACTIVE', 1) * 128)
         out['dominant_clock_GHz_b21'] = cb[0].get('GRBM_GUI_ACTIVE', 0) / 8 / max(1e-9, cb[0].get('avg_us', {}).get('fetch', 0) * 1e3)
+    # round 5: the fused residual block (conv1 -> ReLU -> conv2 + identity in one launch) at batch 21: what the D1 blocks of the
+    # batched plan launch.  Algorithmic bytes: input + output only.
+    rb = run('resblock', os.path.join(outdir, 'rb21'), {'PROBE_DATA': 'relu', 'PROBE_B': '21'})
+    summary['resblock_b21'] = rb
+    rbk = [v for k, v in rb.items() if 'resblock3x3' in k]
+    if rbk:
+        out['resblock_traffic_bytes_b21'] = hbm(rbk[0])
+        out['resblock_algorithmic_bytes_b21'] = 2.0 * 736 * 1280 * 64 * 2 * 21
+        out['resblock_mfma_busy_frac_b21'] = rbk[0].get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / max(1.0, rbk[0].get('GRBM_GUI_ACTIVE', 1) * 128)
+        out['resblock_clock_GHz_b21'] = rbk[0].get('GRBM_GUI_ACTIVE', 0) / 8 / max(1e-9, rbk[0].get('avg_us', {}).get('fetch', 0) * 1e3)
+        pair = [v for k, v in rb.items() if 'c64_stg' in k]
+        if pair:
+            out['two_launch_pair_traffic_bytes_b21'] = sum(hbm(v) for v in pair)      # conv1 (no residual) + conv2 (residual) instantiations
     if warp:
         out['warp_traffic_bytes'] = hbm(warp[0])
     innet = run_bench_pmc(outdir)
@@ -128,7 +141,7 @@ def main():
     if wk:
         out['warp_traffic_bytes_probe_white_noise'] = out.get('warp_traffic_bytes')
         out['warp_traffic_bytes'] = wk[0]['hbm_bytes_per_launch']             # the network's own flows, in sequence
-    json.dump(out, open(os.path.join(outdir, (sys.argv[2] if len(sys.argv) > 2 else 'r04') + '_pmc_traffic.json'), 'w'), indent=1)
+    json.dump(out, open(os.path.join(outdir, (sys.argv[2] if len(sys.argv) > 2 else 'r05') + '_pmc_traffic.json'), 'w'), indent=1)
     print(json.dumps({k: v for k, v in out.items() if k not in ('raw', 'in_network')}, indent=1))
     for k, v in sorted(innet.items(), key=lambda kv: -kv[1]['hbm_bytes_per_launch'])[:14]:
         print('%-52s %8.1f MB/launch  L2 hit %.2f  (%d launches)' % (k[:52], v['hbm_bytes_per_launch'] / 1e6, v['l2_hit'], v['dispatches']))
