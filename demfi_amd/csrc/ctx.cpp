@@ -793,7 +793,8 @@ struct Builder {
         // 2: contexts innermost per tile, the round-3 form that was slower for the rF warps)
         static const int warp_tb = getenv("DEMFI_WARP_TB") ? atoi(getenv("DEMFI_WARP_TB")) : 1;
         const bool fat_warp = kind == DEMFI_OP_WARP && op.nch != 3 && warp_tb != 0;
-        const bool one_launch = kind == DEMFI_OP_CFR || (kind == DEMFI_OP_WARP && op.nch == 3) || fat_warp;
+        static const int pack_tb = getenv("DEMFI_PACK_TB") ? atoi(getenv("DEMFI_PACK_TB")) : 1;   // plane packs as one launch, grid.y = context (22 -> 4 launches per window: -0.1 ms; 0 = one launch per context)
+        const bool one_launch = kind == DEMFI_OP_CFR || (kind == DEMFI_OP_WARP && op.nch == 3) || fat_warp || (kind == DEMFI_OP_PACK && pack_tb);
         if (one_launch) {
             op.bt._pad = fat_warp && warp_tb == 1 ? 1 : 0;
             auto stride = [&](const void* p) { const int64_t cs = ctx_stride_of(p); return cs > 0 ? cs : (int64_t)0; };

@@ -375,3 +375,43 @@ def test_single_call_operator_plans_interpreted_on_the_cpu(synthetic_sd):
     assert (w - w_want).abs().max() < 1e-5
     out = w * src + (1 - w) * bufs['e_s'].permute(0, 3, 1, 2)                                             # the gate kernel's role
     assert (out - want).abs().max() < 1e-5
+
+
+def _plan_digest(env):
+    """finals / delta of a CPU-interpreted fp16 forward + workspace sizes, in a fresh process (the layout switches are read once)."""
+    import json
+    import subprocess
+    code = (
+        "import hashlib, json, torch\n"
+        "from demfi_amd import _lib as L\n"
+        "from demfi_amd.engine import Engine\n"
+        "from demfi_amd.weights import synthetic_state_dict, synthetic_window\n"
+        "from tests.plan_sim import PlanSim\n"
+        "eng = Engine(synthetic_state_dict(0), 32, 64, torch.float16, 'cpu', max_updates=2, n_ctx=2)\n"
+        "sim = PlanSim(eng)\n"
+        "sim.forward_tb(synthetic_window(32, 64, 4), [0.25, 0.75], 2)\n"
+        "h = hashlib.sha256()\n"
+        "for c in range(2):\n"
+        "    for k in ('finals', 'delta', 'occ', 'sharp1'):\n"
+        "        h.update(eng._ctxs[0][c][k].contiguous().numpy().tobytes())\n"
+        "lib = L.load()\n"
+        "print(json.dumps({'digest': h.hexdigest(), 'ws_small': int(eng.workspace.numel()),\n"
+        "                  'ws_720p': int(lib.demfi_workspace_bytes(736, 1280, 3, L.F16, 3, 7)),\n"
+        "                  'ws_1080p': int(lib.demfi_workspace_bytes(1088, 1920, 3, L.F16, 3, 5))}))\n")
+    e = dict(os.environ)
+    e.update(env)
+    r = subprocess.run([sys.executable, '-c', code], cwd=ROOT, env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+def test_workspace_arena_shrinks_the_workspace_and_changes_no_result():
+    """the per-t / trunk buffers are planned by liveness (ctx.cpp, plan_arena): the headline configuration needs
+    <= 45 GB instead of 87.5 GB, config 5 (1080p x16) fits three trunk sets under the half-of-HBM rule, and the launch plan computes
+    bit-identical results whether buffers share memory or not (batched per-t plan, fp16, two recursions, interpreted on the CPU --
+    recycled memory holds the previous tenant's values there exactly as on the GPU)."""
+    on, off = _plan_digest({'DEMFI_ARENA': '1'}), _plan_digest({'DEMFI_ARENA': '0'})
+    assert on['digest'] == off['digest']
+    assert on['ws_small'] < 0.7 * off['ws_small']
+    assert on['ws_720p'] <= 45e9 < 80e9 < off['ws_720p']
+    assert on['ws_1080p'] <= 144e9 * 0.5 < off['ws_1080p']
