@@ -238,9 +238,11 @@ def test_batched_per_t_plan_equals_per_context_plans(synthetic_sd, dtype):
     # pointers of context 0 + one byte stride per pointer, 0 for window-level buffers); fat warp and plane packs NC launches
     from demfi_amd.engine import SEG_HEAD, SEG_TB_HEAD, SEG_TB_ITER
     one, tb = eng.ops(SEG_HEAD), eng.ops(SEG_TB_HEAD)
-    # convolutions, fused residual blocks, CFR and (round 5) the fat warps: ONE launch each for all contexts; plane packs NC launches
-    n_single = sum(1 for o in one if o.kind in (0, 6, 10) or (o.kind == 7 and o.nch != 3))
-    assert len(tb) == n_single + NC * (len(one) - n_single)
+    # convolutions, fused residual blocks, CFR, the thin warps and (round 5) the fat warps and the plane packs: ONE launch each for
+    # all contexts -- the batched per-t sequence has exactly the launches of ONE context's sequence
+    assert len(tb) == len(one)
+    packs = [o for o in tb if o.kind == 1]
+    assert packs and all(o.bt.nb == NC and o.bt.o > 0 for o in packs)
     fat = [o for o in tb if o.kind == 7 and o.nch != 3]
     assert len(fat) == 2 and all(o.bt.nb == NC and o.bt._pad == 1 and o.bt.o > 0 for o in fat)      # one grid slice per context
     assert fat[0].bt.a == 0 and fat[1].bt.a > 0           # Ft warps the window's trunk features (shared), rF this context's refined ones
