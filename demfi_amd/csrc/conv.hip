@@ -2603,39 +2603,48 @@ static int launch_sep(const demfi_conv* h, const demfi_conv* dev, hipStream_t st
 //     One raw s_barrier per unit (784 MFMAs = 25 000 matrix-pipe cycles per wave).
 //   => per step: 8 MFMAs, 1-2 ds_read_b128, 1 global_load_dwordx4.
 // ======================================================================================================
-constexpr int WS_TH = 16;
+// Round 5: the same kernel instantiated for the RDB growth convolutions of FF_RDB (3x3, 96 + 32 k -> 32 channels at half resolution,
+// DeMFInet.py:266-281: 48 launches per window that the general kernel ran at 0.12-0.16 of the matrix peak, per-tile-bound on its
+// gather + nine per-tap barriers): NCH = 1 cout half, the four waves are four row groups of a 32 x 32-pixel tile (eight accumulators
+// each, so still one A load per 8 MFMAs), units of 32 channels may come from pieces with different strides (the block input and the
+// 128-channel growth buffer), 34 x 34 records per unit with no line padding (two units = 146 KiB of LDS), two DMA instructions per
+// step (19 per wave and unit against 18 steps).
 #ifndef DEMFI_WS_NW
 #define DEMFI_WS_NW 4                                            // waves of the streamed-weight kernel's workgroup: 4 (one per SIMD) or 8
 #endif
-template <int KS, int NW> struct WsCfg {
-    static constexpr int RPW = WS_TH / (NW / 2);                 // output rows (32x32 accumulators) per wave
+template <int KS, int NW, int NCH = 2, int TH_ = 16> struct WsCfg {
+    static constexpr int TH = TH_;                               // output rows of a tile
+    static constexpr int RPW = TH / (NW / NCH);                  // output rows (32x32 accumulators) per wave
     static constexpr int BL = KS + RPW - 1;                      // input lines of a wave's rolling B window
-    static constexpr int LH = WS_TH + KS - 1;                    // input lines of a tile
-    static constexpr int LL = (TW + KS - 1 + 7) & ~7;            // records per line (TW + KS - 1 used)
-    static constexpr int NI = LH * LL / 16;                      // DMA instructions per unit (16 records x 64 B each)
+    static constexpr int LH = TH + KS - 1;                       // input lines of a tile
+    static constexpr int LL = KS == 7 ? ((TW + KS - 1 + 7) & ~7) : TW + KS - 1;   // records per line (TW + KS - 1 used)
+    static constexpr int NI = (LH * LL + 15) / 16;               // DMA instructions per unit (16 records x 64 B each)
     static constexpr int UNIT_BYTES = NI * 1024;
     static constexpr int LDS_BYTES = 2 * UNIT_BYTES;
     static constexpr int NG = 2 * KS;                            // (kx, k-step) groups per unit
     static constexpr int NSTEP = NG * KS;
     static constexpr int DEPTH = NW == 8 ? KS : 2 * KS;          // A prefetch distance in steps (8 waves: 256 registers per wave)
     static constexpr int NIW = (NI + NW - 1) / NW;               // DMA instructions per wave (the last one may not exist)
-    static constexpr int DMA_EVERY = 6;                          // one DMA instruction every so many steps
-    static_assert(LH * LL % 16 == 0, "unit buffer must be a whole number of DMA instructions");
-    static_assert(NIW * DMA_EVERY + DEPTH <= NSTEP, "the unit's DMA must be older than the last A fragment consumed in the unit");
+    static constexpr int DMA_EVERY = KS == 7 ? 6 : 1;            // DMA instructions are issued every so many steps ...
+    static constexpr int DMA_PER = KS == 7 ? 1 : 2;              // ... so many at a time
+    static constexpr bool PIECE_STRIDES = KS != 7;               // units may come from pieces with different strides
+    static_assert(LDS_BYTES <= 160 * 1024, "two units must fit LDS");
+    static_assert((NIW + DMA_PER - 1) / DMA_PER * DMA_EVERY + DEPTH <= NSTEP, "the unit's DMA must be older than the last A fragment consumed in the unit");
     static_assert(NSTEP % DEPTH == 0, "static ring indices");
 };
 
-template <int KS, int NW>
+template <int KS, int NW, int NCH = 2, int TH_ = 16>
 __global__ __launch_bounds__(64 * NW, 1) void conv_wstream_c64_kernel(const demfi_conv* __restrict__ d)
 {
-    using C = WsCfg<KS, NW>;
+    using C = WsCfg<KS, NW, NCH, TH_>;
+    constexpr int WS_TH = C::TH;
     constexpr int RPW = C::RPW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hi = lane >> 5, lx = lane & 31;
-    const int cs = wave & 1, rh = wave >> 1;                    // cout half, row group (RPW rows each)
+    const int cs = NCH == 2 ? (wave & 1) : 0, rh = NCH == 2 ? (wave >> 1) : wave;      // cout half, row group (RPW rows each)
     const int H = d->H, W = d->W;
     const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + WS_TH - 1) / WS_TH, tiles_img = tiles_x * tiles_y;
     const int total = tiles_img * d->batch;
@@ -2668,9 +2677,9 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_wstream_c64_kernel(const demf
     int doff[C::NIW], dlc[C::NIW];
 #pragma unroll
     for (int j = 0; j < C::NIW; ++j) {
-        const int rec = (wave + NW * j) * 16 + (lane >> 2);
+        const int rec = min((wave + NW * j) * 16 + (lane >> 2), C::LH * C::LL - 1);      // lanes past the unit (last instruction) re-read its last record
         const int l = rec / C::LL, c = rec - l * C::LL;
-        doff[j] = (int)(l * syb + c * sxb) + (((lane & 3) ^ ((c >> 2) & 3)) << 4);
+        doff[j] = C::PIECE_STRIDES ? (((lane & 3) ^ ((c >> 2) & 3)) << 4) : (int)(l * syb + c * sxb) + (((lane & 3) ^ ((c >> 2) & 3)) << 4);
         dlc[j] = l | (c << 8);
     }
     // ---- B fragments: line (8 rh + r), record (lx + kx), slot (2 ksl + hi) swizzled
@@ -2681,7 +2690,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_wstream_c64_kernel(const demf
         boff[g] = (rh * RPW * C::LL + col) * 64 + ((((g & 1) * 2 + hi) ^ ((col >> 2) & 3)) << 4);
     }
 
-    struct Unit { const char* src; const char* w; int iy0, ix0; bool interior; };
+    struct Unit { const char* src; const char* w; int iy0, ix0; bool interior; int sx, sy; };
     const unsigned lane16 = lane * 16;
     auto unit_info = [&](int u) {
         Unit r;
@@ -2692,8 +2701,10 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_wstream_c64_kernel(const demf
         r.iy0 = ty * WS_TH - KS / 2;
         r.ix0 = tx * TW - KS / 2;
         const demfi_piece& pc = d->pieces[d->chunks[cu].first_piece];
-        r.src = (const char*)pc.v.ptr + bimg * sbb + r.iy0 * syb + r.ix0 * sxb;
-        r.w = (const char*)(wbase + d->chunks[cu].w_off + cs * 64);                // uniform; + ((tap * 2 + ksl) * 2) KiB per step, + lane * 16
+        r.sx = C::PIECE_STRIDES ? (int)(pc.v.sx * 2) : (int)sxb;
+        r.sy = C::PIECE_STRIDES ? (int)(pc.v.sy * 2) : (int)syb;
+        r.src = (const char*)pc.v.ptr + bimg * (C::PIECE_STRIDES ? pc.v.sb * 2 : sbb) + (int64_t)r.iy0 * r.sy + (int64_t)r.ix0 * r.sx;
+        r.w = (const char*)(wbase + d->chunks[cu].w_off + cs * 64);                // uniform; + ((tap * 2 + ksl) * NCH) KiB per step, + lane * 16
         r.interior = r.iy0 >= 0 && r.iy0 + C::LH <= H && r.ix0 >= 0 && r.ix0 + C::LL <= W;
         return r;
     };
@@ -2702,6 +2713,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_wstream_c64_kernel(const demf
         const int i = wave + NW * j;
         if (i >= C::NI) return;                                  // wave-uniform
         const char* g = un.src + doff[j];
+        if constexpr (C::PIECE_STRIDES) g += (dlc[j] & 255) * un.sy + (dlc[j] >> 8) * un.sx;
         if (!un.interior) {
             const int iy = un.iy0 + (dlc[j] & 255), ix = un.ix0 + (dlc[j] >> 8);
             if (!(iy >= 0 && iy < H && ix >= 0 && ix < W)) g = zeros;
@@ -2721,7 +2733,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_wstream_c64_kernel(const demf
     };
     auto a_load = [&](const Unit& un, int t) {                  // A fragment of step t = (kx, ksl, ky): SGPR base + lane offset, global
         const int g = t / KS, ky = t - g * KS, kx = g >> 1, ksl = g & 1;
-        return __builtin_bit_cast(uint4, *gcp<u4_t>(un.w + (unsigned)((((ky * KS + kx) * 2 + ksl) * 2) * 1024 + lane16)));
+        return __builtin_bit_cast(uint4, *gcp<u4_t>(un.w + (unsigned)((((ky * KS + kx) * 2 + ksl) * NCH) * 1024 + lane16)));
     };
 
     const demfi_seg& sg = d->segs[d->sub_seg[0]];
@@ -2774,8 +2786,15 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_wstream_c64_kernel(const demf
             if constexpr (t + C::DEPTH < C::NSTEP) A[t % C::DEPTH] = a_load(cur, t + C::DEPTH);
             else                                   A[t % C::DEPTH] = a_load(nxt, t + C::DEPTH - C::NSTEP);
             // the next unit's tile, one DMA instruction every DMA_EVERY steps
-            if constexpr (t % C::DMA_EVERY == 2 && t / C::DMA_EVERY < C::NIW) {
-                if (has_next) dma_one(std::integral_constant<int, t / C::DMA_EVERY>{}, nxt, nb);
+            if constexpr (KS == 7) {
+                if constexpr (t % C::DMA_EVERY == 2 && t / C::DMA_EVERY < C::NIW) {
+                    if (has_next) dma_one(std::integral_constant<int, t / C::DMA_EVERY>{}, nxt, nb);
+                }
+            } else {
+                if (has_next) {
+                    if constexpr (t * C::DMA_PER < C::NIW) dma_one(std::integral_constant<int, t * C::DMA_PER>{}, nxt, nb);
+                    if constexpr (t * C::DMA_PER + 1 < C::NIW) dma_one(std::integral_constant<int, t * C::DMA_PER + 1>{}, nxt, nb);
+                }
             }
 #pragma unroll
             for (int p = 0; p < RPW; ++p) Mma<half_t>::run(acc[p], a, B[gb][ky + p]);
@@ -2814,33 +2833,50 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_wstream_c64_kernel(const demf
     }
 }
 
-static bool wstream_eligible(const demfi_conv* h)
+// ks / nch: 7 / 2 = Ch_Reducer (7x7, 64 couts), 3 / 1 = the RDB growth convolutions (3x3, 32 couts, units from pieces of different strides)
+static bool wstream_eligible(const demfi_conv* h, int ks = 7, int nch = 2)
 {
-    if (h->dtype != DEMFI_F16 || h->stride != 1 || h->kh != 7 || h->kw != 7 || h->pad_y != 3 || h->pad_x != 3) return false;
+    if (h->dtype != DEMFI_F16 || h->stride != 1 || h->kh != ks || h->kw != ks || h->pad_y != ks / 2 || h->pad_x != ks / 2) return false;
     if (h->inH != h->H || h->inW != h->W || !h->zero_page || h->rec_bytes != 64) return false;
-    if (h->n_chunks < 1 || h->cout_pad != 64 || h->nco != 2) return false;
+    if (h->n_chunks < (ks == 7 ? 1 : 2) || h->cout_pad != 32 * nch || h->nco != nch) return false;
     const demfi_piece& p0 = h->pieces[h->chunks[0].first_piece];
     for (int c = 0; c < h->n_chunks; ++c) {
         const demfi_chunk& ch = h->chunks[c];
         if (ch.n_pieces != 1 || ch.nks != 2) return false;
         const demfi_piece& p = h->pieces[ch.first_piece];
         if (!p.fat || p.nch != 32 || p.up_shift || !p.v.ptr || p.v.sc != 1 || p.v.is_f32) return false;
-        if (p.v.sx != p0.v.sx || p.v.sy != p0.v.sy || p.v.sb != p0.v.sb) return false;
-        if (p.v.sy * 2 * 24 >= (int64_t)1 << 31 || p.v.sx * 2 * 48 >= (int64_t)1 << 31) return false;   // 32-bit per-lane offsets inside a tile
+        if (ks == 7 && (p.v.sx != p0.v.sx || p.v.sy != p0.v.sy || p.v.sb != p0.v.sb)) return false;
+        if (p.v.sy * 2 * 40 >= (int64_t)1 << 31 || p.v.sx * 2 * 48 >= (int64_t)1 << 31) return false;   // 32-bit per-lane offsets inside a tile
     }
     const int sgi = h->sub_seg[0];
-    if (sgi < 0 || h->sub_seg[1] != sgi || h->oct_ch[4] != h->oct_ch[0] + 32) return false;
-    for (int o = 0; o < 8; ++o)
+    if (sgi < 0 || (nch == 2 && (h->sub_seg[1] != sgi || h->oct_ch[4] != h->oct_ch[0] + 32))) return false;
+    for (int o = 0; o < 4 * nch; ++o)
         if (h->oct_seg[o] != sgi || h->oct_n[o] != 8 || h->oct_ch[o] != h->oct_ch[0] + 8 * o) return false;
     const demfi_seg& sg = h->segs[sgi];
     if (sg.mode != DEMFI_MODE_STORE || sg.scale != 1 || sg.dy || sg.dx || sg.res.ptr || !sg.dst.ptr || sg.dst.is_f32 || sg.dst.sc != 1) return false;
     return true;
 }
 
+static bool wstream3_on()
+{
+    static const bool on = !(getenv("DEMFI_WS3") && atoi(getenv("DEMFI_WS3")) == 0);     // A/B: 0 = the general kernel for the RDB growth convolutions
+    return on;
+}
+static int launch_wstream3(const demfi_conv* h, const demfi_conv* dev, hipStream_t st)
+{
+    DEMFI_LDS_ATTR((conv_wstream_c64_kernel<3, 4, 1, 32>));
+    const int total = ((h->W + TW - 1) / TW) * ((h->H + 31) / 32) * h->batch;
+    const int grid = total >= 256 ? 256 : total;
+    constexpr size_t lds = WsCfg<3, 4, 1, 32>::LDS_BYTES;
+    hipLaunchKernelGGL((conv_wstream_c64_kernel<3, 4, 1, 32>), dim3(grid), dim3(256), lds, st, dev);
+    DEMFI_HIP_CHECK(hipGetLastError());
+    return DEMFI_OK;
+}
+
 static int launch_wstream(const demfi_conv* h, const demfi_conv* dev, hipStream_t st)
 {
     DEMFI_LDS_ATTR((conv_wstream_c64_kernel<7, DEMFI_WS_NW>));
-    const int total = ((h->W + TW - 1) / TW) * ((h->H + WS_TH - 1) / WS_TH) * h->batch;
+    const int total = ((h->W + TW - 1) / TW) * ((h->H + 15) / 16) * h->batch;
     const int grid = total >= 256 ? 256 : total;
     constexpr size_t lds = WsCfg<7, DEMFI_WS_NW>::LDS_BYTES;
     hipLaunchKernelGGL((conv_wstream_c64_kernel<7, DEMFI_WS_NW>), dim3(grid), dim3(64 * DEMFI_WS_NW), lds, st, dev);
@@ -2951,7 +2987,7 @@ int dispatch(const demfi_conv* h, const demfi_conv* dev, hipStream_t st, size_t 
 // 3x3 kernel, the narrow kernel with an NHWC destination, the SepConvGRU kernel.  Their layers are packed with cout_perm.
 bool demfi_persist_eligible(const demfi_conv* h)
 {
-    return sep_eligible(h) || wstream_eligible(h) || persist_eligible(h) || (narrow_eligible(h) && persist_out_eligible(h));
+    return sep_eligible(h) || wstream_eligible(h) || (wstream3_on() && wstream_eligible(h, 3, 1)) || persist_eligible(h) || (narrow_eligible(h) && persist_out_eligible(h));
 }
 
 extern "C" int64_t demfi_conv_lds_bytes(const demfi_conv* h)
@@ -3046,6 +3082,7 @@ extern "C" int demfi_conv2d(const demfi_conv* h, const demfi_conv* dev, void* st
         return launch_sep(h, dev, st);
     }
     if (wstream_eligible(h)) return launch_wstream(h, dev, st);
+    if (wstream3_on() && wstream_eligible(h, 3, 1)) return launch_wstream3(h, dev, st);
     if (persist_eligible(h)) {
 #ifdef DEMFI_ABLATION
         static const int var = getenv("DEMFI_PERSIST_VARIANT") ? atoi(getenv("DEMFI_PERSIST_VARIANT")) : 0;

@@ -271,7 +271,7 @@ struct Tensor {
 
 // Liveness plan of one buffer set (round 5, the workspace arena): the big activation buffers whose first access in the launch
 // sequence is a write share ONE arena; off = byte offset of the buffer's footprint inside the arena, size = arena bytes.
-struct ArenaPlan { std::map<std::string, int64_t> off; int64_t size = 0; bool on = false; };
+struct ArenaPlan { std::map<std::string, int64_t> off; int64_t size = 0; int64_t cstride = 0; bool on = false; };     // cstride: context stride of every arena member of a per-t set (the slot size)
 
 struct Weight { std::vector<float> data; std::vector<int64_t> shape; };
 
@@ -397,8 +397,10 @@ struct Layout {
         if (rep > 0) t.cstride = (t.bytes + 15) & ~15ll;
         const int64_t fp = footprint(t, rep);
         auto it = plan && plan->on ? plan->off.find(n) : std::map<std::string, int64_t>::const_iterator();
-        if (plan && plan->on && it != plan->off.end()) t.off = arena_base + it->second;
-        else t.off = take(fp);
+        if (plan && plan->on && it != plan->off.end()) {
+            t.off = arena_base + it->second;
+            if (rep > 0) t.cstride = plan->cstride;              // arena members of a per-t set: copy q sits q SLOTS further (see plan_arena)
+        } else t.off = take(fp);
         t.id = (int)c->id_cstride.size();
         c->id_cstride.push_back(t.cstride);
     }
@@ -1400,6 +1402,47 @@ ArenaPlan plan_arena(const demfi_ctx* c, const BufSet& set, int rep, const std::
         return false;
     };
     std::vector<Iv*> placed;
+    if (rep > 0) {
+        // Per-t set: the arena is a row of SLOTS.  A slot holds, per context, S bytes (S = the largest member: the 3-image buffers
+        // of D1); context q's share of slot j is [j * rep * S + q * S, + S).  A member lives at (slot, offset < S) with context stride
+        // S, so everything context q ever touches lies inside ITS shares: per-t contexts stay independent of one another (they
+        // may run concurrently on different streams, demfi_forward_t) while buffers of one context that are never alive together
+        // share memory.  A multi-image member fills a slot exactly (its images tile the context stride, as the batched plan needs).
+        int64_t S = 0;
+        for (Iv* x : todo) x->size = (Layout::footprint(set.find(x->name)->second, 1) + 255) & ~255ll;     // bytes per context
+        for (Iv* x : todo) S = std::max(S, x->size);
+        std::vector<Iv*> keep;
+        for (Iv* x : todo) {
+            const Tensor& t = set.find(x->name)->second;
+            if (t.kind == 0 && t.d[0] > 1 && ((t.bytes + 15) & ~15ll) != S) { x->ok = false; continue; }   // its images would not tile the slot stride
+            keep.push_back(x);
+        }
+        todo.swap(keep);
+        std::sort(todo.begin(), todo.end(), [](const Iv* a, const Iv* b) { return a->size != b->size ? a->size > b->size : a->live[0].first < b->live[0].first; });
+        std::vector<int> slot_of;
+        int n_slots = 0;
+        for (Iv* x : todo) {
+            int64_t o = -1;
+            int sj = 0;
+            for (; o < 0; ++sj) {
+                std::vector<std::pair<int64_t, int64_t>> busy;
+                for (size_t i = 0; i < placed.size(); ++i)
+                    if (slot_of[i] == sj && together(x, placed[i])) busy.push_back({placed[i]->off, placed[i]->off + placed[i]->size});
+                std::sort(busy.begin(), busy.end());
+                int64_t f = 0;
+                for (auto& b : busy) { if (f + x->size <= b.first) break; f = std::max(f, b.second); }
+                if (f + x->size <= S) { o = f; break; }
+            }
+            x->off = o;
+            placed.push_back(x);
+            slot_of.push_back(sj);
+            n_slots = std::max(n_slots, sj + 1);
+            pl.off[x->name] = (int64_t)sj * rep * S + o;
+        }
+        pl.cstride = S;
+        pl.size = (int64_t)n_slots * rep * S;
+        for (size_t i = 0; i < placed.size(); ++i) placed[i]->off += (int64_t)slot_of[i] * rep * S;      // for the debug print
+    } else
     for (Iv* x : todo) {
         std::vector<std::pair<int64_t, int64_t>> busy;           // address ranges of placed buffers alive at the same time
         for (Iv* y : placed) if (together(x, y)) busy.push_back({y->off, y->off + y->size});

@@ -152,6 +152,38 @@ def test_fused_resblock_vs_two_launches_and_torch(case):
     assert float((d > 0).float().mean()) < 0.05               # and almost everywhere identical
 
 
+@pytest.mark.parametrize('H,W,q', [(16, 32, 1), (37, 75, 2), (70, 100, 3), (368, 640, 0), (368, 640, 3), (133, 530, 2)])
+def test_rdb_growth_conv_streamed_weights(H, W, q):
+    """Round 5: the RDB growth convolutions (DeMFInet.py:266-281: 3x3, 96 + 32 q -> 32, ReLU, written into the next 32 channels of the
+    128-channel growth buffer it also reads) on the 3x3 / 32-cout instantiation of the streamed-weight kernel: 32-channel units from
+    two pieces with DIFFERENT pixel strides (a 96-channel slice of the 1152-channel GFF input, the growth buffer), 32 x 32-pixel tiles,
+    ragged edges, several tiles per workgroup (133 x 530), against an fp64 convolution of the same fp16 operands."""
+    torch.manual_seed(H + W + q)
+    pl = Plan(H, W, torch.float16, DEV)
+    cat = pl._fat(H, W, 1152)
+    grow = pl._fat(H, W, 128)
+    cat.copy_(torch.randn(cat.shape, device=DEV) * 0.5)
+    grow.copy_(torch.relu(torch.randn(grow.shape, device=DEV)))
+    g0 = grow.clone()
+    cin = 96 + 32 * q
+    wt = torch.randn(32, cin, 3, 3) * (1.0 / (cin * 9) ** 0.5)
+    bs = torch.randn(32) * 0.1
+    srcs = [pl.fsrc(cat, 0, c0=192, nch=96)] + ([pl.fsrc(grow, 96, c0=0, nch=32 * q)] if q else [])
+    pl.conv([], 'rdb', srcs, [_Dst(pl.fview(grow, 32 * q), range(32), L.ACT_RELU)], H, W, weight=wt, bias=bs)
+    d = pl._descs[0]
+    assert d.rec_bytes == 64 and d.cout_perm == 1 and d.n_chunks == 3 + q      # the shape the streamed-weight kernel owns
+    pl._upload()
+    pl.launch_conv(0, _stream())
+    torch.cuda.synchronize()
+    xin = torch.cat([cat[0, :, :, 192:288], g0[0, :, :, :32 * q]], 2).permute(2, 0, 1).double().cpu()[None]
+    ref = torch.relu(torch.nn.functional.conv2d(xin, wt.half().double(), bs.double(), padding=1))[0]
+    got = grow[0, :, :, 32 * q:32 * q + 32].permute(2, 0, 1).double().cpu()
+    err = (got - ref).abs().max().item()
+    assert err < 4e-3 * max(1.0, ref.abs().max().item()), (H, W, q, err)
+    keep = [c for c in range(128) if not 32 * q <= c < 32 * q + 32]
+    assert torch.equal(grow[0][:, :, keep], g0[0][:, :, keep])          # nothing else of the growth buffer was touched
+
+
 def test_persistent_conv_needs_its_cout_order():
     """The 64-channel 3x3 layers of the persistent kernel are packed in a permuted cout order (demfi_conv.cout_perm, set by
     demfi_conv_build): a descriptor of that shape without the flag, or a flagged one the kernel cannot take (no zero page),

@@ -379,6 +379,42 @@ def test_single_call_operator_plans_interpreted_on_the_cpu(synthetic_sd):
     assert (out - want).abs().max() < 1e-5
 
 
+def test_per_t_contexts_stay_independent_in_the_arena(synthetic_sd):
+    """The per-t contexts of a trunk set may run CONCURRENTLY on different streams (demfi_forward_t; the runner's DEMFI_TB=0 mode).
+    With buffers sharing memory that only holds if everything context q touches lies in memory no other context touches (the
+    slotted arena of ctx.cpp::plan_arena).  Interpreted on the CPU: the op lists of three contexts interleaved with a lag of
+    11 ops between them leave exactly what each context leaves when it runs alone."""
+    from demfi_amd.engine import SEG_HEAD, SEG_ITER, SEG_TRUNK
+    H, W, N, NC = 32, 64, 2, 3
+    eng = Engine(synthetic_sd, H, W, torch.float16, 'cpu', max_updates=N, n_ctx=NC)
+    x = synthetic_window(H, W, 9)
+    ts = [0.125, 0.5, 0.75]
+    sim = PlanSim(eng)
+    want = []
+    for c, t in enumerate(ts):
+        eng.use_ctx(c)
+        sim.forward(x, t, N)
+        want.append({k: eng._ctxs[0][c][k].clone() for k in ('finals', 'delta', 'occ', 'sharp1')})
+        for k in ('finals', 'delta', 'occ', 'sharp1'):
+            eng._ctxs[0][c][k].zero_()
+    eng.use_ctx(0)
+    eng.x.copy_(x[0])
+    sim.run(eng.ops(SEG_TRUNK))
+    seqs = []
+    for c, t in enumerate(ts):
+        eng._ctxs[0][c]['t_dev'].fill_(t)
+        seqs.append(list(eng.ops(SEG_HEAD, c=c)) + [o for it in range(N) for o in eng.ops(SEG_ITER, it, c=c)])
+    lag, n = 11, len(seqs[0])
+    for i in range(n + lag * (NC - 1)):
+        for c in range(NC):
+            j = i - lag * c
+            if 0 <= j < n:
+                sim.run([seqs[c][j]])
+    for c in range(NC):
+        for k, v in want[c].items():
+            assert torch.equal(eng._ctxs[0][c][k], v), (c, k)
+
+
 def _plan_digest(env):
     """finals / delta of a CPU-interpreted fp16 forward + workspace sizes, in a fresh process (the layout switches are read once)."""
     import json
