@@ -2609,6 +2609,9 @@ static int launch_sep(const demfi_conv* h, const demfi_conv* dev, hipStream_t st
 // each, so still one A load per 8 MFMAs), units of 32 channels may come from pieces with different strides (the block input and the
 // 128-channel growth buffer), 34 x 34 records per unit with no line padding (two units = 146 KiB of LDS), two DMA instructions per
 // step (19 per wave and unit against 18 steps).
+#ifndef DEMFI_WS3_DEPTH
+#define DEMFI_WS3_DEPTH 9
+#endif
 #ifndef DEMFI_WS_NW
 #define DEMFI_WS_NW 4                                            // waves of the streamed-weight kernel's workgroup: 4 (one per SIMD) or 8
 #endif
@@ -2623,10 +2626,13 @@ template <int KS, int NW, int NCH = 2, int TH_ = 16> struct WsCfg {
     static constexpr int LDS_BYTES = 2 * UNIT_BYTES;
     static constexpr int NG = 2 * KS;                            // (kx, k-step) groups per unit
     static constexpr int NSTEP = NG * KS;
-    static constexpr int DEPTH = NW == 8 ? KS : 2 * KS;          // A prefetch distance in steps (8 waves: 256 registers per wave)
+    // A prefetch distance in steps (8 waves: 256 registers per wave).  The 3x3 instantiation runs ONE tile per workgroup on weights no
+    // earlier launch has touched: every A fragment is an L2 miss (~2 us) that 240 workgroups take together, so the ring must cover
+    // that latency (9 steps of ~190 ns) or the launch is bound by it (depth 6: 35-49 us per layer where ~25 are matrix time)
+    static constexpr int DEPTH = NW == 8 ? KS : (KS == 7 ? 2 * KS : DEMFI_WS3_DEPTH);
     static constexpr int NIW = (NI + NW - 1) / NW;               // DMA instructions per wave (the last one may not exist)
     static constexpr int DMA_EVERY = KS == 7 ? 6 : 1;            // DMA instructions are issued every so many steps ...
-    static constexpr int DMA_PER = KS == 7 ? 1 : 2;              // ... so many at a time
+    static constexpr int DMA_PER = KS == 7 ? 1 : 3;              // ... so many at a time
     static constexpr bool PIECE_STRIDES = KS != 7;               // units may come from pieces with different strides
     static_assert(LDS_BYTES <= 160 * 1024, "two units must fit LDS");
     static_assert((NIW + DMA_PER - 1) / DMA_PER * DMA_EVERY + DEPTH <= NSTEP, "the unit's DMA must be older than the last A fragment consumed in the unit");
@@ -2792,8 +2798,10 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_wstream_c64_kernel(const demf
                 }
             } else {
                 if (has_next) {
-                    if constexpr (t * C::DMA_PER < C::NIW) dma_one(std::integral_constant<int, t * C::DMA_PER>{}, nxt, nb);
-                    if constexpr (t * C::DMA_PER + 1 < C::NIW) dma_one(std::integral_constant<int, t * C::DMA_PER + 1>{}, nxt, nb);
+                    static_for<0, C::DMA_PER>([&](auto Q) {
+                        constexpr int j = t * C::DMA_PER + decltype(Q)::value;
+                        if constexpr (j < C::NIW) dma_one(std::integral_constant<int, j>{}, nxt, nb);
+                    });
                 }
             }
 #pragma unroll
