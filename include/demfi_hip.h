@@ -369,7 +369,12 @@ int demfi_conv_build(int dtype, int H, int W, int stride, int batch, const float
 /* ---- forward context: the launch plan of DeMFInet.forward (DeMFInet.py:46-179) behind the C ABI -------
  * A context owns NO device memory: the caller allocates demfi_workspace_bytes() bytes (zero-filled) and binds them.
  * Inside the workspace: [packed weights + biases (one flat blob: the buffer a multi-GPU launch may broadcast) |
- * descriptors | n_trunk trunk buffer sets | n_trunk * n_ctx per-t buffer sets].  n_trunk / n_ctx > 1 build
+ * descriptors | n_trunk trunk buffer sets | n_trunk * n_ctx per-t buffer sets].  Since ABI v7 the big activation buffers of a set
+ * are planned by liveness and share an arena (buffers that are never alive together occupy the same bytes; the workspace of the
+ * 720p x8 configuration with 3 x 7 sets: 87.5 -> 36.1 GB): the named inputs / outputs of demfi_ctx_buffer ("x", "t", "sink",
+ * "finals", "delta", "occ", "sharp1", "overlay", "ffo", "aF", "F01", "ft") own their memory, other buffers hold their value only
+ * while the plan needs it.  Everything a per-t context touches lies in memory no other context touches (slots with a common context
+ * stride), so the independence promised below is kept.  Environment DEMFI_ARENA=0: one region per buffer (debugging).  n_trunk / n_ctx > 1 build
  * independent buffer sets so that a scheduler can overlap the trunk of window w+1 with the time instants of window w,
  * and several time instants of one window on different streams (results do not depend on it).
  * Re-entrant per context; one context per (GPU, frame size, dtype). */
