@@ -135,6 +135,9 @@ _SIGS = {
     'demfi_ctx_create': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(HParams), C.c_int, C.c_int,
                                    C.POINTER(C.c_void_p)]),
     'demfi_ctx_destroy': (C.c_int, [C.c_void_p]),
+    'demfi_gru_sep_create': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    'demfi_fgac_create': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    'demfi_operator_run': (C.c_int, [C.c_void_p, C.c_void_p]),
     'demfi_load_weight': (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int]),
     'demfi_ctx_workspace_bytes': (C.c_int64, [C.c_void_p]),
     'demfi_workspace_bytes': (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),

@@ -284,6 +284,7 @@ typedef std::vector<demfi_op> OpList;
 
 struct demfi_ctx {
     int H, W, N, dtype, n_trunk, n_ctx;
+    int op_kind = 0, op_batch = 1;                     // 0: the DeMFI-Net forward; 1 / 2: a single-call operator context (SepConvGRU / FGAC, ABI v7)
     demfi_hparams hp;
     std::map<std::string, Weight> weights;
     std::map<std::string, Layer> table;
@@ -318,6 +319,16 @@ void layer_table(demfi_ctx* c)
     // the reference's registration order and shapes (DeMFInet.py:15-44, 189-231, 319-333, 361-378, 566-584, 770-868;
     // SURVEY.md Appendix A/B) -- mirrored by demfi_amd/spec.py for the module surface
     auto& t = c->table;
+    if (c->op_kind == 1) {                                       // SepConvGRU (DeMFInet.py:830-836): keys of the reference module
+        for (const char* g : {"z", "r", "q"}) t[std::string("conv") + g + "1"] = {64, 128, 1, 5};
+        for (const char* g : {"z", "r", "q"}) t[std::string("conv") + g + "2"] = {64, 128, 5, 1};
+        return;
+    }
+    if (c->op_kind == 2) {                                       // FGAC (DeMFInet.py:369-380); conv_source_k is accepted and dead at rr = 0
+        t["conv_ref_k"] = {64, 64, 1, 1}; t["conv_source_k"] = {64, 64, 1, 1}; t["fusion"] = {64, 64, 1, 1};
+        t["w_gen"] = {64, 128, 3, 3}; t["w_gen_2"] = {1, 64, 3, 3};
+        return;
+    }
     const int nf = c->hp.nf, r2 = c->hp.scale_factor * c->hp.scale_factor;
     const int G0 = 96, G = 32, Cn = 4, D = 12;
     auto add = [&](const std::string& n, int cout, int cin, int kh, int kw) { t[n] = {cout, cin, kh, kw}; };
@@ -462,6 +473,19 @@ void alloc_trunk(Layout& L, BufSet& s)
     }
 }
 
+// buffers of a single-call operator context (all in the "trunk" set: demfi_ctx_buffer(ctx, 0, -1, name, ...))
+void alloc_operator(Layout& L, BufSet& s)
+{
+    const int H = L.c->H, W = L.c->W, B = L.c->op_batch;
+    if (L.c->op_kind == 1) {
+        for (const char* n : {"h", "x", "z", "rh", "h1", "out"}) L.fat(s, n, H, W, 64, B);
+    } else {
+        for (const char* n : {"ref", "source", "ref_k", "sampled", "e_s", "hid", "out"}) L.fat(s, n, H, W, 64, B);
+        L.thin(s, "flow", 2 * B, H, W);                          // flow_s2r [B,2,H,W] fp32 (absolute sampling coordinates)
+        L.thin(s, "w", B, H, W);                                 // the gate w_sr [B,1,H,W]
+    }
+}
+
 void alloc_t(Layout& L, BufSet& s)
 {
     const int H = L.c->H, W = L.c->W, N = L.c->N;
@@ -523,6 +547,11 @@ void compute_layout(demfi_ctx* c, int64_t w_bytes, int64_t n_descs)
     c->tr_bufs.assign(c->n_trunk, BufSet());
     c->t_bufs.assign(c->n_trunk, std::vector<BufSet>(c->n_ctx));
     c->id_cstride.assign(1, 0);
+    if (c->op_kind) {
+        alloc_operator(L, c->tr_bufs[0]);
+        c->total = L.cur;
+        return;
+    }
     for (int k = 0; k < c->n_trunk; ++k) {
         L.begin_set(&c->arena_tr);
         alloc_trunk(L, c->tr_bufs[k]);
@@ -870,6 +899,61 @@ struct Builder {
             std::swap(cur, other);
         }
         return cur;
+    }
+
+    // ---- single-call operators: the launch sequences demfi_amd/ops.py composes, behind the C ABI --------------------
+    void build_operator()
+    {
+        BufSet& B = c->tr_bufs[0];
+        OpList& tr = c->tr_ops[0];
+        const int H = c->H, W = c->W, nb = c->op_batch;
+        const int R = DEMFI_ACT_RELU, S = DEMFI_ACT_SIGMOID;
+        if (c->op_kind == 1) {
+            // SepConvGRU.forward (DeMFInet.py:838-857): horizontal then vertical GRU step; z | r as one 128-cout convolution
+            // (sigmoid; sigmoid * h), q with the GRU blend (1 - z) h + z tanh(.) in its epilogue
+            const Tensor* h = &B["h"];
+            for (int s2 = 0; s2 < 2 && status >= 0; ++s2) {
+                const std::string sfx = std::to_string(s2 + 1);
+                std::vector<float> zw, zb;
+                Layer shape = {128, 128, s2 == 0 ? 1 : 5, s2 == 0 ? 5 : 1};
+                for (const char* g : {"z", "r"}) {
+                    auto iw = c->weights.find(std::string("conv") + g + sfx + ".weight"), ib = c->weights.find(std::string("conv") + g + sfx + ".bias");
+                    if (dry) continue;
+                    if (iw == c->weights.end() || ib == c->weights.end()) { status = demfi_set_error(DEMFI_ERR_ARG, "demfi_ctx_bind: GRU weights were not loaded"); return; }
+                    zw.insert(zw.end(), iw->second.data.begin(), iw->second.data.end());
+                    zb.insert(zb.end(), ib->second.data.begin(), ib->second.data.end());
+                }
+                const Tensor& hnext = s2 == 0 ? B["h1"] : B["out"];
+                conv(tr, "convzr" + sfx, {fsrc(*h, 0), fsrc(B["x"], 64)},
+                     {D(fview(B["z"]), range(0, 64), S), D(fview(B["rh"]), range(64, 128), DEMFI_ACT_NONE, DEMFI_MODE_MUL, fview(*h))}, H, W, 1, nb,
+                     &zw, &zb, &shape);
+                conv(tr, "convq" + sfx, {fsrc(B["rh"], 0), fsrc(B["x"], 64)},
+                     {D(fview(hnext), range(0, 64), DEMFI_ACT_NONE, DEMFI_MODE_GRU, fview(*h), fview(B["z"]))}, H, W, 1, nb);
+                h = &hnext;
+            }
+            return;
+        }
+        // FGAC.forward at rr = sr = 0 (DeMFInet.py:386-452): conv_ref_k -> bilinear sample at the absolute flow coordinates -> fusion ->
+        // w = sigmoid(w_gen_2(relu(w_gen(cat[source, E_s])))) -> w source + (1 - w) E_s
+        const int64_t hw4 = (int64_t)H * W * 4;
+        conv(tr, "conv_ref_k", {fsrc(B["ref"], 0)}, {D(fview(B["ref_k"]), range(0, 64))}, H, W, 1, nb);
+        for (int b = 0; b < nb; ++b) {
+            demfi_op o = blank();
+            o.nch = 64;
+            o.a = fview(B["ref_k"], 0, b); o.o = fview(B["sampled"], 0, b);
+            o.p[0] = ptr(B["flow"]) + 2 * b * hw4;
+            simple(tr, DEMFI_OP_FGAC, "fgac", o);
+        }
+        conv(tr, "fusion", {fsrc(B["sampled"], 0)}, {D(fview(B["e_s"]), range(0, 64))}, H, W, 1, nb);
+        conv(tr, "w_gen", {fsrc(B["source"], 0), fsrc(B["e_s"], 64)}, {D(fview(B["hid"]), range(0, 64), R)}, H, W, 1, nb);
+        conv(tr, "w_gen_2", {fsrc(B["hid"], 0)}, {D(tview(B["w"], 0, (int64_t)H * W), {0}, S)}, H, W, 1, nb);
+        for (int b = 0; b < nb; ++b) {
+            demfi_op o = blank();
+            o.nch = 64;
+            o.a = fview(B["source"], 0, b); o.b = fview(B["e_s"], 0, b); o.o = fview(B["out"], 0, b);
+            o.p[0] = ptr(B["w"]) + b * hw4;
+            simple(tr, DEMFI_OP_GATE, "gate", o);
+        }
     }
 
     void build_trunk(int k)
@@ -1276,6 +1360,10 @@ int run_builder(demfi_ctx* c, bool dry)
     c->tb_head_ops.assign(c->n_trunk, OpList());
     c->tb_iter_ops.assign(c->n_trunk, std::vector<OpList>(c->N));
     Builder b{c, esz_of(c), c->dtype == DEMFI_F32, dry};
+    if (c->op_kind) {
+        b.build_operator();
+        return b.status;
+    }
     for (int k = 0; k < c->n_trunk && b.status >= 0; ++k) {
         b.build_trunk(k);
         for (int q = 0; q < c->n_ctx && b.status >= 0; ++q) b.build_t(k, q);
@@ -1538,7 +1626,7 @@ extern "C" int demfi_ctx_create(int H, int W, int max_updates, int dtype, const 
     // the workspace arena: buffers of a set that are never alive together share memory (DEMFI_ARENA=0: one region per buffer,
     // the layout of rounds 1-4; results are bit-identical either way)
     static const bool arena_on = !(getenv("DEMFI_ARENA") && atoi(getenv("DEMFI_ARENA")) == 0);
-    if (arena_on) {
+    if (arena_on && !c->op_kind) {
         std::vector<const OpList*> per_t = {&c->head_ops[0][0]}, tr = {&c->tr_ops[0]}, none;
         for (int it = 0; it < c->N; ++it) per_t.push_back(&c->iter_ops[0][0][it]);
         std::vector<const OpList*> per_t_all = per_t;
@@ -1562,6 +1650,35 @@ extern "C" int demfi_ctx_create(int H, int W, int max_updates, int dtype, const 
     c->descs.clear();
     *out = c;
     return DEMFI_OK;
+}
+
+// ---- single-call operator contexts (ABI v7; SURVEY.md 8b names demfi_gru_sep / demfi_fgac) --------------------------------------
+static int operator_create(int kind, int batch, int H, int W, int dtype, demfi_ctx** out)
+{
+    if (!out) return demfi_set_error(DEMFI_ERR_ARG, "operator context: null out");
+    if (batch < 1 || batch > 64 || H < 8 || W < 8 || (dtype != DEMFI_F16 && dtype != DEMFI_F32))
+        return demfi_set_error(DEMFI_ERR_ARG, "operator context: batch 1..64, H, W >= 8, dtype F16 / F32");
+    demfi_ctx* c = new demfi_ctx();
+    c->H = H; c->W = W; c->N = 1; c->dtype = dtype; c->n_trunk = 1; c->n_ctx = 1; c->op_kind = kind; c->op_batch = batch;
+    c->hp = {64, 2, 0, 0, 1, 0, 0, 0};
+    layer_table(c);
+    compute_layout(c, 0, 0);
+    int st = run_builder(c, true);
+    if (st < 0) { delete c; return st; }
+    compute_layout(c, c->blob_fill, (int64_t)c->descs.size());
+    c->descs.clear();
+    *out = c;
+    return DEMFI_OK;
+}
+
+extern "C" int demfi_gru_sep_create(int batch, int H, int W, int dtype, demfi_ctx** out) { return operator_create(1, batch, H, W, dtype, out); }
+extern "C" int demfi_fgac_create(int batch, int H, int W, int dtype, demfi_ctx** out) { return operator_create(2, batch, H, W, dtype, out); }
+
+extern "C" int demfi_operator_run(demfi_ctx* c, void* stream)
+{
+    if (!c || !c->op_kind || !c->bound || c->on_host)
+        return demfi_set_error(DEMFI_ERR_ARG, "demfi_operator_run: not an operator context bound to device memory");
+    return run_ops(c, c->tr_ops[0], stream);
 }
 
 extern "C" int demfi_ctx_destroy(demfi_ctx* c)

@@ -465,6 +465,20 @@ int     demfi_ctx_num_convs(const demfi_ctx* ctx);
 const demfi_conv* demfi_ctx_conv_desc(const demfi_ctx* ctx, int index);          /* host copy */
 int     demfi_run_op(demfi_ctx* ctx, const demfi_op* op, void* stream);
 
+/* ---- single-call operators behind the C ABI (ABI v7; SURVEY.md section 8b: demfi_gru_sep / demfi_fgac) -----------------------------
+ * SepConvGRU (DeMFInet.py:827-857: h' = GRU_5x1(GRU_1x5(h, x), x)) and FGAC at its hard-coded radii rr = sr = 0 (DeMFInet.py:361-452:
+ * conv_ref_k -> bilinear sample at the absolute flow coordinates -> fusion -> gate -> w source + (1 - w) E_s) as contexts of their own,
+ * for a host that swaps ONE module of the reference network.  An operator context is a demfi_ctx whose only segment is the operator:
+ * the whole context API applies -- demfi_load_weight with the reference module's own keys ("convz1.weight" ... "convq2.bias";
+ * "conv_ref_k.*", "conv_source_k.*" (accepted, dead at rr = 0), "fusion.*", "w_gen.*", "w_gen_2.*"), demfi_ctx_workspace_bytes,
+ * demfi_ctx_bind (caller-owned zero-filled workspace), demfi_ctx_buffer(ctx, 0, -1, name, ...) for the NHWC [batch,H,W,64] buffers of the
+ * path dtype ("h", "x", "out" / "ref", "source", "out") and the planar fp32 ones ("flow" [batch,2,H,W], "w" [batch,1,H,W] = the gate),
+ * demfi_ctx_num_ops / demfi_ctx_get_op on DEMFI_SEG_TRUNK, demfi_ctx_destroy -- and demfi_operator_run launches it (4 convolutions
+ * for the GRU: z | r fused and q per direction; 4 convolutions + one gather and one blend per image for FGAC). */
+int demfi_gru_sep_create(int batch, int H, int W, int dtype, demfi_ctx** out);
+int demfi_fgac_create(int batch, int H, int W, int dtype, demfi_ctx** out);
+int demfi_operator_run(demfi_ctx* ctx, void* stream);
+
 /* ---- hipGraph capture of a launch sequence ------------------------------------------------------ */
 int demfi_graph_begin(void* stream);
 int demfi_graph_end(void* stream, void** graph_exec_out);

@@ -1,5 +1,7 @@
 """Single-call operators (demfi_amd/ops.py: SepConvGRU, FGAC) on a real MI355X against the oracle's restatement of the same
 reference modules (oracle/demfi_oracle.py: sep_conv_gru = DeMFInet.py:838-857, fgac = DeMFInet.py:386-452)."""
+import ctypes as C
+
 import pytest
 import torch
 
@@ -91,3 +93,83 @@ def test_operators_reject_what_the_reference_modules_would():
         op(torch.zeros(1, 64, 8, 8, device=DEV), torch.zeros(1, 64, 8, 16, device=DEV))       # size mismatch
     with pytest.raises(ValueError):
         op(torch.zeros(1, 64, 8, 8), torch.zeros(1, 64, 8, 8))                                 # wrong device
+
+
+# ------------------------------------------------------------------------------------------------------
+# the same two operators through the C ABI alone (operator contexts, ABI v7): what a non-Python host binds
+# ------------------------------------------------------------------------------------------------------
+class _COperator:
+    """ctypes-only driver of an operator context: create, load the reference module's keys, bind a caller-owned workspace, fill the
+    named buffers, demfi_operator_run, read the named outputs.  torch only provides the device memory."""
+
+    def __init__(self, kind, B, H, W, dtype, sd, prefix):
+        from demfi_amd import _lib as L
+        self.L, self.lib = L, L.load()
+        self.ctx = C.c_void_p()
+        create = self.lib.demfi_gru_sep_create if kind == 'gru' else self.lib.demfi_fgac_create
+        L.check(create(B, H, W, L.F32 if dtype == torch.float32 else L.F16, C.byref(self.ctx)), 'create')
+        keys = ['conv%s%d' % (g, i) for i in (1, 2) for g in 'zrq'] if kind == 'gru' else ['conv_ref_k', 'conv_source_k', 'fusion', 'w_gen', 'w_gen_2']
+        for k in keys:
+            for part in ('weight', 'bias'):
+                t = sd[prefix + k + '.' + part].detach().float().contiguous()
+                shape = (C.c_int64 * t.dim())(*t.shape)
+                L.check(self.lib.demfi_load_weight(self.ctx, (k + '.' + part).encode(), t.data_ptr(), shape, t.dim()), 'load_weight')
+        n = self.lib.demfi_ctx_workspace_bytes(self.ctx)
+        self.ws = torch.zeros(n, dtype=torch.uint8, device=DEV)
+        L.check(self.lib.demfi_ctx_bind(self.ctx, self.ws.data_ptr(), n, 0, torch.cuda.current_stream().cuda_stream), 'bind')
+        self.dtype = dtype
+
+    def buf(self, name):
+        off, kind, dims = C.c_int64(0), C.c_int32(0), (C.c_int32 * 4)()
+        self.L.check(self.lib.demfi_ctx_buffer(self.ctx, 0, -1, name.encode(), C.byref(off), C.byref(kind), dims), 'buffer')
+        d = list(dims)
+        if kind.value == 0:
+            n = d[0] * d[1] * d[2] * d[3] * (4 if self.dtype == torch.float32 else 2)
+            return self.ws[off.value:off.value + n].view(self.dtype).view(d[0], d[1], d[2], d[3])
+        return self.ws[off.value:off.value + d[0] * d[1] * d[2] * 4].view(torch.float32).view(d[0], d[1], d[2])
+
+    def run(self):
+        self.L.check(self.lib.demfi_operator_run(self.ctx, torch.cuda.current_stream().cuda_stream), 'operator_run')
+        torch.cuda.synchronize()
+
+    def close(self):
+        self.lib.demfi_ctx_destroy(self.ctx)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16])
+def test_c_level_sep_conv_gru_matches_the_oracle(sd, dtype):
+    """VERDICT r4 missing #3 / SURVEY 8b: demfi_gru_sep as a C entry point (DeMFInet.py:838-857)."""
+    B, H, W = 2, 37, 75
+    torch.manual_seed(11)
+    h = torch.tanh(torch.randn(B, 64, H, W)).half().float()
+    x = torch.relu(torch.randn(B, 64, H, W)).half().float()
+    op = _COperator('gru', B, H, W, dtype, sd, 'Booster_Module.GB.')
+    op.buf('h').copy_(h.permute(0, 2, 3, 1))
+    op.buf('x').copy_(x.permute(0, 2, 3, 1))
+    op.run()
+    got = op.buf('out').permute(0, 3, 1, 2).float().cpu()
+    assert (got - O.sep_conv_gru(sd, h, x)).abs().max() < TOL[dtype]
+    assert op.lib.demfi_ctx_num_ops(op.ctx, 0, 0, 0, 0) == 4           # z | r and q per direction
+    op.close()
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16])
+def test_c_level_fgac_matches_the_oracle(sd, dtype):
+    """demfi_fgac as a C entry point (DeMFInet.py:386-452 at rr = sr = 0): out and the gate w_sr."""
+    B, H, W = 2, 24, 40
+    torch.manual_seed(5)
+    ref = (torch.randn(B, 64, H, W) * 0.5).half().float()
+    src = (torch.randn(B, 64, H, W) * 0.5).half().float()
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing='ij')
+    flow = torch.stack([xs, ys])[None].repeat(B, 1, 1, 1) + torch.randn(B, 2, H, W) * 3.0
+    flow[:, :, :2] -= 6.0
+    name = 'FAC_FB_Module.shared_FGAC'
+    op = _COperator('fgac', B, H, W, dtype, sd, name + '.')
+    op.buf('ref').copy_(ref.permute(0, 2, 3, 1))
+    op.buf('source').copy_(src.permute(0, 2, 3, 1))
+    op.buf('flow').copy_(flow.reshape(2 * B, H, W))
+    op.run()
+    want, w_want = O.fgac(sd, name, ref, src, flow)
+    assert (op.buf('out').permute(0, 3, 1, 2).float().cpu() - want).abs().max() < TOL[dtype]
+    assert (op.buf('w').cpu().view(B, 1, H, W) - w_want).abs().max() < TOL[dtype]
+    op.close()
