@@ -249,6 +249,9 @@ __global__ __launch_bounds__(RB_NTHREADS, 1) void resblock3x3_c64_kernel(const R
     }
 
     // ================= MFMA waves ================================================================================
+#ifdef DEMFI_RB_PRIO
+    __builtin_amdgcn_s_setprio(DEMFI_RB_PRIO);                  // experiment: MFMA waves above the helper waves of their SIMD
+#endif
     const int hi = lane >> 5, lx = lane & 31;
     const int cs = wave & 1, rh = wave >> 1;                    // cout half, row half (8 rows each)
     const unsigned lane16 = lane * 16;
