@@ -65,6 +65,12 @@ int build_conv(int dtype, int H, int W, int stride, int batch, const float* w, c
         // measured at 720p (same box): the 48 RDB growth convs 0.045-0.072 -> 0.035-0.058 ms, dec2 0.082 -> 0.070; the 96-cout
         // layers (nco = 3: LFF, GFF.1) get slower with it, hence nco <= 2
         if (!sep && !persist_shape && rec == 128 && nco <= 2 && n_wg <= 5 * 256) rec = 64;
+        // round 5: the RDB growth shape (3x3, <= 32 couts, >= 3 units of 32 channels from NHWC pieces) belongs to the 3x3 instantiation
+        // of the streamed-weight kernel at any grid size: it walks 32-channel units (64-byte records)
+        static const bool ws3 = !(getenv("DEMFI_WS3") && atoi(getenv("DEMFI_WS3")) == 0);
+        bool rdb_shape = ws3 && !sep && esz == 2 && kh == 3 && kw == 3 && stride == 1 && sub == 1 && n_dsts == 1 && dsts[0].n == 32 && cin >= 96 && pad_y < 0 && pad_x < 0;
+        for (int i = 0; rdb_shape && i < n_srcs; ++i) rdb_shape = srcs[i].fat && !srcs[i].up_shift && srcs[i].nch % 32 == 0;
+        if (rdb_shape) rec = 64;
     }
 
     // ---- every original input channel must be fed exactly once ------------------------------------------------
