@@ -119,3 +119,24 @@ def test_fuzz_forward_fp32_vs_oracle(H, W, N, tv, seed):
         assert abs(O.psnr(got[0][i][0].cpu().numpy(), gt) - O.psnr(ref[0][i][0].numpy(), gt)) <= 1e-3
     assert np.median(np.abs(got[2][N][0].cpu().numpy() - ref[2][N][0].numpy())) < 2e-4
     assert np.median(np.abs(got[3][N][0].cpu().numpy() - ref[3][N][0].numpy())) < 2e-5
+
+
+# ---- round 5: the fused residual block and the RDB growth convolutions (own generator: the cases above keep their shapes) --------
+_rng5 = random.Random(20260930)
+RESBLOCK = [(_rng5.randint(8, 120), _rng5.randint(8, 260), _rng5.randint(1, 3)) for _ in range(10)] + [(176, 900, 2)]
+
+
+@pytest.mark.parametrize('H,W,batch', RESBLOCK)
+def test_fuzz_fused_resblock(H, W, batch):
+    """strips of 30 columns x steps of 16 rows: ragged last strip / step, chains that start mid-strip (176 x 900 x 2: 660 items on 256
+    workgroups), images of fewer than 16 rows or 30 columns"""
+    K.test_fused_resblock_vs_two_launches_and_torch((H, W, batch))
+
+
+RDB = [(_rng5.randint(8, 200), _rng5.randint(8, 330), q) for q in (0, 1, 2, 3, 1, 2, 3, 0)]
+
+
+@pytest.mark.parametrize('H,W,q', RDB)
+def test_fuzz_rdb_growth_conv(H, W, q):
+    """32 x 32-pixel tiles of the 3x3 streamed-weight instantiation at pseudo-random frame sizes, 3 .. 6 units of 32 channels"""
+    K.test_rdb_growth_conv_streamed_weights(H, W, q)
