@@ -324,7 +324,7 @@ def main():
         prof = eng.profile(a.n_tst, isolated=False, batched=runner.tb)
         per_t = sum(p[3] for p in prof if p[0] != 'trunk') / nb
         trunk = sum(p[3] for p in prof if p[0] == 'trunk')
-        convs = [p for p in prof if p[1] in ('conv', 'resblock')]              # resblock (round 5): conv1 -> ReLU -> conv2 + identity in ONE launch
+        convs = [p for p in prof if p[1] in ('conv', 'resblock', 'gru_r', 'gru_zq')]              # resblock (round 5): conv1 -> ReLU -> conv2 + identity in ONE launch
         dom = max(convs, key=lambda p: p[3])
         grp = [p for p in convs if p[2].startswith('Decoder_res.')]          # D1 residual blocks: 3x3 64->64, batch 3
         fused = bool(grp) and all(p[1] == 'resblock' for p in grp)

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('DEMFI_HIP_LIB') or os.path.join(_HERE, 'csrc', 'libdemfi_hip.so')   # override: ablation builds
 
 F16, F32 = 0, 1
-ABI_VERSION = 7
+ABI_VERSION = 8
 ACT_NONE, ACT_RELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3
 MODE_STORE, MODE_MUL, MODE_GRU = 0, 1, 2
 MAX_PIECES, MAX_CHUNKS, MAX_SEGS, MAX_OCTS = 48, 40, 8, 32
@@ -90,6 +90,10 @@ _SIGS = {
     'demfi_conv2d': (C.c_int, [C.POINTER(Conv), C.c_void_p, C.c_void_p]),
     'demfi_resblock_eligible': (C.c_int, [C.POINTER(Conv), C.POINTER(Conv)]),
     'demfi_resblock3x3_c64': (C.c_int, [C.POINTER(Conv), C.POINTER(Conv), C.c_void_p]),
+    'demfi_gru_r_eligible': (C.c_int, [C.POINTER(Conv)]),
+    'demfi_gru_r': (C.c_int, [C.POINTER(Conv), C.c_void_p]),
+    'demfi_gru_zq_eligible': (C.c_int, [C.POINTER(Conv), C.POINTER(Conv)]),
+    'demfi_gru_zq': (C.c_int, [C.POINTER(Conv), C.POINTER(Conv), C.c_void_p]),
     'demfi_space_to_depth': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'demfi_reflect_pad': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'demfi_overlay_mean': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),

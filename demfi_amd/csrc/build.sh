@@ -11,6 +11,7 @@ SRCS_CPP="abi.cpp"
 [ -f metrics.hip ] && SRCS_HIP="$SRCS_HIP metrics.hip"
 [ -f fgac_window.hip ] && SRCS_HIP="$SRCS_HIP fgac_window.hip"
 [ -f resblock.hip ] && SRCS_HIP="$SRCS_HIP resblock.hip"
+[ -f gru.hip ] && SRCS_HIP="$SRCS_HIP gru.hip"
 [ -f ctx.cpp ] && SRCS_CPP="$SRCS_CPP ctx.cpp"
 [ -f png_codec.cpp ] && SRCS_CPP="$SRCS_CPP png_codec.cpp"
 # stale objects must never be linked: a failed compile has to fail the build
@@ -22,7 +23,7 @@ objs=()
 CONV_FLAGS="-fno-slp-vectorize"
 for s in $SRCS_HIP; do
   o="${s%.hip}.o"; objs+=("$o")
-  xf=""; { [ "$s" = conv.hip ] || [ "$s" = resblock.hip ]; } && xf="$CONV_FLAGS"
+  xf=""; { [ "$s" = conv.hip ] || [ "$s" = resblock.hip ] || [ "$s" = gru.hip ]; } && xf="$CONV_FLAGS"
   $HIPCC $FLAGS $xf -c "$s" -o "$o" & pids+=($!)
 done
 for s in $SRCS_CPP; do
@@ -37,11 +38,12 @@ echo "built $(pwd)/libdemfi_hip.so"
 # --trace: third library whose persistent 64->64 kernels stamp s_memtime at their phase boundaries (tools/phase_trace.py)
 if [ "$1" = "--trace" ]; then
   $HIPCC $FLAGS $XFLAGS $CONV_FLAGS -DDEMFI_TRACE -c conv.hip -o conv_trace.o &
+  $HIPCC $FLAGS $XFLAGS $CONV_FLAGS -DDEMFI_TRACE -c gru.hip -o gru_trace.o &
   $HIPCC $FLAGS $XFLAGS $CONV_FLAGS -DDEMFI_TRACE -c resblock.hip -o resblock_trace.o
   wait
   trc=()
   for o in "${objs[@]}"; do
-    if [ "$o" = conv.o ]; then trc+=(conv_trace.o); elif [ "$o" = resblock.o ]; then trc+=(resblock_trace.o); else trc+=("$o"); fi
+    if [ "$o" = conv.o ]; then trc+=(conv_trace.o); elif [ "$o" = resblock.o ]; then trc+=(resblock_trace.o); elif [ "$o" = gru.o ]; then trc+=(gru_trace.o); else trc+=("$o"); fi
   done
   $HIPCC --offload-arch=gfx950 -shared -fPIC "${trc[@]}" -o libdemfi_hip_trace.so -lz -lpthread
   echo "built $(pwd)/libdemfi_hip_trace.so"

@@ -311,6 +311,10 @@ struct demfi_ctx {
     // convolution runs once with batch x n_ctx (the copies of a per-t buffer are contiguous), point-wise ops once per context
     std::vector<OpList> tb_head_ops;                   // [trunk]
     std::vector<std::vector<OpList>> tb_iter_ops;      // [trunk][it]
+    // fusion decisions of the sizing pass ("<kind>:<name>" per fused launch, in plan order).  The arena gives the buffers a fused launch
+    // never touches (the scratch between the convolutions of a residual block, the z buffer of a GRU half-step) NO memory, so the
+    // bind pass must fuse exactly the same launches: checked in demfi_ctx_bind.
+    std::vector<std::string> fused_dry, fused_now;
     std::vector<uint8_t> host_blob;                    // packed weights + biases staged on the host
     std::map<std::string, std::pair<int64_t, int64_t>> pack_cache;   // layer signature -> (w_off, b_off) inside the blob
     int64_t blob_fill = 0;
@@ -864,8 +868,10 @@ struct Builder {
 
     // Round 5: the two launches conv() has just appended (conv1 -> ReLU -> t, conv2 + identity) become ONE launch of the fused
     // residual-block kernel when the pair qualifies (fp16 plan, 3x3 64 -> 64, persistent-kernel packing): the intermediate stays in
-    // LDS, the scratch buffer t is not touched.  Both descriptors are kept as they are (the plan interpreter of the CPU tests and
-    // the A/B switch DEMFI_RESBLOCK=0 run them one after the other).
+    // LDS, the scratch buffer t is not touched -- and under the workspace arena it has NO memory (its views point at the arena's first
+    // bytes, which belong to a live tenant): a RESBLOCK op must never be executed as its two convolutions on the bound workspace.  Both
+    // descriptors are kept as they are for the CPU plan interpreter (which gives the intermediate private memory, tests/plan_sim.py)
+    // and for DEMFI_RESBLOCK=0, which changes the sizing pass too (the scratch then has memory).
     void fuse_resblock(OpList& seg, const std::string& name)
     {
         static const bool on = !(getenv("DEMFI_RESBLOCK") && atoi(getenv("DEMFI_RESBLOCK")) == 0);
@@ -889,6 +895,38 @@ struct Builder {
         seg.pop_back();
         seg.pop_back();
         seg.push_back(op);
+        c->fused_now.push_back("resblock:" + name);
+    }
+
+    // Round 6: one SepConvGRU half-step (DeMFInet.py:844-849 / 851-856).  conv() has just appended the three plain 64-cout layers
+    //     convr: [h, x] -> r*h (MUL)     convz: [h, x] -> z (sigmoid, into the z buffer)     convq: [r*h, x] -> h' (GRU epilogue, aux = z)
+    // The first becomes a launch of the round-6 kernel's R mode, the other two ONE launch of its ZQ mode (gru.hip: z stays on chip, the z
+    // buffer is never touched) when they qualify (fp16 plan).  The descriptors stay as they are: DEMFI_GRU6=0 and the CPU plan
+    // interpreter run the three layers through demfi_conv2d (the round-5 kernel at 64 couts).
+    void fuse_gru(OpList& seg, const std::string& name)
+    {
+        static const bool on = !(getenv("DEMFI_GRU6") && atoi(getenv("DEMFI_GRU6")) == 0);
+        if (status < 0 || !on || seg.size() < 3) return;
+        const demfi_op oq = seg[seg.size() - 1], oz = seg[seg.size() - 2], orr = seg[seg.size() - 3];
+        if (oq.kind != DEMFI_OP_CONV || oz.kind != DEMFI_OP_CONV || orr.kind != DEMFI_OP_CONV) return;
+        demfi_conv hq = c->descs[oq.conv], hz = c->descs[oz.conv], hr = c->descs[orr.conv];
+        if (dry) {                                               // sizing pass: the blobs are not placed yet
+            static const char some = 0;
+            for (demfi_conv* h : {&hq, &hz, &hr}) { h->wpack = h->zero_page = &some; h->bias = (const float*)&some; }
+        }
+        if (!demfi_gru_r_eligible(&hr) || !demfi_gru_zq_eligible(&hz, &hq)) return;
+        demfi_op r = orr, zq;
+        r.kind = DEMFI_OP_GRU_R;
+        memset(&zq, 0, sizeof(zq));
+        zq.kind = DEMFI_OP_GRU_ZQ;
+        zq.conv = oz.conv;
+        zq.nch = oq.conv;
+        zq.macs = oz.macs + oq.macs;
+        strncpy(zq.name, (name + ".convzq").c_str(), sizeof(zq.name) - 1);
+        seg.pop_back(); seg.pop_back(); seg.pop_back();
+        seg.push_back(r);
+        seg.push_back(zq);
+        c->fused_now.push_back("gru:" + name);
     }
 
     // x_{k+1} = x_k + conv2(relu(conv1(x_k))) ping-ponging between buffers a and b (t = scratch); returns the result buffer
@@ -930,6 +968,16 @@ struct Builder {
                     zb.insert(zb.end(), ib->second.data.begin(), ib->second.data.end());
                 }
                 const Tensor& hnext = s2 == 0 ? B["h1"] : B["out"];
+                static const bool gru6_env = !(getenv("DEMFI_GRU6") && atoi(getenv("DEMFI_GRU6")) == 0);
+                if (gru6_env && c->dtype == DEMFI_F16) {         // round 6: r*h, then z + q + blend in one launch (fuse_gru)
+                    conv(tr, "convr" + sfx, {fsrc(*h, 0), fsrc(B["x"], 64)}, {D(fview(B["rh"]), range(0, 64), DEMFI_ACT_NONE, DEMFI_MODE_MUL, fview(*h))}, H, W, 1, nb);
+                    conv(tr, "convz" + sfx, {fsrc(*h, 0), fsrc(B["x"], 64)}, {D(fview(B["z"]), range(0, 64), S)}, H, W, 1, nb);
+                    conv(tr, "convq" + sfx, {fsrc(B["rh"], 0), fsrc(B["x"], 64)},
+                         {D(fview(hnext), range(0, 64), DEMFI_ACT_NONE, DEMFI_MODE_GRU, fview(*h), fview(B["z"]))}, H, W, 1, nb);
+                    fuse_gru(tr, "step" + sfx);
+                    h = &hnext;
+                    continue;
+                }
                 conv(tr, "convzr" + sfx, {fsrc(*h, 0), fsrc(B["x"], 64)},
                      {D(fview(B["z"]), range(0, 64), S), D(fview(B["rh"]), range(64, 128), DEMFI_ACT_NONE, DEMFI_MODE_MUL, fview(*h))}, H, W, 1, nb,
                      &zw, &zb, &shape);
@@ -1280,10 +1328,12 @@ struct Builder {
             dyn_m16.insert(dyn_m16.end(), 5, -1);
         }
         // ============================ recursive boosting, one list per iteration ====================================
-        // SepConvGRU (838-857): z | r share their input -> one 128-cout conv
+        // SepConvGRU (838-857): z | r share their input -> one 128-cout conv (fp32 plan, DEMFI_GRU6=0); round 6, fp16: see fuse_gru
+        static const bool gru6_env = !(getenv("DEMFI_GRU6") && atoi(getenv("DEMFI_GRU6")) == 0);
+        const bool gru6 = gru6_env && c->dtype == DEMFI_F16;
         std::vector<float> zrw[2], zrb[2];
         const Layer zr_shape[2] = {{128, 128, 1, 5}, {128, 128, 5, 1}};
-        for (int s = 0; s < 2 && status >= 0 && !dry; ++s) {
+        for (int s = 0; s < 2 && status >= 0 && !dry && !gru6; ++s) {
             const std::string sfx = std::to_string(s + 1);
             for (const char* g : {"z", "r"}) {
                 auto iw = c->weights.find(p + "GB.conv" + g + sfx + ".weight"), ib = c->weights.find(p + "GB.conv" + g + sfx + ".bias");
@@ -1319,11 +1369,18 @@ struct Builder {
             for (int s = 0; s < 2; ++s) {
                 const Tensor& hnext = s == 0 ? B["h1"] : hout;
                 const std::string sfx = std::to_string(s + 1);
+                if (gru6) {
+                    // round 6: r*h, then z + q + blend in one launch (fuse_gru); the three plain layers of the reference module
+                    conv(sg, p + "GB.convr" + sfx, {fsrc(*h, 0), fsrc(B["xb"], 64)},
+                         {D(fview(B["rh"]), range(0, 64), DEMFI_ACT_NONE, DEMFI_MODE_MUL, fview(*h))}, H, W);
+                    conv(sg, p + "GB.convz" + sfx, {fsrc(*h, 0), fsrc(B["xb"], 64)}, {D(fview(B["zb"]), range(0, 64), DEMFI_ACT_SIGMOID)}, H, W);
+                } else
                 conv(sg, p + "GB.convzr" + sfx, {fsrc(*h, 0), fsrc(B["xb"], 64)},
                      {D(fview(B["zb"]), range(0, 64), DEMFI_ACT_SIGMOID),
                       D(fview(B["rh"]), range(64, 128), DEMFI_ACT_NONE, DEMFI_MODE_MUL, fview(*h))}, H, W, 1, 1, &zrw[s], &zrb[s], &zr_shape[s]);
                 conv(sg, p + "GB.convq" + sfx, {fsrc(B["rh"], 0), fsrc(B["xb"], 64)},
                      {D(fview(hnext), range(0, 64), DEMFI_ACT_NONE, DEMFI_MODE_GRU, fview(*h), fview(B["zb"]))}, H, W);
+                if (gru6) fuse_gru(sg, p + "GB.step" + sfx);
                 h = &hnext;
             }
             conv(sg, p + "flow_occ.conv1", {fsrc(hout, 0)}, {D(fview(B["fo1"]), range(0, 32), R)}, H, W);
@@ -1365,10 +1422,20 @@ int run_builder(demfi_ctx* c, bool dry)
     c->iter_ops.assign(c->n_trunk, std::vector<std::vector<OpList>>(c->n_ctx, std::vector<OpList>(c->N)));
     c->tb_head_ops.assign(c->n_trunk, OpList());
     c->tb_iter_ops.assign(c->n_trunk, std::vector<OpList>(c->N));
+    c->fused_now.clear();
     Builder b{c, esz_of(c), c->dtype == DEMFI_F32, dry};
+    // the sizing pass records which launches it fused; the bind pass must fuse the same ones (their untouched scratch has no memory)
+    auto done = [&]() {
+        if (b.status < 0) return b.status;
+        if (dry) c->fused_dry = c->fused_now;
+        else if (c->fused_now != c->fused_dry)
+            return demfi_set_error(DEMFI_ERR_ARG, "demfi_ctx_bind: the bound plan fuses %d launches, the sizing pass fused %d (or others): the "
+                                   "arena gave their scratch buffers no memory -- set DEMFI_ARENA=0 and report", (int)c->fused_now.size(), (int)c->fused_dry.size());
+        return b.status;
+    };
     if (c->op_kind) {
         b.build_operator();
-        return b.status;
+        return done();
     }
     for (int k = 0; k < c->n_trunk && b.status >= 0; ++k) {
         b.build_trunk(k);
@@ -1379,7 +1446,7 @@ int run_builder(demfi_ctx* c, bool dry)
             b.tb = 1;
         }
     }
-    return b.status;
+    return done();
 }
 
 // ---- workspace arena (round 5) -----------------------------------------------------------------------------------
@@ -1397,6 +1464,13 @@ void op_accesses(const demfi_ctx* c, const demfi_op& op, std::vector<std::pair<c
     switch (op.kind) {
     case DEMFI_OP_CONV: conv_in(c->descs[op.conv]); conv_out(c->descs[op.conv]); break;
     case DEMFI_OP_RESBLOCK: conv_in(c->descs[op.conv]); conv_out(c->descs[op.nch]); break;
+    case DEMFI_OP_GRU_R: conv_in(c->descs[op.conv]); conv_out(c->descs[op.conv]); break;
+    case DEMFI_OP_GRU_ZQ: {                                      // reads h, x, r*h; writes h'; the z buffer (convz's dst == convq's aux) is not touched
+        const demfi_conv& dq = c->descs[op.nch];
+        conv_in(c->descs[op.conv]); conv_in(dq);
+        for (int i = 0; i < dq.n_segs; ++i) { rd(dq.segs[i].res.ptr); wr(dq.segs[i].dst.ptr); }
+        break;
+    }
     case DEMFI_OP_PACK: for (int i = 0; i < 32; ++i) rd(op.p[i]); wr(op.o.ptr); break;
     case DEMFI_OP_S2D: case DEMFI_OP_OVERLAY: rd(op.p[0]); wr(op.p[1]); break;
     case DEMFI_OP_FGAC: rd(op.a.ptr); rd(op.p[0]); wr(op.o.ptr); break;
@@ -1433,7 +1507,8 @@ bool op_overwrites(const demfi_ctx* c, const demfi_op& op, const Tensor& t, int6
         return false;
     };
     if (op.kind == DEMFI_OP_CONV) return conv_full(c->descs[op.conv]);
-    if (op.kind == DEMFI_OP_RESBLOCK) return conv_full(c->descs[op.nch]);
+    if (op.kind == DEMFI_OP_RESBLOCK || op.kind == DEMFI_OP_GRU_ZQ) return conv_full(c->descs[op.nch]);
+    if (op.kind == DEMFI_OP_GRU_R) return conv_full(c->descs[op.conv]);
     if (op.kind == DEMFI_OP_PACK) return (int64_t)(intptr_t)op.o.ptr == t_addr && op.nch == t.d[3] && t.d[0] == 1;
     return false;
 }
@@ -1907,6 +1982,13 @@ extern "C" int demfi_run_op(demfi_ctx* c, const demfi_op* op, void* stream)
         if (op->conv < 0 || op->conv >= (int)c->descs.size() || op->nch < 0 || op->nch >= (int)c->descs.size())
             return demfi_set_error(DEMFI_ERR_ARG, "demfi_run_op: descriptor index");
         return demfi_resblock3x3_c64(&c->descs[op->conv], &c->descs[op->nch], stream);
+    case DEMFI_OP_GRU_R:
+        if (op->conv < 0 || op->conv >= (int)c->descs.size()) return demfi_set_error(DEMFI_ERR_ARG, "demfi_run_op: descriptor index");
+        return demfi_gru_r(&c->descs[op->conv], stream);
+    case DEMFI_OP_GRU_ZQ:
+        if (op->conv < 0 || op->conv >= (int)c->descs.size() || op->nch < 0 || op->nch >= (int)c->descs.size())
+            return demfi_set_error(DEMFI_ERR_ARG, "demfi_run_op: descriptor index");
+        return demfi_gru_zq(&c->descs[op->conv], &c->descs[op->nch], stream);
     case DEMFI_OP_PACK:
         if (op->bt.nb > 1)
             return demfi_pack_planes_batched((const float* const*)op->p, op->nch, op->o.ptr, c->dtype, op->o.sx, H, W, &op->bt, stream);

@@ -192,9 +192,19 @@ class Plan:
         L.check(self.lib.demfi_resblock3x3_c64(C.byref(self._descs[i1]), C.byref(self._descs[i2]), stream), what)
 
 
+    def launch_gru_r(self, i, stream, what='gru_r'):
+        """Descriptor i (the reset-gate layer with the MUL epilogue) on the round-6 SepConvGRU kernel (demfi_gru_r)."""
+        L.check(self.lib.demfi_gru_r(C.byref(self._descs[i]), stream), what)
+
+    def launch_gru_zq(self, iz, iq, stream, what='gru_zq'):
+        """Descriptors iz (update gate, sigmoid -> z buffer) and iq (candidate, GRU epilogue) as ONE launch: z stays on chip."""
+        L.check(self.lib.demfi_gru_zq(C.byref(self._descs[iz]), C.byref(self._descs[iq]), stream), what)
+
+
 SEG_TRUNK, SEG_HEAD, SEG_ITER, SEG_TB_HEAD, SEG_TB_ITER = 0, 1, 2, 3, 4
 KIND_NAME = {0: 'conv', 1: 'pack', 2: 's2d', 3: 'overlay', 4: 'fgac', 5: 'gate', 6: 'cfr', 7: 'warp', 8: 'fgac_window', 9: 'avg_pool',
-             10: 'resblock'}        # resblock: ONE launch for conv1 -> ReLU -> conv2 + identity (op.conv / op.nch = the two descriptors)
+             10: 'resblock',        # resblock: ONE launch for conv1 -> ReLU -> conv2 + identity (op.conv / op.nch = the two descriptors)
+             11: 'gru_r', 12: 'gru_zq'}   # round 6: SepConvGRU half-step as r*h, then z + q + blend in one launch (op.conv / op.nch = convz / convq)
 
 
 class Engine:

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DEMFI_ABI_VERSION 7
+#define DEMFI_ABI_VERSION 8
 
 enum demfi_dtype { DEMFI_F16 = 0, DEMFI_F32 = 1 };
 
@@ -205,6 +205,21 @@ int demfi_conv2d(const demfi_conv* host_desc, const demfi_conv* dev_desc, void* 
  * launches), else 0. */
 int demfi_resblock_eligible(const demfi_conv* h1, const demfi_conv* h2);
 int demfi_resblock3x3_c64(const demfi_conv* h1, const demfi_conv* h2, void* stream);
+
+/* SepConvGRU half-step with the update gate kept on chip (ABI v8; DeMFInet.py:838-857, horizontal 844-849, vertical 851-856):
+ *     launch R  (demfi_gru_r)  : r * h = sigmoid(convr([h, x])) * h
+ *     launch ZQ (demfi_gru_zq) : h' = (1 - z) h + z tanh(convq([r * h, x])),  z = sigmoid(convz([h, x]))
+ * instead of the z | r and q launches of demfi_conv2d: z never goes to memory (handed from the z waves to the q waves through LDS,
+ * rounded to fp16 as the stored z was), 896 instead of 1 152 bytes per pixel and half-step.  The arguments are HOST descriptors of
+ * the plain 64-cout layers exactly as demfi_conv_build makes them for demfi_conv2d (1x5 or 5x1, fp16, two 64-channel NHWC pieces):
+ *   hr: [h, x] -> MUL epilogue with res == h;   hz: [h, x] -> sigmoid, STORE into the z buffer (never touched by the fused launch);
+ *   hq: [r*h, x] -> GRU epilogue with res == h, aux == hz's destination.
+ * The kernel arguments travel by value (no device descriptors).  *_eligible: 1 when the descriptors are such layers (then the fused
+ * launch equals the demfi_conv2d launches up to the summation order of the fp32 accumulators), else 0. */
+int demfi_gru_r_eligible(const demfi_conv* hr);
+int demfi_gru_r(const demfi_conv* hr, void* stream);
+int demfi_gru_zq_eligible(const demfi_conv* hz, const demfi_conv* hq);
+int demfi_gru_zq(const demfi_conv* hz, const demfi_conv* hq, void* stream);
 
 /* pixel_reshuffle(cat(B0,B1,B-1,B2), 2) (DeMFInet.py:234-235, 290-316): x fp32 [3,4,H,W] (C,T order of the
  * module input, batch 1) -> fat NHWC [H/2, W/2, 48], channel = (frame*3 + c)*4 + ry*2 + rx. */
@@ -393,7 +408,9 @@ typedef struct demfi_hparams {           /* DeMFInet.py:17-21, 32, 42, 326, 328;
 enum demfi_op_kind {
     DEMFI_OP_CONV = 0, DEMFI_OP_PACK = 1, DEMFI_OP_S2D = 2, DEMFI_OP_OVERLAY = 3, DEMFI_OP_FGAC = 4, DEMFI_OP_GATE = 5,
     DEMFI_OP_CFR = 6, DEMFI_OP_WARP = 7, DEMFI_OP_FGAC_WINDOW = 8, DEMFI_OP_AVG_POOL = 9,
-    DEMFI_OP_RESBLOCK = 10      /* fused residual block: conv = descriptor of conv1, nch = descriptor of conv2 (demfi_resblock3x3_c64) */
+    DEMFI_OP_RESBLOCK = 10,     /* fused residual block: conv = descriptor of conv1, nch = descriptor of conv2 (demfi_resblock3x3_c64) */
+    DEMFI_OP_GRU_R = 11,        /* reset gate of a SepConvGRU half-step: conv = descriptor of convr (demfi_gru_r)                        */
+    DEMFI_OP_GRU_ZQ = 12        /* update gate + candidate + blend: conv = descriptor of convz, nch = descriptor of convq (demfi_gru_zq) */
 };
 enum demfi_segment { DEMFI_SEG_TRUNK = 0, DEMFI_SEG_T_HEAD = 1, DEMFI_SEG_ITER = 2,     /* TRUNK: ops 0, 1 = s2d, overlay (the prologue demfi_ingest_u8 replaces) */
                      DEMFI_SEG_TB_HEAD = 3, DEMFI_SEG_TB_ITER = 4 };                     /* the batched per-t plan of demfi_forward_tb (context index ignored) */

@@ -203,6 +203,23 @@ class PlanSim:
                 self.conv(d1)
                 self.conv(d2)
                 self.reg.pop()
+            elif k == 11:                                                  # round 6: reset gate of a GRU half-step == its convolution
+                self.conv(e.conv_desc(op.conv))
+            elif k == 12:
+                # z + q + blend in one launch == convz (sigmoid) then convq (GRU epilogue) with z in PRIVATE memory: the fused kernel
+                # hands z over through LDS and never touches the plan's z buffer, which has no memory of its own under the arena
+                dz = L.Conv.from_buffer_copy(bytes(e.conv_desc(op.conv)))
+                dq = L.Conv.from_buffer_copy(bytes(e.conv_desc(op.nch)))
+                sz, sq = dz.segs[dz.sub_seg[0]], dq.segs[dq.sub_seg[0]]
+                assert sq.aux.ptr == sz.dst.ptr and sz.dst.sx == 64 and sz.dst.sy == dz.W * 64
+                tmp = torch.zeros(dz.batch * dz.H * dz.W * 64 + 64, dtype=torch.float16)
+                self.reg.append((tmp.data_ptr(), tmp.numel() * tmp.element_size(), tmp))
+                for v in (sz.dst, sq.aux):
+                    v.ptr = tmp.data_ptr()
+                    v.sb = dz.H * dz.W * 64
+                self.conv(dz)
+                self.conv(dq)
+                self.reg.pop()
             elif k == 1:                                                   # pack planar fp32 planes -> NHWC slice
                 dst = self.strided(op.o, op.nch, H, W)
                 for c in range(op.nch):

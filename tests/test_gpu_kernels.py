@@ -522,6 +522,63 @@ def test_sep_gru_persistent_kernel(kh, kw, H, W, batch):
     assert (nchw(hn) - ((1 - nchw(zb)) * nchw(h) + nchw(zb) * qv)).abs().max() < 1e-2
 
 
+@pytest.mark.parametrize('kh,kw', [(1, 5), (5, 1)])
+@pytest.mark.parametrize('H,W,batch', [(8, 32, 1), (37, 75, 2), (64, 96, 1), (100, 45, 1), (33, 8, 3), (16, 160, 1), (96, 64, 2)])
+def test_gru_half_step_r_then_zq(kh, kw, H, W, batch):
+    """Round 6 (gru.hip): a SepConvGRU half-step (DeMFInet.py:844-849 / 851-856) as  r*h  (demfi_gru_r) and  z + q + blend  in one launch
+    (demfi_gru_zq; z stays on chip).  Checked against fp32 torch on the same fp16 operands and against the round-5 path (the same three
+    layers through demfi_conv2d: equal up to the summation order of the fp32 accumulators).  Ragged tiles in both directions, batch > 1,
+    tiles that straddle the image along the filter axis (lines) and across it (pixels)."""
+    torch.manual_seed(23 + kh)
+    pl = Plan(H, W, torch.float16, DEV)
+    h, xx = pl._fat(H, W, 64, batch), pl._fat(H, W, 64, batch)
+    h.copy_(torch.tanh(torch.randn(h.shape, device=DEV)))
+    xx.copy_(torch.randn(xx.shape, device=DEV))
+    zb, rh, hn = pl._fat(H, W, 64, batch), pl._fat(H, W, 64, batch), pl._fat(H, W, 64, batch)
+    rh2, hn2 = pl._fat(H, W, 64, batch), pl._fat(H, W, 64, batch)
+    wz, wr, wq = (torch.randn(64, 128, kh, kw) * 0.05 for _ in range(3))
+    bz, br, bq = (torch.randn(64) * 0.1 for _ in range(3))
+    seg = []
+    pl.conv(seg, 'r', [pl.fsrc(h, 0), pl.fsrc(xx, 64)], [_Dst(pl.fview(rh), range(64), mode=L.MODE_MUL, res=pl.fview(h))],
+            H, W, batch=batch, weight=wr, bias=br)
+    pl.conv(seg, 'z', [pl.fsrc(h, 0), pl.fsrc(xx, 64)], [_Dst(pl.fview(zb), range(64), L.ACT_SIGMOID)], H, W, batch=batch, weight=wz, bias=bz)
+    pl.conv(seg, 'q', [pl.fsrc(rh, 0), pl.fsrc(xx, 64)],
+            [_Dst(pl.fview(hn), range(64), mode=L.MODE_GRU, res=pl.fview(h), aux=pl.fview(zb))], H, W, batch=batch, weight=wq, bias=bq)
+    # the same layers writing other buffers: the round-5 path (demfi_conv2d)
+    pl.conv(seg, 'r', [pl.fsrc(h, 0), pl.fsrc(xx, 64)], [_Dst(pl.fview(rh2), range(64), mode=L.MODE_MUL, res=pl.fview(h))],
+            H, W, batch=batch, weight=wr, bias=br)
+    pl.conv(seg, 'q', [pl.fsrc(rh2, 0), pl.fsrc(xx, 64)],
+            [_Dst(pl.fview(hn2), range(64), mode=L.MODE_GRU, res=pl.fview(h), aux=pl.fview(zb))], H, W, batch=batch, weight=wq, bias=bq)
+    pl._upload()
+    assert pl.lib.demfi_gru_r_eligible(C.byref(pl._descs[0])) == 1
+    assert pl.lib.demfi_gru_zq_eligible(C.byref(pl._descs[1]), C.byref(pl._descs[2])) == 1
+    assert pl.lib.demfi_gru_zq_eligible(C.byref(pl._descs[0]), C.byref(pl._descs[2])) == 0          # r is not an update gate
+    assert pl.lib.demfi_gru_r_eligible(C.byref(pl._descs[1])) == 0
+    for rep in range(2):                                   # twice: the launches leave no state behind
+        zb.fill_(7.0); rh.zero_(); hn.zero_()
+        pl.launch_gru_r(0, _stream())
+        pl.launch_gru_zq(1, 2, _stream())
+    torch.cuda.synchronize()
+    assert float(zb.min()) == 7.0                           # the fused launch never touches the z buffer
+    F = torch.nn.functional
+    nchw = lambda t: t.permute(0, 3, 1, 2).float().cpu()
+    q16 = lambda z: z.half().float()
+    pad = (kh // 2, kw // 2)
+    hx = torch.cat([nchw(h), nchw(xx)], 1)
+    r = torch.sigmoid(F.conv2d(hx, q16(wr), br, padding=pad))
+    assert (nchw(rh) - r * nchw(h)).abs().max() < 4e-3
+    z = q16(torch.sigmoid(F.conv2d(hx, q16(wz), bz, padding=pad)))                       # z is handed over as fp16
+    qv = torch.tanh(F.conv2d(torch.cat([nchw(rh), nchw(xx)], 1), q16(wq), bq, padding=pad))
+    assert (nchw(hn) - ((1 - z) * nchw(h) + z * qv)).abs().max() < 4e-3
+    # against the round-5 launches on the same operands
+    pl.launch_conv(1, _stream())                            # z -> zb
+    pl.launch_conv(3, _stream())                            # r*h -> rh2
+    pl.launch_conv(4, _stream())                            # -> hn2
+    torch.cuda.synchronize()
+    assert (rh.float() - rh2.float()).abs().max() < 2e-3
+    assert (hn.float() - hn2.float()).abs().max() < 4e-3
+
+
 # ------------------------------------------------------------------------------------------------------
 # warps: fixtures from the reference + bit-identical integer maps
 # ------------------------------------------------------------------------------------------------------

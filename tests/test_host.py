@@ -42,7 +42,7 @@ def test_library_exports_every_declared_symbol():
     lib = L.load()
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.demfi_abi_version() == L.ABI_VERSION == 7
+    assert lib.demfi_abi_version() == L.ABI_VERSION == 8
     assert C.sizeof(L.Batch) == 8 + 4 * 8 + 32 * 8
     assert C.sizeof(L.View) == 48 and C.sizeof(L.Piece) == 64 and C.sizeof(L.Chunk) == 24 and C.sizeof(L.Seg) == 168
 

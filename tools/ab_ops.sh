@@ -20,7 +20,7 @@ try:
     for l in open(ops):
         f = l.split()
         if len(f) >= 4:
-            acc[f[2] if f[1] in ('conv', 'resblock') else f[1]].append(float(f[3]) / (float(f[7][3:]) if len(f) > 7 and f[1] == 'warp_fat' else 1.0))
+            acc[f[2] if f[1] in ('conv', 'resblock', 'gru_r', 'gru_zq') else f[1]].append(float(f[3]) / (float(f[7][3:]) if len(f) > 7 and f[1] == 'warp_fat' else 1.0))
             segsum[f[0]] += float(f[3])
 except OSError:
     pass
@@ -31,7 +31,7 @@ try:
 except Exception as e:
     head = 'bench failed: %s' % e
 sel = ['warp_fat', 'warp_thin', 'pack', 'cfr', 'fgac', 'Dec_last2', 'Dec_last2_2', 'Booster_Module.flow_occ.conv2', 'Decoder_res.0.conv1',
-       'Decoder_res.0.conv2', 'Decoder_res.0', 'Decoder_res_2.0', 'Booster_Module.GB.convzr1', 'Booster_Module.GB.convq1', 'Ch_Reducer', 'Refine_Module.enc1#t']
+       'Decoder_res.0.conv2', 'Decoder_res.0', 'Decoder_res_2.0', 'Booster_Module.GB.convzr1', 'Booster_Module.GB.convq1', 'Booster_Module.GB.convr1', 'Booster_Module.GB.step1.convzq', 'Booster_Module.GB.convr2', 'Booster_Module.GB.step2.convzq', 'Ch_Reducer', 'Refine_Module.enc1#t']
 short = lambda k: k.split('.')[-1] if k.count('.') > 1 else k
 print('[%s] %s' % (tag or 'product', head))
 print('    ' + '  '.join('%s %.4f x%d' % (short(k), sum(acc[k]) / len(acc[k]), len(acc[k])) for k in sel if acc[k]))
