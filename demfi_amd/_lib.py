@@ -64,7 +64,7 @@ class ConvDst(C.Structure):
 
 class HParams(C.Structure):
     _fields_ = [('nf', C.c_int32), ('scale_factor', C.c_int32), ('num_resb_facfb', C.c_int32), ('num_resb_dec', C.c_int32),
-                ('shared_fgac', C.c_int32), ('fgac_rr', C.c_int32), ('fgac_sr', C.c_int32), ('_pad', C.c_int32)]
+                ('shared_fgac', C.c_int32), ('fgac_rr', C.c_int32), ('fgac_sr', C.c_int32), ('flags', C.c_int32)]
 
 
 class Batch(C.Structure):
@@ -117,6 +117,10 @@ _SIGS = {
     'demfi_fgac_window': (C.c_int, [C.POINTER(View), C.POINTER(View), C.c_void_p, C.POINTER(View), C.c_int, C.c_int, C.c_int,
                                     C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     'demfi_avg_pool_fat': (C.c_int, [C.POINTER(View), C.POINTER(View), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    'demfi_absmean_map': (C.c_int, [C.POINTER(View), C.POINTER(View), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    'demfi_minmax_scratch_floats': (C.c_int64, []),
+    'demfi_minmax_normalize': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    'demfi_one_minus': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     'demfi_gate_blend': (C.c_int, [C.c_void_p, C.POINTER(View), C.POINTER(View), C.POINTER(View), C.c_int, C.c_int,
                                    C.c_int, C.c_void_p]),
     'demfi_pack_planes': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p]),

@@ -12,6 +12,7 @@ SRCS_CPP="abi.cpp"
 [ -f fgac_window.hip ] && SRCS_HIP="$SRCS_HIP fgac_window.hip"
 [ -f resblock.hip ] && SRCS_HIP="$SRCS_HIP resblock.hip"
 [ -f gru.hip ] && SRCS_HIP="$SRCS_HIP gru.hip"
+[ -f viz.hip ] && SRCS_HIP="$SRCS_HIP viz.hip"
 [ -f ctx.cpp ] && SRCS_CPP="$SRCS_CPP ctx.cpp"
 [ -f png_codec.cpp ] && SRCS_CPP="$SRCS_CPP png_codec.cpp"
 # stale objects must never be linked: a failed compile has to fail the build
@@ -54,4 +55,22 @@ if [ "$1" = "--ablation" ]; then
   for o in "${objs[@]}"; do [ "$o" = conv.o ] && abl+=(conv_abl.o) || abl+=("$o"); done
   $HIPCC --offload-arch=gfx950 -shared -fPIC "${abl[@]}" -o libdemfi_hip_abl.so -lz -lpthread
   echo "built $(pwd)/libdemfi_hip_abl.so"
+fi
+# --asan: host-side AddressSanitizer + UBSan build: the three host translation units -- the plan builder / arena
+# planner / op interpreter (ctx.cpp), the ABI glue (abi.cpp) and the PNG codec that parses untrusted bytes (png_codec.cpp) --
+# instrumented, linked with the ordinary kernel objects.  Run with tools/asan_check.sh (preloads the sanitizer runtime under python).
+if [ "$1" = "--asan" ]; then
+  # pointer-overflow is off on purpose: the sizing pass of demfi_ctx_create lays the plan out on a NULL base (addresses == workspace offsets)
+SAN="-O1 -g -fsanitize=address,undefined -fno-sanitize=pointer-overflow -fno-gpu-sanitize -fno-omit-frame-pointer -shared-libsan -fno-sanitize-recover=undefined"
+  aso=()
+  for o in "${objs[@]}"; do
+    case "$o" in
+      ctx.o|abi.o|png_codec.o)
+        $HIPCC --offload-arch=gfx950 -std=c++17 -fPIC -ffp-contract=off -I../../include -Wno-unused-result $SAN -x hip -c "${o%.o}.cpp" -o "${o%.o}_asan.o"
+        aso+=("${o%.o}_asan.o") ;;
+      *) aso+=("$o") ;;
+    esac
+  done
+  $HIPCC --offload-arch=gfx950 -shared -fPIC -fsanitize=address,undefined -shared-libsan "${aso[@]}" -o libdemfi_hip_asan.so -lz -lpthread
+  echo "built $(pwd)/libdemfi_hip_asan.so"
 fi

@@ -475,6 +475,12 @@ void alloc_trunk(Layout& L, BufSet& s)
     L.thin(s, "gate", 2, H, W);
     L.fat(s, "aF", H, W, 64, 2);
     L.thin(s, "overlay", 3, H, W);
+    if (L.c->hp.flags & DEMFI_HP_EXTRAS) {
+        // per FGAC direction b (0: F1 -> F0, 1: F0 -> F1), planes 6 b + {0: 1 - w_sr, 1: source_v, 2: init_ref_k, 3: E_s, 4: bolstered_F_s,
+        // 5: diff}: the min-max normalised channel means of DeMFInet.py:454-494 (w_sr itself is the "gate" buffer)
+        L.thin(s, "viz", 12, H, W);
+        L.thin(s, "vizs", 1, 1, (int)demfi_minmax_scratch_floats());
+    }
     if (L.c->dtype == DEMFI_F16) {
         L.fat(s, "u1a", H2, W2, 64);                // t-independent part of Refine_Module.enc1 (see build_trunk)
         L.fat(s, "xff16", H, W, 16);                // window-constant planes of the Mixer / D2 inputs: 4 frames x 3 colours | flow_10, flow_01
@@ -1074,7 +1080,7 @@ struct Builder {
                     rkn = "rkp"; skn = "skp";
                 }
                 demfi_op o = blank();
-                o.nch = 64; o.conv = c->hp.fgac_rr; o._pad = c->hp._pad;
+                o.nch = 64; o.conv = c->hp.fgac_rr; o._pad = c->hp.flags & DEMFI_HP_FGAC_CENTRED;
                 o.a = fview(B[rkn], 0, b); o.b = fview(B[skn], 0, b); o.o = fview(B["smp"], 0, b);
                 o.p[0] = ptr(B["ffo"]) + (b == 0 ? 0 : 2) * hw4;
                 simple(tr, DEMFI_OP_FGAC_WINDOW, "fgac_window", o);
@@ -1094,6 +1100,25 @@ struct Builder {
                 o.a = fview(*enc, 0, b); o.b = fview(B["E"], 0, b); o.o = fview(B["aF"], 0, b);
                 o.p[0] = ptr(B["gate"]) + b * hw4;
                 simple(tr, DEMFI_OP_GATE, "gate", o);
+            }
+            if (c->hp.flags & DEMFI_HP_EXTRAS) {
+                // the maps FGAC.forward returns besides its output (DeMFInet.py:454-496): diff (always computed by the reference, returned
+                // in the training / visualisation tuples of DeMFInet.forward 167-176) and the four visualisation maps + (1 - w_sr)
+                auto vz = [&](int k) { return ptr(B["viz"]) + (6 * b + k) * hw4; };
+                auto absmean = [&](int k, demfi_view a, demfi_view bb) {
+                    demfi_op o = blank();
+                    o.conv = 0; o.nch = 64; o.a = a; o.b = bb; o.p[0] = vz(k);
+                    simple(tr, DEMFI_OP_VIZ, "viz_absmean", o);
+                    demfi_op n = blank();
+                    n.conv = 1; n.p[0] = vz(k); n.p[1] = ptr(B["vizs"]);
+                    simple(tr, DEMFI_OP_VIZ, "viz_normalize", n);
+                };
+                { demfi_op o = blank(); o.conv = 2; o.p[0] = vz(0); o.p[1] = ptr(B["gate"]) + b * hw4; simple(tr, DEMFI_OP_VIZ, "viz_one_minus", o); }
+                absmean(1, fview(*enc, 0, src), NOVIEW);                    // source_v
+                absmean(2, fview(B["rk"], 0, b), NOVIEW);                   // init_ref_k = conv_ref_k(ref)
+                absmean(3, fview(B["E"], 0, b), NOVIEW);                    // E_s
+                absmean(4, fview(B["aF"], 0, b), NOVIEW);                   // bolstered_F_s
+                absmean(5, fview(B["aF"], 0, b), fview(*enc, 0, src));      // diff = bolstered_F_s - source_v
             }
         }
         if (c->dtype == DEMFI_F16) {
@@ -1472,6 +1497,7 @@ void op_accesses(const demfi_ctx* c, const demfi_op& op, std::vector<std::pair<c
         break;
     }
     case DEMFI_OP_PACK: for (int i = 0; i < 32; ++i) rd(op.p[i]); wr(op.o.ptr); break;
+    case DEMFI_OP_VIZ: rd(op.a.ptr); rd(op.b.ptr); rd(op.p[1]); if (op.conv == 1) { rd(op.p[0]); wr(op.p[1]); } wr(op.p[0]); break;
     case DEMFI_OP_S2D: case DEMFI_OP_OVERLAY: rd(op.p[0]); wr(op.p[1]); break;
     case DEMFI_OP_FGAC: rd(op.a.ptr); rd(op.p[0]); wr(op.o.ptr); break;
     case DEMFI_OP_FGAC_WINDOW: rd(op.a.ptr); rd(op.b.ptr); rd(op.p[0]); wr(op.o.ptr); break;
@@ -1691,8 +1717,8 @@ extern "C" int demfi_ctx_create(int H, int W, int max_updates, int dtype, const 
     if (h.num_resb_facfb < 0 || h.num_resb_dec < 0 || h.num_resb_facfb > 32 || h.num_resb_dec > 32)
         return demfi_set_error(DEMFI_ERR_ARG, "demfi_ctx_create: residual block counts");
     // fgac_rr / fgac_sr: the radii hard-coded to 0 at DeMFInet.py:401-402; > 0 selects the generalised window FGAC
-    // (demfi_fgac_window, both path dtypes; h._pad = index map: 0 reference code, 1 pixel-centred window)
-    if (h.fgac_rr < 0 || h.fgac_rr > 2 || h.fgac_sr < 0 || h.fgac_sr > 4 || (h._pad != 0 && h._pad != 1))
+    // (demfi_fgac_window, both path dtypes; flags bit 0 = index map: 0 reference code, 1 pixel-centred window)
+    if (h.fgac_rr < 0 || h.fgac_rr > 2 || h.fgac_sr < 0 || h.fgac_sr > 4 || (h.flags & ~(DEMFI_HP_FGAC_CENTRED | DEMFI_HP_EXTRAS)))
         return demfi_set_error(DEMFI_ERR_ARG, "demfi_ctx_create: fgac_rr in 0..2, fgac_sr in 0..4, map in {0,1}");
     if (h.fgac_rr == 0 && h.fgac_sr != 0)
         return demfi_set_error(DEMFI_ERR_ARG, "demfi_ctx_create: fgac_sr > 0 needs fgac_rr > 0 (the pooled point-wise form is not built)");
@@ -1993,6 +2019,11 @@ extern "C" int demfi_run_op(demfi_ctx* c, const demfi_op* op, void* stream)
         if (op->bt.nb > 1)
             return demfi_pack_planes_batched((const float* const*)op->p, op->nch, op->o.ptr, c->dtype, op->o.sx, H, W, &op->bt, stream);
         return demfi_pack_planes((const float* const*)op->p, op->nch, op->o.ptr, c->dtype, op->o.sx, H, W, stream);
+    case DEMFI_OP_VIZ:
+        if (op->conv == 0) return demfi_absmean_map(&op->a, op->b.ptr ? &op->b : nullptr, (float*)op->p[0], op->nch, H, W, stream);
+        if (op->conv == 1) return demfi_minmax_normalize((float*)op->p[0], (int64_t)H * W, (float*)op->p[1], stream);
+        if (op->conv == 2) return demfi_one_minus((const float*)op->p[1], (float*)op->p[0], (int64_t)H * W, stream);
+        return demfi_set_error(DEMFI_ERR_ARG, "demfi_run_op: visualisation sub-op %d", op->conv);
     case DEMFI_OP_S2D:
         return demfi_space_to_depth((const float*)op->p[0], (void*)op->p[1], c->dtype, H, W, stream);
     case DEMFI_OP_OVERLAY:

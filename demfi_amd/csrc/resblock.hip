@@ -562,7 +562,13 @@ bool rb_layer_ok(const demfi_conv* h)
     if (!p.fat || p.nch != 64 || p.up_shift != 0 || !p.v.ptr || p.v.is_f32 || p.v.sc != 1) return false;
     const int sg = h->sub_seg[0];
     if (sg < 0 || h->sub_seg[1] != sg || h->oct_ch[4] != h->oct_ch[0] + 32) return false;
+    // exactly what the fused kernel reproduces and nothing it would silently drop: ONE segment that owns all eight octets
+    // as one run of 64 channels, no packed copy, no uint8 sink, no aux view
+    if (h->n_segs != 1 || h->pack.ptr || h->u8_sink) return false;
+    for (int o = 0; o < 8; ++o)
+        if (h->oct_seg[o] != sg || h->oct_n[o] != 8 || h->oct_ch[o] != h->oct_ch[0] + 8 * o) return false;
     const demfi_seg& seg = h->segs[sg];
+    if (seg.aux.ptr) return false;
     if (seg.mode != DEMFI_MODE_STORE || seg.scale != 1 || seg.dy || seg.dx || !seg.dst.ptr || seg.dst.is_f32 || seg.dst.sc != 1) return false;
     return true;
 }

@@ -11,10 +11,11 @@ import torch.distributed as dist
 _ACTIVE = False
 
 
-def init(world, rank, local_rank=0, backend=None):
-    """Initialise the process group when world > 1 (env:// rendezvous, MASTER_ADDR should be 127.0.0.1)."""
+def init(world, rank, local_rank=0, backend=None, force=False):
+    """Initialise the process group when world > 1 (env:// rendezvous, MASTER_ADDR should be 127.0.0.1).  force: also for a world of
+    one -- every collective below then really runs (tests/test_gpu_dist.py drives the RCCL code path on a single-GPU box that way)."""
     global _ACTIVE
-    if world <= 1:
+    if world <= 1 and not force:
         return False
     if not dist.is_initialized():
         backend = backend or ('nccl' if torch.cuda.is_available() else 'gloo')
@@ -41,7 +42,7 @@ def broadcast_weights(engine, world, src=0):
     """One flat broadcast of the already-repacked weight/bias blob of an engine (~15 MB fp16 / 30 MB fp32).  Only the
     ENGINE's copy changes: a model whose parameters are not also synchronised would repack zeros the next time it builds
     an engine -- use ``broadcast_state_dict`` for models (bench.py, ClipRunner launches)."""
-    if world <= 1 or not active():
+    if not active():
         return
     dist.broadcast(engine.weight_blob, src=src)
 
@@ -50,7 +51,7 @@ def broadcast_state_dict(model, world, src=0, device=None):
     """ONE flat broadcast (RCCL over xGMI on the GPU box, gloo in the CPU tests) of all 260 parameter tensors
     (7 408 284 fp32 = 29.6 MB) from rank ``src``; every rank then holds the real state_dict, so any engine it builds later
     (another frame size, more contexts) packs the right weights.  Bumps the model's weights version."""
-    if world <= 1 or not active():
+    if not active():
         return
     params = [p for _, p in sorted(model.state_dict().items())]
     dev = device or params[0].device

@@ -204,7 +204,7 @@ class Plan:
 SEG_TRUNK, SEG_HEAD, SEG_ITER, SEG_TB_HEAD, SEG_TB_ITER = 0, 1, 2, 3, 4
 KIND_NAME = {0: 'conv', 1: 'pack', 2: 's2d', 3: 'overlay', 4: 'fgac', 5: 'gate', 6: 'cfr', 7: 'warp', 8: 'fgac_window', 9: 'avg_pool',
              10: 'resblock',        # resblock: ONE launch for conv1 -> ReLU -> conv2 + identity (op.conv / op.nch = the two descriptors)
-             11: 'gru_r', 12: 'gru_zq'}   # round 6: SepConvGRU half-step as r*h, then z + q + blend in one launch (op.conv / op.nch = convz / convq)
+             11: 'gru_r', 12: 'gru_zq', 13: 'viz'}   # round 6: SepConvGRU half-step as r*h, then z + q + blend in one launch (op.conv / op.nch = convz / convq)
 
 
 class Engine:
@@ -230,7 +230,8 @@ class Engine:
             raise NotImplementedError('the HIP path is built for nf=64, scale_factor=2 (the released configuration)')
         chp = L.HParams(self.hp.nf, self.hp.scale_factor, self.hp.num_ResB_FACFB, self.hp.num_ResB_Dec,
                         1 if self.hp.shared_FGAC_flag else 0, getattr(self.hp, 'fgac_rr', 0), getattr(self.hp, 'fgac_sr', 0),
-                        getattr(self.hp, 'fgac_map', 0))
+                        (1 if getattr(self.hp, 'fgac_map', 0) else 0) | (2 if getattr(self.hp, 'extras', False) else 0))
+        self.extras = bool(getattr(self.hp, 'extras', False))
         self._ctx = C.c_void_p()
         self._n_trunk, self._n_ctx = max(1, n_trunk), max(1, n_ctx)
         L.check(self.lib.demfi_ctx_create(H, W, max_updates, self.dt, C.byref(chp), self._n_trunk, self._n_ctx,
@@ -288,8 +289,11 @@ class Engine:
 
     def _trunk_dict(self, k):
         H, W = self.H, self.W
-        return {'x': self.buffer('x', k).view(3, 4, H, W), 'overlay': self.buffer('overlay', k), 'ffo': self.buffer('ffo', k),
-                'aF': self.buffer('aF', k), 'F01': self.buffer('F01', k)}
+        d = {'x': self.buffer('x', k).view(3, 4, H, W), 'overlay': self.buffer('overlay', k), 'ffo': self.buffer('ffo', k),
+             'aF': self.buffer('aF', k), 'F01': self.buffer('F01', k), 'gate': self.buffer('gate', k)}
+        if self.extras:                                       # maps of the visualisation / training return tuples (DEMFI_HP_EXTRAS)
+            d['viz'] = self.buffer('viz', k).view(2, 6, H, W)
+        return d
 
     def _ctx_dict(self, k, c):
         H, W, N = self.H, self.W, self.N
@@ -418,6 +422,12 @@ class Engine:
         flat = [(sname, op) for sname, ops in segs for op in ops]
         tot = [0.0] * len(flat)
         if isolated:
+            # under the workspace arena an op replayed out of plan order reads memory later tenants have recycled (wrong access
+            # patterns, possibly NaNs): the isolated loop is only meaningful on the unaliased layout
+            import os
+            if os.environ.get('DEMFI_ARENA', '1') != '0':
+                raise RuntimeError('Engine.profile(isolated=True) replays single ops out of plan order: run it with DEMFI_ARENA=0 '
+                                   '(one memory region per buffer); the default in-sequence profile needs nothing')
             for i, (_, op) in enumerate(flat):
                 self.run_op(op, h)
                 for _ in range(reps):

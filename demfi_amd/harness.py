@@ -17,6 +17,10 @@ def reflect_pad_to_multiple(x, multiple=32):
         return x
     if not x.is_cuda:
         raise RuntimeError('demfi_amd.harness: GPU tensor required (HIP-only path)')
+    if B > 1 and x.stride(0) == 0:
+        # ONE window stacked as a stride-0 batch (what a x M caller passes): pad it once and keep the stride-0 layout, which is how
+        # DeMFInet.forward recognises a same-window batch (trunk once + the batched per-t plan) without reading the input
+        return reflect_pad_to_multiple(x[0:1], multiple).expand(B, -1, -1, -1, -1)
     x = x.contiguous().float()
     out = torch.empty((B, Cc, T, h + ph, w + pw), dtype=torch.float32, device=x.device)
     st = torch.cuda.current_stream(x.device).cuda_stream
@@ -24,12 +28,18 @@ def reflect_pad_to_multiple(x, multiple=32):
     return out
 
 
-def pad_forward_crop(model, x, t_value, num_update, multiple=32):
-    """Returns the model's 5-tuple cropped to the input size (utils.py:1452-1476)."""
+def pad_forward_crop(model, x, t_value, num_update, multiple=32, is_training=None, same_window=None):
+    """Returns the model's return tuple (the 5-tuple of DeMFInet.py:178, or the 7-tuples of the visualisation / training branches)
+    with every map cropped to the input size (utils.py:1452-1476).  A batch of ONE window at several t: pass it as
+    ``x.expand(B, ...)`` (kept stride-0 through the pad) or say ``same_window=True`` -- the trunk then runs once."""
     h, w = x.shape[-2:]
-    d1, fin, flows, occs, ov = model(reflect_pad_to_multiple(x, multiple), t_value, num_update)
-    cr = lambda z: z[..., :h, :w]
-    return ([cr(z) for z in d1], [[cr(z) for z in f] for f in fin], [cr(z) for z in flows], [cr(z) for z in occs], cr(ov))
+    out = model(reflect_pad_to_multiple(x, multiple), t_value, num_update, is_training, same_window=same_window)
+
+    def crop(z):
+        if torch.is_tensor(z):
+            return z[..., :h, :w]
+        return [crop(y) for y in z]
+    return tuple(crop(z) for z in out)
 
 
 def t_schedule(multiple_mfi):

@@ -4,7 +4,9 @@ Drop-in for /root/reference/DeMFInet.py:13-179 at inference: same constructor ar
 scale_factor, num_ResB_FACFB, num_ResB_Dec, shared_FGAC_flag, visualization_flag``), the same 260
 ``state_dict`` keys / shapes so ``load_state_dict(ckpt['state_dict_Model'])``
 (main.py:316,351) works unchanged, the same ``forward(x, t_value, num_update=None, is_training=None)``
-signature and the same 5-tuple return structure (DeMFInet.py:178).  The body is not PyTorch: forward
+signature and the same return structures: the 5-tuple of DeMFInet.py:178, with ``args.visualization_flag`` the 7-tuple of 174-176
+(+ blending_weights, difference_maps: FGAC's gates and min-max normalised channel-mean maps, 454-496) and with ``is_training`` the
+7-tuple of 170-172 (+ difference_maps, flow_t0_t1_predictions) -- the numbers of the inference forward, no autograd graph.  The body is not PyTorch: forward
 hands ``x`` to ``demfi_amd.engine.Engine`` which launches the gfx950 kernels of ``libdemfi_hip.so``.
 There is no CPU / eager fallback: without a GPU or without the built library forward raises.
 
@@ -63,7 +65,7 @@ class DeMFInet(nn.Module):
         self._engines = {}
         self._weights_version += 1
 
-    def engine(self, H, W, num_update, n_ctx=1, n_trunk=1, exact_ctx=False):
+    def engine(self, H, W, num_update, n_ctx=1, n_trunk=1, exact_ctx=False, extras=False):
         """Engine for a frame size (built on first use: weight repack + buffer allocation).  n_ctx: independent per-t
         buffer sets (WindowRunner batches / overlaps the time instants of a window over them); exact_ctx: the batched plan
         covers ALL per-t contexts of an engine, so a cached engine with more of them does not do.  Two cache slots per
@@ -73,7 +75,8 @@ class DeMFInet(nn.Module):
         if not torch.cuda.is_available():
             raise RuntimeError('demfi_amd.DeMFInet.forward needs an MI355X: the forward path is HIP-only '
                                '(no CPU fallback)')
-        key = (H, W, self.path_dtype)
+        extras = bool(extras or self.hp.extras)
+        key = (H, W, self.path_dtype) + (('extras',) if extras else ())
         eng = self._engines.get(key)
         if exact_ctx:
             if eng is not None and eng.N >= num_update and eng.n_ctx == n_ctx:
@@ -84,18 +87,54 @@ class DeMFInet(nn.Module):
             self._engines.pop(key, None)                           # release the old workspace before the new one is allocated
             del eng
             sd = {k: v.detach() for k, v in self.state_dict().items()}
-            eng = Engine(sd, H, W, self.path_dtype, self.device, max(num_update, 3), self.hp, n_ctx=n_ctx, n_trunk=n_trunk)
+            hp = self.hp
+            if extras and not hp.extras:
+                import copy
+                hp = copy.copy(self.hp)
+                hp.extras = True
+            eng = Engine(sd, H, W, self.path_dtype, self.device, max(num_update, 3), hp, n_ctx=n_ctx, n_trunk=n_trunk)
             self._engines[key] = eng
         return eng
 
-    def _collect(self, eng, n, clone):
+    def _collect(self, eng, n, clone, extras=False):
         c = (lambda z: z.clone()) if clone else (lambda z: z)
         H, W = eng.H, eng.W
         d1 = [c(eng.sharp1[3 * i:3 * i + 3].unsqueeze(0)) for i in range(3)]
         fin = [[c(eng.finals[it, i].unsqueeze(0)) for i in range(3)] for it in range(n)]
         flows = [c(eng.delta[i, 0:4].unsqueeze(0)) for i in range(n + 1)]
         occs = [c(eng.occ[i:i + 1].unsqueeze(0)) for i in range(n + 1)]
-        return d1, fin, flows, occs, c(eng.overlay.unsqueeze(0))
+        out = (d1, fin, flows, occs, c(eng.overlay.unsqueeze(0)))
+        if extras:
+            # FGAC's extra returns per direction b (0: F1 -> F0 with flow_01, 1: F0 -> F1 with flow_10; DeMFInet.py:346-349, 495-496):
+            # [w_sr, 1 - w_sr, source_v, init_ref_k, E_s, bolstered_F_s_ch1] and diff -- computed by the HIP plan (DEMFI_OP_VIZ)
+            m = lambda z: c(z.reshape(1, 1, H, W))
+            bw = [[m(eng.gate[b])] + [m(eng.viz[b, k]) for k in range(5)] for b in range(2)]
+            diffs = [m(eng.viz[b, 5]) for b in range(2)]
+            f01, f10 = c(eng.ffo[0:2].unsqueeze(0)), c(eng.ffo[2:4].unsqueeze(0))
+            rft = [c(eng.delta[0, 0:2].unsqueeze(0)), c(eng.delta[0, 2:4].unsqueeze(0))]
+            out = out + ((bw, diffs, [f01, f10], rft),)
+        return out
+
+    def _finish(self, outs, n, is_training):
+        """List of per-item _collect results -> the reference's return structure (DeMFInet.py:167-179)."""
+        cat = lambda xs: xs[0] if len(xs) == 1 else torch.cat(xs, 0)
+        base = ([cat([o[0][i] for o in outs]) for i in range(3)],
+                [[cat([o[1][it][i] for o in outs]) for i in range(3)] for it in range(n)],
+                [cat([o[2][i] for o in outs]) for i in range(n + 1)],
+                [cat([o[3][i] for o in outs]) for i in range(n + 1)],
+                cat([o[4] for o in outs]))
+        if len(outs[0]) == 5:
+            return base
+        bw = [[cat([o[5][0][b][k] for o in outs]) for k in range(6)] for b in range(2)]
+        diffs = [cat([o[5][1][b] for o in outs]) for b in range(2)]
+        difference_maps = [diffs[0], diffs[1], diffs[0], diffs[1]]                          # DeMFInet.py:358
+        if is_training:                                                                      # 170-172
+            return base + (difference_maps, [[cat([o[5][3][i] for o in outs]) for i in range(2)]])
+        if self.hp.visualization_flag:
+            blending_weights = [bw[0], bw[1], bw[0], bw[1], [cat([o[5][2][i] for o in outs]) for i in range(2)]]   # 356-357, 167-168
+        else:                                                                                # FGAC returns the bare gate then (496)
+            blending_weights = [bw[0][0], bw[1][0], bw[0][0], bw[1][0]]
+        return base + (blending_weights, difference_maps)                                    # 174-176
 
     def _check_input(self, x, t_value):
         if x.dim() != 5 or x.shape[1] != 3 or x.shape[2] != 4:
@@ -112,10 +151,10 @@ class DeMFInet(nn.Module):
         same_window (B >= 2): the items are ONE window at B time instants (what a x M caller stacks) -> trunk once + the batched
         per-t plan.  None = detect it from the layout only (a stride-0 ``expand`` along the batch: no device sync, no read of the
         input); True = the caller says so (equal copies); False = never.  Results are bit-identical either way."""
-        if is_training:
-            raise NotImplementedError('training branch (DeMFInet.py:170-172) is outside the inference hot path')
-        if self.hp.visualization_flag:
-            raise NotImplementedError('visualization outputs (DeMFInet.py:174-176) are outside the hot path')
+        # is_training / args.visualization_flag only select a longer return tuple (DeMFInet.py:167-176): the extra members (FGAC's gates,
+        # its min-max normalised channel-mean maps and diff; the first flow pair) come from the same forward.  No autograd graph is built:
+        # this is the inference path's arithmetic.
+        extras = bool(is_training or self.hp.visualization_flag)
         self._check_input(x, t_value)
         n = 1 if num_update is None else int(num_update)          # DeMFInet.py:126-128
         B, _, _, H, W = x.shape
@@ -126,7 +165,7 @@ class DeMFInet(nn.Module):
             # dimension maps onto the batched per-t plan -- trunk once, every convolution of the per-t segment once over
             # batch x B (demfi_forward_tb).  Bit-identical to B separate calls (tests/test_gpu_e2e.py).  Items with different
             # windows need their own trunks and run one after the other below (the clip runner pipelines those).
-            eng = self.engine(H, W, n, n_ctx=B, exact_ctx=True)
+            eng = self.engine(H, W, n, n_ctx=B, exact_ctx=True, extras=extras)
             eng.use_ctx(0, trunk=0)
             eng.x.copy_(x[0].to(torch.float32), non_blocking=True)
             tb = eng._tb_dict(0)
@@ -136,14 +175,22 @@ class DeMFInet(nn.Module):
             eng.run_tb(stream, n)
             for b in range(B):
                 eng.use_ctx(b)
-                outs.append(self._collect(eng, n, True))
+                outs.append(self._collect(eng, n, True, extras))
             eng.use_ctx(0)
         elif B >= 2:
+            if same_window is None and not getattr(self, '_warned_batch', False):
+                # a caller that stacks MATERIALISED copies of one window (torch.stack / repeat instead of expand) lands here:
+                # B trunks and a second engine instead of one trunk + the batched per-t plan.  Results are identical; say it once.
+                import warnings
+                self._warned_batch = True
+                warnings.warn('demfi_amd.DeMFInet.forward: batch of %d with a non-zero batch stride is treated as %d DIFFERENT windows (one trunk '
+                              'each).  If the items are ONE window at several t, pass same_window=True or x.expand(B, ...) to run the trunk once; '
+                              'pass same_window=False to silence this.' % (B, B), stacklevel=2)
             # Items with DIFFERENT windows (DeMFInet.py:51: a real batch dimension): every item needs its own trunk.  They are pipelined
             # over two trunk buffer sets -- the trunk of item b + 1 (small half-resolution launches) runs on a side stream beside the
             # per-t segment of item b -- instead of running strictly one after the other (VERDICT r4 missing #2).  Same launches on the
             # same data: results are bit-identical to B separate calls.
-            eng = self.engine(H, W, n, n_trunk=2)
+            eng = self.engine(H, W, n, n_trunk=2, extras=extras)
             main = torch.cuda.current_stream(x.device)
             side = self._side_stream = getattr(self, '_side_stream', None) or torch.cuda.Stream(device=x.device)
             trunk_done = [torch.cuda.Event() for _ in range(B)]
@@ -167,27 +214,22 @@ class DeMFInet(nn.Module):
                 eng.t_dev.copy_(t_value[b].reshape(-1)[:1].to(torch.float32), non_blocking=True)
                 eng.sink.zero_()
                 eng.run_t(stream, n)
-                outs.append(self._collect(eng, n, True))
+                outs.append(self._collect(eng, n, True, extras))
                 item_done[b].record(main)
             x.record_stream(side)
             eng.use_ctx(0, trunk=0)
         else:
-            eng = self.engine(H, W, n)
+            eng = self.engine(H, W, n, extras=extras)
         for b in range(B if not outs else 0):
             eng.x.copy_(x[b].to(torch.float32), non_blocking=True)
             eng.t_dev.copy_(t_value[b].reshape(-1)[:1].to(torch.float32), non_blocking=True)
             eng.sink.zero_()                        # the uint8 sink of a WindowRunner sharing this engine must not fire
             eng.run_trunk(stream)
             eng.run_t(stream, n)
-            outs.append(self._collect(eng, n, clone_outputs or B > 1))
-        if B == 1:
+            outs.append(self._collect(eng, n, clone_outputs or B > 1, extras))
+        if B == 1 and not extras:
             return outs[0]
-        cat = lambda xs: torch.cat(xs, 0)
-        return ([cat([o[0][i] for o in outs]) for i in range(3)],
-                [[cat([o[1][it][i] for o in outs]) for i in range(3)] for it in range(n)],
-                [cat([o[2][i] for o in outs]) for i in range(n + 1)],
-                [cat([o[3][i] for o in outs]) for i in range(n + 1)],
-                cat([o[4] for o in outs]))
+        return self._finish(outs, n, bool(is_training))
 
     @torch.no_grad()
     def forward_window(self, x, t_values, num_update):

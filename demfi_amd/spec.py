@@ -26,6 +26,9 @@ class HyperParams:
         # radii of the generalised FGAC (function-local constants 0 at DeMFInet.py:401-402) and its index map
         # (0: as the reference code computes it, 1: pixel-centred window) -- extensions, defaults = the released model
         self.fgac_rr, self.fgac_sr, self.fgac_map = fgac_rr, fgac_sr, fgac_map
+        # engine-level switch: also compute the maps of the visualisation / training return tuples (DeMFInet.py:167-176, 454-496);
+        # DeMFInet.forward turns it on for args.visualization_flag and for is_training calls
+        self.extras = bool(visualization_flag)
 
 
 def layer_table(hp=None):

@@ -20,7 +20,15 @@ def _key_seed(seed, key):
 KEY_GAIN = {'Dec_last2.weight': 0.3, 'Dec_last2_2.weight': 0.1}
 
 
-def synthetic_state_dict(seed=0, hp=None, gain=1.0, bias_std=0.02, dtype=torch.float32):
+# output rows that produce flows / occlusion logits: flow_01 | flow_10 | occ_0 of FF_RDB (DeMFInet.py:247-253), the refined flow / occlusion
+# residuals of the UNet (rows 0:5 of dec3, 78-84) and the per-recursion deltas of FlowOcc (860-868)
+FLOW_ROWS = {'FF_RDB_Module.UPNet.2': slice(128, 133), 'Refine_Module.dec3': slice(0, 5), 'Booster_Module.flow_occ.conv2': slice(0, 5)}
+
+
+def synthetic_state_dict(seed=0, hp=None, gain=1.0, bias_std=0.02, dtype=torch.float32, flow_gain=1.0):
+    """flow_gain < 1 (round 6, the second weight regime of the parity fixtures): the layers' rows that emit flows and occlusion logits
+    are scaled down -- small motions (a few pixels instead of +-6..20) and unsaturated occlusion maps, which is what a trained
+    checkpoint looks like; every other tensor is identical to flow_gain = 1."""
     sd = {}
     for key, shape in state_dict_shapes(hp).items():
         g = torch.Generator().manual_seed(_key_seed(seed, key))
@@ -33,6 +41,9 @@ def synthetic_state_dict(seed=0, hp=None, gain=1.0, bias_std=0.02, dtype=torch.f
             sd[key] = (torch.randn(shape, generator=g, dtype=torch.float32) * std).to(dtype)
         else:
             sd[key] = (torch.randn(shape, generator=g, dtype=torch.float32) * bias_std).to(dtype)
+        rows = FLOW_ROWS.get(key.rsplit('.', 1)[0])
+        if rows is not None and flow_gain != 1.0:
+            sd[key][rows] *= flow_gain
     return sd
 
 
@@ -61,10 +72,18 @@ def _numpy_scalar_globals():
 
 
 def _safe_load(path):
+    """torch.load(weights_only=True) with the numpy scalar globals of a reference checkpoint allow-listed.  Only UNPICKLING problems are
+    turned into the "re-save it" advice; a missing / unreadable file raises its own OSError."""
+    import pickle
+    allow = _numpy_scalar_globals()
     try:
-        with torch.serialization.safe_globals(_numpy_scalar_globals()):
-            return torch.load(path, map_location='cpu', weights_only=True)
-    except Exception as e:                                      # pickle.UnpicklingError and friends
+        if hasattr(torch.serialization, 'safe_globals'):            # torch >= 2.5: scoped allow-list
+            with torch.serialization.safe_globals(allow):
+                return torch.load(path, map_location='cpu', weights_only=True)
+        if hasattr(torch.serialization, 'add_safe_globals'):        # torch 2.4: process-wide allow-list
+            torch.serialization.add_safe_globals(allow)
+        return torch.load(path, map_location='cpu', weights_only=True)
+    except (pickle.UnpicklingError, RuntimeError) as e:
         raise ValueError('%s: cannot be read with weights_only=True (%s). Re-save it as {"state_dict_Model": model.state_dict()} '
                          'or a bare state_dict of tensors.' % (path, str(e).splitlines()[0])) from e
 

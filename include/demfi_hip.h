@@ -302,6 +302,15 @@ int demfi_fgac_window(const demfi_view* ref_k, const demfi_view* source_k, const
 /* F.avg_pool2d(x, 2sr+1, stride 1, padding sr) (count_include_pad), fp16 NHWC. */
 int demfi_avg_pool_fat(const demfi_view* src, const demfi_view* out, int C, int H, int W, int sr, void* stream);
 
+/* Visualisation extras of FGAC.forward (DeMFInet.py:454-496; returned by DeMFInet.forward when args.visualization_flag or is_training,
+ * 167-176).  demfi_absmean_map: out[H,W] = mean over the C channels of |a| (b == NULL) or |a - b| (torch.mean(torch.abs(.), 1));
+ * demfi_minmax_normalize: plane = (plane - min(plane)) / max(plane - min(plane)) in place, the reference's two in-place steps
+ * (459-461), deterministic; scratch: demfi_minmax_scratch_floats() floats; demfi_one_minus: out = 1 - in (the (1 - w_sr) map, 495). */
+int     demfi_absmean_map(const demfi_view* a, const demfi_view* b, float* out, int C, int H, int W, void* stream);
+int64_t demfi_minmax_scratch_floats(void);
+int     demfi_minmax_normalize(float* plane, int64_t n, float* scratch, void* stream);
+int     demfi_one_minus(const float* in, float* out, int64_t n, void* stream);
+
 /* Eq.(4) gate blend (DeMFInet.py:452): out = w*source + (1-w)*e; w planar fp32 [H,W]. */
 int demfi_gate_blend(const float* w, const demfi_view* source, const demfi_view* e, const demfi_view* out,
                      int C, int H, int W, void* stream);
@@ -387,9 +396,13 @@ int demfi_conv_build(int dtype, int H, int W, int stride, int batch, const float
  * descriptors | n_trunk trunk buffer sets | n_trunk * n_ctx per-t buffer sets].  Since ABI v7 the big activation buffers of a set
  * are planned by liveness and share an arena (buffers that are never alive together occupy the same bytes; the workspace of the
  * 720p x8 configuration with 3 x 7 sets: 87.5 -> 36.1 GB): the named inputs / outputs of demfi_ctx_buffer ("x", "t", "sink",
- * "finals", "delta", "occ", "sharp1", "overlay", "ffo", "aF", "F01", "ft") own their memory, other buffers hold their value only
+ * "finals", "delta", "occ", "sharp1", "overlay", "ffo", "aF", "F01", "ft", "gate", "viz") own their memory, other buffers hold their value only
  * while the plan needs it.  Everything a per-t context touches lies in memory no other context touches (slots with a common context
- * stride), so the independence promised below is kept.  Environment DEMFI_ARENA=0: one region per buffer (debugging).  n_trunk / n_ctx > 1 build
+ * stride), so the independence promised below is kept.  The liveness plan holds for executions in PLAN ORDER (trunk, head, recursions
+ * 0..N-1, or prefixes of it): demfi_run_op on a single op out of order reads memory later tenants have recycled.  The scratch of a fused
+ * launch (DEMFI_OP_RESBLOCK's intermediate, DEMFI_OP_GRU_ZQ's z buffer) has NO memory under the arena: such an op must not be run as its
+ * constituent convolutions on the bound workspace, and demfi_ctx_bind fails if it would fuse other launches than the sizing pass did.
+ * Environment DEMFI_ARENA=0: one region per buffer (debugging, isolated per-op profiling).  n_trunk / n_ctx > 1 build
  * independent buffer sets so that a scheduler can overlap the trunk of window w+1 with the time instants of window w,
  * and several time instants of one window on different streams (results do not depend on it).
  * Re-entrant per context; one context per (GPU, frame size, dtype). */
@@ -402,15 +415,21 @@ typedef struct demfi_hparams {           /* DeMFInet.py:17-21, 32, 42, 326, 328;
     int32_t num_resb_dec;                /* 5                                                            */
     int32_t shared_fgac;                 /* 1                                                            */
     int32_t fgac_rr, fgac_sr;            /* 0, 0: the radii hard-coded at DeMFInet.py:401-402 (generalised FGAC when > 0) */
-    int32_t _pad;                        /* generalised FGAC index map: 0 = as the reference code computes it, 1 = pixel-centred */
+    int32_t flags;                       /* bit 0: generalised FGAC index map (0 = as the reference code computes it, 1 = pixel-centred);
+                                            bit 1 (DEMFI_HP_EXTRAS, ABI v8): also compute the maps of the reference's visualisation /
+                                            training return tuples (DeMFInet.py:167-176, 454-496) into the trunk buffer "viz"        */
 } demfi_hparams;
+#define DEMFI_HP_FGAC_CENTRED 1
+#define DEMFI_HP_EXTRAS       2
 
 enum demfi_op_kind {
     DEMFI_OP_CONV = 0, DEMFI_OP_PACK = 1, DEMFI_OP_S2D = 2, DEMFI_OP_OVERLAY = 3, DEMFI_OP_FGAC = 4, DEMFI_OP_GATE = 5,
     DEMFI_OP_CFR = 6, DEMFI_OP_WARP = 7, DEMFI_OP_FGAC_WINDOW = 8, DEMFI_OP_AVG_POOL = 9,
     DEMFI_OP_RESBLOCK = 10,     /* fused residual block: conv = descriptor of conv1, nch = descriptor of conv2 (demfi_resblock3x3_c64) */
     DEMFI_OP_GRU_R = 11,        /* reset gate of a SepConvGRU half-step: conv = descriptor of convr (demfi_gru_r)                        */
-    DEMFI_OP_GRU_ZQ = 12        /* update gate + candidate + blend: conv = descriptor of convz, nch = descriptor of convq (demfi_gru_zq) */
+    DEMFI_OP_GRU_ZQ = 12,       /* update gate + candidate + blend: conv = descriptor of convz, nch = descriptor of convq (demfi_gru_zq) */
+    DEMFI_OP_VIZ = 13           /* visualisation extras (DEMFI_HP_EXTRAS): conv = 0 channel mean of |a - b| (b optional) -> plane p[0];
+                                   1 min-max normalisation of plane p[0] in place (scratch p[1]); 2 plane p[0] = 1 - plane p[1]           */
 };
 enum demfi_segment { DEMFI_SEG_TRUNK = 0, DEMFI_SEG_T_HEAD = 1, DEMFI_SEG_ITER = 2,     /* TRUNK: ops 0, 1 = s2d, overlay (the prologue demfi_ingest_u8 replaces) */
                      DEMFI_SEG_TB_HEAD = 3, DEMFI_SEG_TB_ITER = 4 };                     /* the batched per-t plan of demfi_forward_tb (context index ignored) */

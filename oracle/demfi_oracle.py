@@ -263,6 +263,48 @@ def fgac(sd, name, ref, source, flow):
     return w * source + (1 - w) * e, w
 
 
+def _minmax_map(x):
+    """mean over channels of |x|, then the global min-max normalisation FGAC.forward applies in place (DeMFInet.py:456-462 for diff;
+    465-470, 473-478, 481-486, 489-494 for the visualisation maps): x -= x.min(); x /= x.max()  (the max is taken AFTER the shift)."""
+    m = torch.mean(torch.abs(x), 1, keepdim=True)
+    b, c, h, w = m.shape
+    m = m.reshape(b, -1).clone()
+    m -= m.min(1, keepdim=True)[0]
+    m /= m.max(1, keepdim=True)[0]
+    return m.view(b, 1, h, w)
+
+
+def fgac_extras(sd, name, ref, source, flow):
+    """What FGAC.forward returns besides its output (DeMFInet.py:454-496, rr = sr = 0): with args.visualization_flag the list
+    [w_sr, 1 - w_sr, source_v, init_ref_k, E_s, bolstered_F_s_ch1] (each min-max normalised channel mean except the two gates), and the
+    normalised diff map (always).  Returns (out, [six maps], diff)."""
+    rk = conv(sd, name + '.conv_ref_k', ref)
+    e = conv(sd, name + '.fusion', fgac_sample(rk, flow))
+    w = torch.sigmoid(conv(sd, name + '.w_gen_2', F.relu(conv(sd, name + '.w_gen', torch.cat([source, e], 1)))))
+    out = w * source + (1 - w) * e
+    return out, [w, 1 - w, _minmax_map(source), _minmax_map(rk), _minmax_map(e), _minmax_map(out)], _minmax_map(out - source)
+
+
+def forward_extras(sd, x, nf=64, shared_fgac=True):
+    """The members DeMFInet.forward adds to its return tuple (DeMFInet.py:167-176): with is_training (..., difference_maps,
+    flow_t0_t1_predictions), with args.visualization_flag (..., blending_weights, difference_maps).  They depend on the window only
+    (FF_RDB + FAC-FB).  Returns (blending_weights, difference_maps): blending_weights = [bw_F0, bw_F1, bw_F0, bw_F1, [flow_01, flow_10]]
+    (356-357, 168), difference_maps = [diff_1to0, diff_0to1, diff_1to0, diff_0to1] (358)."""
+    assert x.shape[0] == 1
+    B0, B1, Bm1, B2 = x[:, :, 0], x[:, :, 1], x[:, :, 2], x[:, :, 3]
+    F0, F1, flow_01, flow_10, _ = ff_rdb(sd, B0, B1, Bm1, B2, nf)
+    p = 'FAC_FB_Module.'
+    enc = F.relu(conv(sd, p + 'conv_first', torch.cat([F0, F1], 0)))
+    for i in range(5):
+        enc = resblock(sd, p + 'feature_extraction.%d' % i, enc)
+    e0, e1 = enc[0:1], enc[1:2]
+    n0 = p + ('shared_FGAC' if shared_fgac else 'FGAC_F1toF0')
+    n1 = p + ('shared_FGAC' if shared_fgac else 'FGAC_F0toF1')
+    _, bw0, d0 = fgac_extras(sd, n0, e1, e0, flow_01)
+    _, bw1, d1 = fgac_extras(sd, n1, e0, e1, flow_10)
+    return [bw0, bw1, bw0, bw1, [flow_01, flow_10]], [d0, d1, d0, d1]
+
+
 def fac_fb(sd, F0, F1, flow_10, flow_01, n_res=5, shared=True, fgac_radii=(0, 0, 0)):
     """FAC_FB.forward (DeMFInet.py:335-358): shared encoder on both frames, then FGAC both ways.  fgac_radii = (rr, sr,
     mode): the generalised FGAC (fgac_general) when rr > 0."""

@@ -220,6 +220,18 @@ class PlanSim:
                 self.conv(dz)
                 self.conv(dq)
                 self.reg.pop()
+            elif k == 13:                                                  # visualisation extras (DEMFI_HP_EXTRAS)
+                if op.conv == 0:
+                    a = self.strided(op.a, op.nch, H, W).float()
+                    if op.b.ptr:
+                        a = a - self.strided(op.b, op.nch, H, W).float()
+                    self.planes(op.p[0], 1, H, W).copy_(a.abs().mean(0, keepdim=True))
+                elif op.conv == 1:
+                    pl = self.planes(op.p[0], 1, H, W)
+                    pl -= pl.min()
+                    pl /= pl.max()
+                else:
+                    self.planes(op.p[0], 1, H, W).copy_(1 - self.planes(op.p[1], 1, H, W))
             elif k == 1:                                                   # pack planar fp32 planes -> NHWC slice
                 dst = self.strided(op.o, op.nch, H, W)
                 for c in range(op.nch):

@@ -137,6 +137,41 @@ def test_config2_720p_fp16_vs_oracle_other_windows_schedule_ends(seed, tv):
     torch.cuda.empty_cache()
 
 
+def test_config2_720p_second_weight_regime_fp32_strict_and_fp16_margin():
+    """Round 6: one full-size oracle point in the SECOND weight regime (synthetic_state_dict(flow_gain=0.3): flows of
+    a few pixels, occlusion maps spread over (0, 1) -- what a trained checkpoint looks like; every other full-size test uses the
+    saturated xavier regime).  fp32: |dPSNR| <= 1e-3 dB and PSNR(build, oracle) > 60 dB; fp16: the same gate as config 2, margin recorded."""
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    sd = synthetic_state_dict(0, flow_gain=0.3)
+    x = synthetic_window(736, 1280, 4)
+    t = torch.tensor([[0.375]])
+    with torch.no_grad():
+        ref = O.forward(sd, x, t, 3)
+    occ = ref[3][-1]
+    print('regime 2 at 736x1280: |flow| max %.2f px, occlusion saturated (<0.02 or >0.98) on %.1f %% of the pixels' %
+          (float(ref[2][-1].abs().max()), 100.0 * float(((occ < 0.02) | (occ > 0.98)).float().mean())))
+    gt = x[0, :, 0].numpy()
+    for dtype in (torch.float32, torch.float16):
+        m = DeMFInet(HyperParams(), dtype=dtype)
+        m.load_state_dict(sd)
+        m = m.to(DEV).eval()
+        d1, fin, flows, occs, ov = m(x.to(DEV), t.to(DEV), 3)
+        for i in range(3):
+            got = fin[2][i][0].cpu().numpy()
+            exp = ref[1][2][i][0].numpy()
+            ps, dps = O.psnr(got, exp), O.psnr(got, gt) - O.psnr(exp, gt)
+            assert np.isfinite(got).all()
+            if dtype == torch.float32:
+                assert abs(dps) <= 1e-3 and ps > 60.0, (i, ps, dps)
+            else:
+                print('720p fp16 N=3 regime 2 frame %d: PSNR vs fp32 oracle %.2f dB (margin %.2f dB over the 44 dB gate), dPSNR vs pseudo-GT %+.4f dB'
+                      % (i, ps, ps - 44.0, dps))
+                record_fp16_margin('regime2_720p_seed4_t0.375', i, ps, dps, size='736x1280', n_tst=3, t=0.375, seed=4, flow_gain=0.3)
+                assert ps >= 44.0 and abs(dps) <= 5e-3, (i, ps, dps)
+        del m
+        torch.cuda.empty_cache()
+
+
 def test_config2_720p_runner_batched_equals_module():
     """The benched scheduler at the benched size: the 7 time instants of a 720p window as ONE launch sequence batched over 7
     per-t contexts (demfi_forward_tb; at this size the batched convolutions choose other record sizes / grids than the

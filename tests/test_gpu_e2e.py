@@ -116,7 +116,7 @@ def test_batch_of_same_window_runs_the_batched_plan_bit_identically(dtype):
     t = torch.tensor([[0.125], [0.5], [0.875]], device=DEV)
     # a stride-0 view is detected from the layout alone (no device sync, no read of the input); a materialised copy needs the
     # caller's word (same_window=True); without it the items run as distinct windows -- same results, B trunks
-    for xb, kw in ((x1.expand(B, -1, -1, -1, -1), {}), (x1.repeat(B, 1, 1, 1, 1), {'same_window': True}), (x1.repeat(B, 1, 1, 1, 1), {})):
+    for xb, kw in ((x1.expand(B, -1, -1, -1, -1), {}), (x1.repeat(B, 1, 1, 1, 1), {'same_window': True}), (x1.repeat(B, 1, 1, 1, 1), {'same_window': False})):
         m._engines.pop((H, W, dtype, 'batch'), None)
         d1, fin, flows, occs, ov = m(xb, t, N, **kw)
         batched = (H, W, dtype, 'batch') in m._engines
@@ -145,7 +145,7 @@ def test_batch_of_distinct_windows_pipelines_trunks_bit_identically(dtype):
     H, W, N, B = 64, 96, 2, 4
     x = torch.cat([synthetic_window(H, W, 30 + b) for b in range(B)], 0).to(DEV)
     t = torch.tensor([[0.25], [0.5], [0.75], [0.125]], device=DEV)
-    d1, fin, flows, occs, ov = m(x, t, N)
+    d1, fin, flows, occs, ov = m(x, t, N, same_window=False)
     assert m._engines[(H, W, dtype)].n_trunk >= 2 and tuple(fin[N - 1][2].shape) == (B, 3, H, W)
     for b in range(B):
         s = m(x[b:b + 1], t[b:b + 1], N)
@@ -167,7 +167,7 @@ def test_batch_of_two_and_non_shared_fgac():
     m = m.to(DEV).eval()
     x = torch.cat([synthetic_window(32, 32, 6), synthetic_window(32, 32, 16)], 0)
     t = torch.tensor([[0.5], [0.25]])
-    out = m(x.to(DEV), t.to(DEV), 1)
+    out = m(x.to(DEV), t.to(DEV), 1, same_window=False)
     assert tuple(out[1][0][2].shape) == (2, 3, 32, 32)
     with torch.no_grad():
         for b in range(2):
@@ -368,3 +368,94 @@ def test_final_only_runner_delivers_the_same_frames(model16):
     u_b, us_b = fo.run_window_u8(frames)
     torch.cuda.synchronize()
     assert torch.equal(u_a, u_b) and torch.equal(us_a, us_b)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16])
+def test_visualisation_and_training_return_tuples(golden_dir, dtype):
+    """Round 6, SURVEY 8(f4): args.visualization_flag = True -> the 7-tuple of DeMFInet.py:174-176 (blending_weights with FGAC's six
+    maps per direction + [flow_01, flow_10], difference_maps), is_training = True -> the 7-tuple of 170-172 (difference_maps,
+    flow_t0_t1_predictions); fixture from the unpatched reference.  The five leading members are those of the plain forward."""
+    g = np.load(os.path.join(golden_dir, 'extras_64x96_t0500_n1.npz'))
+    H, W = int(g['H']), int(g['W'])
+    x = synthetic_window(H, W, int(g['seed'])).to(DEV)
+    t = torch.tensor([[float(g['t'])]], device=DEV)
+    mv = DeMFInet(HyperParams(visualization_flag=True), dtype=dtype)
+    mv.load_state_dict(synthetic_state_dict(0))
+    mv = mv.to(DEV).eval()
+    out = mv(x, t, 1)
+    assert len(out) == 7
+    bw, diffs = out[5], out[6]
+    assert len(bw) == 5 and len(diffs) == 4 and len(bw[0]) == 6 and len(bw[4]) == 2
+    # fp32: conv summation order (1e-5 on the gates), amplified by 1 / (max - min) in the normalised maps; fp16: fp16 features
+    tol = 1e-4 if dtype == torch.float32 else 3e-2
+    for b in range(2):
+        for k in range(6):
+            assert tuple(bw[b][k].shape) == (1, 1, H, W)
+            d = np.abs(bw[b][k][0, 0].cpu().numpy() - g['bw'][b, k])
+            assert d.max() < tol and np.median(d) < tol / 10, (b, k, d.max(), np.median(d))
+            assert torch.equal(bw[b][k], bw[b + 2][k])
+        assert np.abs(diffs[b][0, 0].cpu().numpy() - g['diff'][b]).max() < tol
+        assert torch.equal(diffs[b], diffs[b + 2])
+        if dtype == torch.float32:
+            assert float(bw[b][4].min()) == 0.0 and float(bw[b][4].max()) == 1.0
+    assert np.median(np.abs(bw[4][0][0].cpu().numpy() - g['flow_01'])) < (2e-4 if dtype == torch.float32 else 5e-2)
+    plain = _model(dtype)
+    ref5 = plain(x, t, 1)
+    assert torch.equal(out[1][0][2], ref5[1][0][2]) and torch.equal(out[0][1], ref5[0][1])
+    # training tuple from a model built WITHOUT the flag: an engine with the extras is built on demand
+    tr = plain(x, t, 1, True)
+    assert len(tr) == 7 and len(tr[5]) == 4 and len(tr[6]) == 1 and len(tr[6][0]) == 2
+    assert np.abs(tr[5][1][0, 0].cpu().numpy() - g['train_diff'][1]).max() < tol
+    assert torch.equal(tr[1][0][2], ref5[1][0][2])
+    assert torch.equal(tr[6][0][0], ref5[2][0][:, 0:2]) and torch.equal(tr[6][0][1], ref5[2][0][:, 2:4])
+    if dtype == torch.float32:
+        assert np.median(np.abs(tr[6][0][0][0].cpu().numpy() - g['train_rflow'][0])) < 2e-4
+    # a batch of the same window: the maps are replicated per item
+    ob = mv(x.expand(2, -1, -1, -1, -1), torch.tensor([[0.5], [0.25]], device=DEV), 1)
+    assert tuple(ob[5][0][2].shape) == (2, 1, H, W) and torch.equal(ob[5][0][2][0], bw[0][2][0]) and torch.equal(ob[6][1][1], diffs[1][0])
+
+
+def test_second_weight_regime_fp32_goldens_and_fp16_margin(golden_dir):
+    """Round 6: small flows (<= 3 px) and unsaturated occlusion maps -- synthetic_state_dict(flow_gain=0.3)
+    -- against fixtures from the reference: fp32 |dPSNR| <= 1e-3 dB; fp16 stated against the fp32 fixtures, margins recorded."""
+    from tests.conftest import record_fp16_margin
+    sd = synthetic_state_dict(0, flow_gain=0.3)
+    m32, m16 = _model(torch.float32, sd), _model(torch.float16, sd)
+    for name in ('e2e_smallflow_64x96_t0500_n3', 'e2e_smallflow_64x96_t0125_n2'):
+        g = np.load(os.path.join(golden_dir, name + '.npz'))
+        N = int(g['N'])
+        x = synthetic_window(int(g['H']), int(g['W']), int(g['seed']))
+        t = torch.tensor([[float(g['t'])]], device=DEV)
+        d1, fin, flows, occs, ov = m32(x.to(DEV), t, N)
+        gt = x[0, :, 0].numpy()
+        for it in range(N):
+            for i in range(3):
+                got = fin[it][i][0].cpu().numpy()
+                _close(got, g['finals'][it, i], (name, it, i))
+                assert abs(O.psnr(got, gt) - O.psnr(g['finals'][it, i], gt)) <= 1e-3
+                assert O.psnr(got, g['finals'][it, i]) > 60.0
+        for i in range(N + 1):
+            _close(flows[i][0].cpu().numpy(), g['flows'][i], name, scale=10.0)
+            _close(occs[i][0].cpu().numpy(), g['occs'][i], name)
+        f16 = m16(x.to(DEV), t, N)[1]
+        for i in range(3):
+            got = f16[N - 1][i][0].cpu().numpy()
+            ps, dps = O.psnr(got, g['finals'][N - 1, i]), O.psnr(got, gt) - O.psnr(g['finals'][N - 1, i], gt)
+            print('%s fp16 frame %d: PSNR vs the reference fixture %.2f dB, dPSNR vs pseudo-GT %+.4f dB' % (name, i, ps, dps))
+            record_fp16_margin('regime2_' + name, i, ps, dps, size='64x96', n_tst=N, t=float(g['t']), seed=int(g['seed']), flow_gain=0.3)
+            assert np.isfinite(got).all() and ps >= 40.0
+
+
+def test_materialised_same_window_batch_warns_once():
+    """a batch of materialised copies without the caller's word runs as distinct windows (identical results) and says so once."""
+    import warnings
+    m = _model(torch.float16)
+    x = synthetic_window(32, 64, 3).to(DEV).repeat(2, 1, 1, 1, 1)
+    t = torch.tensor([[0.25], [0.75]], device=DEV)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        a = m(x, t, 1)
+        b = m(x, t, 1)
+    assert sum('DIFFERENT windows' in str(i.message) for i in w) == 1
+    c = m(x, t, 1, same_window=True)
+    assert torch.equal(a[1][0][2], c[1][0][2]) and torch.equal(a[1][0][2], b[1][0][2])

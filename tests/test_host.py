@@ -53,7 +53,7 @@ def test_forward_fails_loudly_without_gpu():
     m = DeMFInet(HyperParams())
     with pytest.raises(RuntimeError):
         m(torch.zeros(1, 3, 4, 32, 32), torch.tensor([[0.5]]), 1)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(RuntimeError):                         # round 6: the training / visualisation tuples exist, and are HIP-only too
         m(torch.zeros(1, 3, 4, 32, 32), torch.tensor([[0.5]]), 1, is_training=True)
 
 
@@ -126,6 +126,27 @@ def test_plan_matches_oracle_fp32(synthetic_sd):
         assert (eng.delta[i, 0:4] - flows[i][0]).abs().max() < 2e-4
         assert (eng.occ[i:i + 1] - occs[i][0]).abs().max() < 1e-4
     assert torch.equal(eng.overlay, ov[0])
+
+
+def test_plan_with_visualisation_extras(synthetic_sd):
+    """DEMFI_HP_EXTRAS: the plan also computes FGAC's gates, min-max normalised channel-mean maps and diff (DeMFInet.py:454-496) -- the
+    interpreted plan against the oracle's restatement, fp32; the frames do not change."""
+    H, W, N = 32, 64, 1
+    hp = HyperParams(visualization_flag=True)
+    eng = Engine(synthetic_sd, H, W, torch.float32, 'cpu', max_updates=N, hp=hp)
+    plain = Engine(synthetic_sd, H, W, torch.float32, 'cpu', max_updates=N)
+    assert eng.n_launches(N)[0] == plain.n_launches(N)[0] + 2 * (1 + 2 * 5)     # per direction: 1 - w, five (mean, normalise) pairs
+    x = synthetic_window(H, W, 4)
+    PlanSim(eng).forward(x, 0.375, N)
+    PlanSim(plain).forward(x, 0.375, N)
+    assert torch.equal(eng.finals, plain.finals)
+    with torch.no_grad():
+        bw, diffs = O.forward_extras(synthetic_sd, x)
+    for b in range(2):
+        assert (eng.gate[b] - bw[b][0][0, 0]).abs().max() < 1e-5
+        for k in range(5):
+            assert (eng.viz[b, k] - bw[b][k + 1][0, 0]).abs().max() < 2e-5, (b, k)
+        assert (eng.viz[b, 5] - diffs[b][0, 0]).abs().max() < 2e-5
 
 
 def test_plan_non_shared_fgac():

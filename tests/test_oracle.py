@@ -172,3 +172,43 @@ def test_generalised_fgac_matches_patched_reference(golden_dir, synthetic_sd):
         fac0, att0 = O.fgac_window(rk, sk, fl, 0, 0, mode)
         assert torch.equal(att0, torch.ones_like(att0))
         assert (fac0 - O.fgac_sample_explicit(rk, fl)[0]).abs().max() < 1e-6
+
+
+def test_extras_of_the_visualisation_and_training_tuples(golden_dir, synthetic_sd):
+    """Round 6: FGAC's extra returns (DeMFInet.py:454-496) and DeMFInet.forward's longer tuples (167-176), fixture from the UNPATCHED
+    reference with args.visualization_flag = True / is_training = True."""
+    g = _load(golden_dir, 'extras_64x96_t0500_n1')
+    x = synthetic_window(int(g['H']), int(g['W']), int(g['seed']))
+    with torch.no_grad():
+        bw, diffs = O.forward_extras(synthetic_sd, x)
+    assert len(bw) == 5 and len(diffs) == 4
+    for b in range(2):
+        for k in range(6):
+            assert np.abs(bw[b][k][0, 0].numpy() - g['bw'][b, k]).max() < 5e-6, (b, k)
+        assert np.abs(diffs[b][0, 0].numpy() - g['diff'][b]).max() < 5e-6
+        assert np.array_equal(g['diff'][b], g['train_diff'][b])                 # the training tuple carries the same maps
+        assert g['bw'][b, 2:].min() == 0.0 and g['bw'][b, 2:].max() == 1.0      # min-max normalised
+    assert np.abs(bw[4][0][0].numpy() - g['flow_01']).max() < 5e-5 and np.abs(bw[4][1][0].numpy() - g['flow_10']).max() < 5e-5
+
+
+def test_second_weight_regime_small_flows_unsaturated_occlusion(golden_dir):
+    """Round 6: every other fixture uses xavier weights whose flows reach +-6..20 px and whose occlusion maps
+    saturate.  flow_gain = 0.3 on the flow / occlusion rows gives sub-pixel .. 3 px motions and occlusion spread over (0, 1)."""
+    from demfi_amd.weights import synthetic_state_dict
+    sd = synthetic_state_dict(0, flow_gain=0.3)
+    for name in ('e2e_smallflow_64x96_t0500_n3', 'e2e_smallflow_64x96_t0125_n2'):
+        g = _load(golden_dir, name)
+        N = int(g['N'])
+        x = synthetic_window(int(g['H']), int(g['W']), int(g['seed']))
+        with torch.no_grad():
+            d1, fin, flows, occs, ov = O.forward(sd, x, torch.tensor([[float(g['t'])]]), N)
+        gt = x[0, :, 0].numpy()
+        for it in range(N):
+            for i in range(3):
+                assert np.abs(fin[it][i][0].numpy() - g['finals'][it, i]).max() < 5e-5
+                assert abs(O.psnr(fin[it][i][0].numpy(), gt) - O.psnr(g['finals'][it, i], gt)) <= 1e-3
+        for i in range(N + 1):
+            assert np.abs(flows[i][0].numpy() - g['flows'][i]).max() < 5e-5
+            assert np.abs(occs[i][0].numpy() - g['occs'][i]).max() < 5e-5
+        sat = ((g['occs'][-1] < 0.02) | (g['occs'][-1] > 0.98)).mean()
+        assert np.abs(g['flows'][-1]).max() < 4.0 and sat < 0.05                # the regime the fixture claims

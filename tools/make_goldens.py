@@ -291,7 +291,69 @@ def fgac_window_fixtures():
     np.savez_compressed(os.path.join(OUT, 'fgac_window_16x24.npz'), **rec)
 
 
+def round6():
+    """Fixtures added in round 6: (a) the visualisation / training return tuples of the UNPATCHED reference (DeMFInet.py:167-176,
+    454-496), (b) a second weight regime -- small flows, unsaturated occlusion (synthetic_state_dict(flow_gain=0.3)) -- end to end."""
+    x = synthetic_window(64, 96, 1)
+    t = torch.tensor([[0.5]], dtype=torch.float32)
+    sd = synthetic_state_dict(0)
+    viz_args = types.SimpleNamespace(**{**vars(ARGS), 'visualization_flag': True})
+    nv = R.DeMFInet(viz_args).eval()
+    nv.load_state_dict(sd)
+    with torch.no_grad():
+        out_v = nv(x, t, 1)                                    # 7-tuple of DeMFInet.py:174-176
+        out_t = R.DeMFInet(ARGS).eval()
+        out_t.load_state_dict(sd)
+        out_t = out_t(x, t, 1, True)                           # is_training: 7-tuple of 170-172 (eval-mode numbers)
+        mine_bw, mine_diff = O.forward_extras(sd, x)
+    bw, diffs = out_v[5], out_v[6]
+    assert len(out_v) == 7 and len(bw) == 5 and len(diffs) == 4 and len(out_t) == 7
+    assert all(torch.equal(a, b) for a, b in zip(bw[0], bw[2])) and torch.equal(diffs[0], diffs[2]) and torch.equal(diffs[1], diffs[3])
+    rec = dict(H=64, W=96, seed=1, t=np.float32(0.5), N=1, weight_seed=0,
+               bw=torch.stack([torch.stack([m[0, 0] for m in bw[b]]) for b in range(2)]).numpy(),          # [2, 6, H, W]
+               diff=torch.stack([diffs[b][0, 0] for b in range(2)]).numpy(),                                # [2, H, W]
+               flow_01=bw[4][0][0].numpy(), flow_10=bw[4][1][0].numpy(),
+               St=out_v[1][0][2][0].numpy(),
+               train_diff=torch.stack([out_t[5][b][0, 0] for b in range(2)]).numpy(),
+               train_rflow=torch.stack([out_t[6][0][i][0] for i in range(2)]).numpy())                       # [2, 2, H, W]
+    np.savez_compressed(os.path.join(OUT, 'extras_64x96_t0500_n1.npz'), **rec)
+    d = max(float((a - b).abs().max()) for b in range(2) for a, b in zip(bw[b], mine_bw[b]))
+    d = max(d, max(float((a - b).abs().max()) for a, b in zip(diffs, mine_diff)))
+    print('extras_64x96           oracle-vs-reference max|diff| = %.3e (gates, normalised maps, diff)' % d)
+
+    sd2 = synthetic_state_dict(0, flow_gain=0.3)
+    net = R.DeMFInet(ARGS).eval()
+    net.load_state_dict(sd2)
+    for tag, (H, W, seed, tval, N) in {'e2e_smallflow_64x96_t0500_n3': (64, 96, 1, 0.5, 3), 'e2e_smallflow_64x96_t0125_n2': (64, 96, 2, 0.125, 2)}.items():
+        x = synthetic_window(H, W, seed)
+        t = torch.tensor([[tval]], dtype=torch.float32)
+        with torch.no_grad():
+            d1, fin, flows, occs, ov = net(x, t, N)
+            mine = O.forward(sd2, x, t, N)
+        rec = dict(H=H, W=W, seed=seed, t=np.float32(tval), N=N, weight_seed=0, flow_gain=np.float32(0.3),
+                   d1=torch.stack([z[0] for z in d1]).numpy(),
+                   finals=torch.stack([torch.stack([z[0] for z in f]) for f in fin]).numpy(),
+                   flows=torch.stack([z[0] for z in flows]).numpy(),
+                   occs=torch.stack([z[0] for z in occs]).numpy(),
+                   overlay=ov[0].numpy())
+        np.savez_compressed(os.path.join(OUT, tag + '.npz'), **rec)
+        d = max(float((a - b).abs().max()) for a, b in zip(fin[-1], mine[1][-1]))
+        print('%-30s oracle-vs-reference %.3e   |flow| max %.2f px, mean %.2f px; occlusion in [%.3f, %.3f], saturated (<0.02 or >0.98): %.1f %%' %
+              (tag, d, float(flows[-1].abs().max()), float(flows[-1].abs().mean()), float(occs[-1].min()), float(occs[-1].max()),
+               100.0 * float(((occs[-1] < 0.02) | (occs[-1] > 0.98)).float().mean())))
+    # for the record: the same statistics of the first regime
+    net.load_state_dict(sd)
+    with torch.no_grad():
+        _, _, flows, occs, _ = net(synthetic_window(64, 96, 1), torch.tensor([[0.5]]), 3)
+    print('%-30s (regime 1)            |flow| max %.2f px, mean %.2f px; occlusion in [%.3f, %.3f], saturated: %.1f %%' %
+          ('e2e_64x96_t0500_n3', float(flows[-1].abs().max()), float(flows[-1].abs().mean()), float(occs[-1].min()), float(occs[-1].max()),
+           100.0 * float(((occs[-1] < 0.02) | (occs[-1] > 0.98)).float().mean())))
+
+
 if __name__ == '__main__':
+    if '--round6' in sys.argv:
+        round6()
+        sys.exit(0)
     if '--fgac-window' in sys.argv:
         fgac_window_fixtures()
         sys.exit(0)
@@ -300,3 +362,4 @@ if __name__ == '__main__':
     else:
         main()
         round2()
+        round6()
