@@ -180,15 +180,26 @@ __global__ __launch_bounds__(G_NTHREADS, 1) void gru_sep5_kernel(const GArgs a)
         const int px = dw * 8 + (lane >> 3);                     // pixel of this lane in every DMA instruction / staged line
         const unsigned slot16 = (unsigned)(((lane & 7) ^ ((px >> 1) & 7)) << 4);
         // instruction k of helper dw = window line k, records 8 dw .. 8 dw + 7 -> LDS bytes [(4 k + dw) 1024, + 1024)
-        auto issue_piece = [&](const GPiece& pc, char* lds, int img, int P0, int L0) {
+        // carry: the tile continues the previous one along the filter axis (same image, same pixels, TL lines further): its first 4
+        // window lines ARE the previous window's last 4 -- copied inside LDS (this helper's chunk of each line: 4 ds_read + 4 ds_write)
+        // instead of fetched again.  A helper's VMEM instruction is the scarce thing (130-400 cycles each beside the MFMA waves) and the
+        // re-fetched halo lines missed the XCD's L2 (32 windows of 144 KiB per XCD): -1/3 of the DMA instructions, -1/3 of the fabric reads.
+        auto issue_piece = [&](const GPiece& pc, char* lds, int img, int P0, int L0, bool carry) {
             const char* base = pc.ptr + (int64_t)img * pc.sb + (int64_t)(L0 - 2) * pc.sl + (int64_t)P0 * pc.sp;      // wave-uniform
             const unsigned voff = (unsigned)(px * pc.sp) + slot16;
             const bool pok = P0 + px < a.Plen;
+            u4_t halo[4];
+            if (carry) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) halo[j] = *(const u4_t*)(lds + (4 * (TL + j) + dw) * 1024 + lane * 16);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // in registers before the DMA below may overwrite lines TL .. TL + 3
+            }
             if (L0 - 2 >= 0 && L0 - 2 + WL <= a.Llen && P0 + 32 <= a.Plen) {
                 // uniform line base (SALU) + ONE 32-bit lane offset: the saddr form, no VALU per instruction -- the helpers share their
                 // SIMDs with the MFMA waves and a starved helper needed ~600 cycles per instruction with 64-bit per-lane addresses
 #pragma unroll
                 for (int k = 0; k < NIW; ++k) {
+                    if (k < 4 && carry) continue;                // wave-uniform
                     const char* lb = base + (int64_t)k * pc.sl;
                     lb = (const char*)(((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)((uint64_t)lb >> 32)) << 32) |
                                        (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(uint64_t)lb));   // uniform already: folds away, pins lb to SGPRs
@@ -200,11 +211,17 @@ __global__ __launch_bounds__(G_NTHREADS, 1) void gru_sep5_kernel(const GArgs a)
             } else {
 #pragma unroll
                 for (int k = 0; k < NIW; ++k) {
+                    if (k < 4 && carry) continue;
                     const int l = L0 - 2 + k;
                     const char* g = (pok && l >= 0 && l < a.Llen) ? base + (int64_t)k * pc.sl + voff : a.zeros;
                     __builtin_amdgcn_global_load_lds((const DEMFI_GLOBAL void*)g,
                                                      (__attribute__((address_space(3))) void*)(lds + (4 * k + dw) * 1024), 16, 0, 0);
                 }
+            }
+            if (carry) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) *(u4_t*)(lds + (4 * j + dw) * 1024 + lane * 16) = halo[j];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // written before this wave arrives at the barrier that hands the piece over
             }
         };
         int it = it0;
@@ -214,9 +231,9 @@ __global__ __launch_bounds__(G_NTHREADS, 1) void gru_sep5_kernel(const GArgs a)
         if constexpr (MODE == GM_ZQ) {
             // staged outputs (in piece 2): line r = bytes [4096 r, +4096), helper dw owns its chunk dw = pixels 8 dw .. 8 dw + 7
             const unsigned dlane = (unsigned)(px * a.d_sp) + slot16;
-            issue_piece(a.h, S0, img, P0, L0);
-            issue_piece(a.rh, S1, img, P0, L0);
-            issue_piece(a.x, S2, img, P0, L0);
+            issue_piece(a.h, S0, img, P0, L0, false);
+            issue_piece(a.rh, S1, img, P0, L0, false);
+            issue_piece(a.x, S2, img, P0, L0, false);
             // A helper's VMEM instruction takes ~400 cycles while the MFMA waves of its SIMD run a matrix phase and 130-220 while they are in
             // their epilogues (profiles/r06_gru_phase_trace.txt).  Per tile: the previous tile's 8 output stores and the wait for x under
             // phase A, the next tile's h (12 DMA instructions) under phase B, r*h (12) under the sigmoid / tanh pass, x (12) after the staged
@@ -253,13 +270,15 @@ __global__ __launch_bounds__(G_NTHREADS, 1) void gru_sep5_kernel(const GArgs a)
                 G_STAMP(wave, trk, 1);
                 asm volatile("s_barrier" ::: "memory");         // B: x has landed; every MFMA wave is done with h, r*h
                 int nimg = img, nP0 = P0, nL0 = L0;
+                bool carry = false;
                 if (more) {
                     pos_of(it + 1, nimg, nP0, nL0);
-                    issue_piece(a.h, S0, nimg, nP0, nL0);        // 12 instructions under phase B ...
+                    carry = nimg == img && nP0 == P0 && nL0 == L0 + TL;
+                    issue_piece(a.h, S0, nimg, nP0, nL0, carry);  // 8 (12 at a strip start) instructions under phase B ...
                 }
                 G_STAMP(wave, trk, 2);
                 asm volatile("s_barrier" ::: "memory");         // C: every MFMA wave is done with x
-                if (more) issue_piece(a.rh, S1, nimg, nP0, nL0); // ... 12 under the sigmoid / tanh pass
+                if (more) issue_piece(a.rh, S1, nimg, nP0, nL0, carry); // ... 8 under the sigmoid / tanh pass
                 G_STAMP(wave, trk, 3);
                 asm volatile("s_barrier" ::: "memory");         // D: q~ is in LDS
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the next tile's h, r*h have landed: E tells the MFMA waves
@@ -272,7 +291,7 @@ __global__ __launch_bounds__(G_NTHREADS, 1) void gru_sep5_kernel(const GArgs a)
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 }
                 // this helper's DMA instructions overwrite exactly the chunks it has just read
-                if (more) issue_piece(a.x, S2, nimg, nP0, nL0);
+                if (more) issue_piece(a.x, S2, nimg, nP0, nL0, carry);   // lines 8 .. 11 of the x piece survived the staging (lines 0 .. 7)
                 G_STAMP(wave, trk, 5);
                 ++trk;
                 have_prev = true; pimg = img; pP0 = P0; pL0 = L0;
@@ -281,24 +300,30 @@ __global__ __launch_bounds__(G_NTHREADS, 1) void gru_sep5_kernel(const GArgs a)
             }
             do_stores(pimg, pP0, pL0);
         } else {
-            issue_piece(a.x, S0, img, P0, L0);
-            issue_piece(a.h, S1, img, P0, L0);
+            issue_piece(a.x, S0, img, P0, L0, false);
+            issue_piece(a.h, S1, img, P0, L0, false);
+            bool h_carried = false;                              // the h piece in flight was issued with the halo carried (4 instructions fewer)
             for (;;) {
                 const bool more = it + 1 < it1;
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NIW) : "memory");
+                // outstanding, in order: x | h  ->  x has landed when only h's instructions are left
+                if (h_carried) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NIW - 4) : "memory");
+                else           asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NIW) : "memory");
                 G_STAMP(wave, trk, 0);
                 asm volatile("s_barrier" ::: "memory");         // A: x has landed
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 G_STAMP(wave, trk, 1);
                 asm volatile("s_barrier" ::: "memory");         // B: h has landed; every MFMA wave is done with x
                 int nimg = img, nP0 = P0, nL0 = L0;
+                bool carry = false;
                 if (more) {
                     pos_of(it + 1, nimg, nP0, nL0);
-                    issue_piece(a.x, S0, nimg, nP0, nL0);
+                    carry = nimg == img && nP0 == P0 && nL0 == L0 + TL;
+                    issue_piece(a.x, S0, nimg, nP0, nL0, carry);
                 }
                 G_STAMP(wave, trk, 2);
                 asm volatile("s_barrier" ::: "memory");         // C: epilogues done, h is free
-                if (more) issue_piece(a.h, S1, nimg, nP0, nL0);
+                if (more) issue_piece(a.h, S1, nimg, nP0, nL0, carry);
+                h_carried = carry;
                 G_STAMP(wave, trk, 3);
                 ++trk;
                 if (!more) break;
@@ -563,20 +588,31 @@ __global__ __launch_bounds__(G_NTHREADS, 1) void gru_sep5_kernel(const GArgs a)
             asm volatile("" ::"v"(acc[0]), "v"(acc[1]), "v"(acc[2]), "v"(acc[3]), "v"(acc[4]), "v"(acc[5]), "v"(acc[6]), "v"(acc[7]));
 #endif
             G_STAMP(wave, trk, 4);
+            // r * h: h from the window's centre lines; barrier C (the h piece is free) AFTER the epilogue.  Measured alternative (round 6): h
+            // into registers first and C before the epilogue, so that the helpers issue the next h under it -- the tile got 20 % SLOWER
+            // (epilogue + stores 5 500 -> 11 200 cycles: the helpers' DMA and these 16 partial-line stores share the CU's memory pipe)
             char* const ob = a.dst + (int64_t)img * a.d_sb + (int64_t)(P0 + lx) * a.d_sp + (cs * 32 + hi * 8) * 2;
             const bool pok = P0 + lx < a.Plen;
             g_for<0, 8>([&](auto P) {
                 constexpr int p = decltype(P)::value;
                 const int l = L0 + role * 8 + p;
+                f2_t sg[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {                    // sigmoid, 16 values at a time, packed multiplies / adds
+                    f2_t e = f2_t{acc[p][2 * i], acc[p][2 * i + 1]} * KS_SIG;
+                    e = f2_t{__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)} + 1.0f;
+                    sg[i] = f2_t{__builtin_amdgcn_rcpf(e.x), __builtin_amdgcn_rcpf(e.y)};
+                }
 #pragma unroll
                 for (int m2 = 0; m2 < 2; ++m2) {
-                    const u4_t rr = *(const u4_t*)(t1 + (2 + p) * G_LS + soff[m2]);
-                    const h8_t r = __builtin_bit_cast(h8_t, rr);
+                    const h8_t r = __builtin_bit_cast(h8_t, *(const u4_t*)(t1 + (2 + p) * G_LS + soff[m2]));
                     h8_t o;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[p][(2 * m2 + (j >> 2)) * 4 + (j & 3)] * KS_SIG));
-                        o[j] = (half_t)__builtin_fmaf(s, (float)r[j], 0.0f);
+                    for (int j = 0; j < 2; ++j) {               // quads 2 m2, 2 m2 + 1 = pairs 4 m2 .. 4 m2 + 3
+                        o[2 * j] = (half_t)__builtin_fmaf(sg[4 * m2 + j].x, (float)r[2 * j], 0.0f);
+                        o[2 * j + 1] = (half_t)__builtin_fmaf(sg[4 * m2 + j].y, (float)r[2 * j + 1], 0.0f);
+                        o[4 + 2 * j] = (half_t)__builtin_fmaf(sg[4 * m2 + 2 + j].x, (float)r[4 + 2 * j], 0.0f);
+                        o[4 + 2 * j + 1] = (half_t)__builtin_fmaf(sg[4 * m2 + 2 + j].y, (float)r[4 + 2 * j + 1], 0.0f);
                     }
                     if (pok && l < a.Llen) *gp<u4_t>(ob + (int64_t)l * a.d_sl + m2 * 32) = __builtin_bit_cast(u4_t, o);
                 }

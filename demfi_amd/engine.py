@@ -401,6 +401,74 @@ class Engine:
     def n_convs(self):
         return self.lib.demfi_ctx_num_convs(self._ctx)
 
+    def op_algorithmic_bytes(self, op):
+        """ALGORITHMIC HBM bytes of one launch: every tensor it reads or writes counted once -- input pieces (an
+        image a batched launch re-reads with batch stride 0 counts once), residual / aux, outputs, packed weights; planar operands at 4 B.
+        What bench.py prices against the 8 TB/s ceiling in its per-op table; the measured bytes are the PMC figures beside it."""
+        H, W = self.H, self.W
+        kind = KIND_NAME.get(op.kind, '')
+        esz = 4 if self.f32 else 2
+        nb = max(1, int(op.bt.nb))
+
+        def conv_in(d):
+            tot = 0
+            for i in range(d.n_pieces):
+                pc = d.pieces[i]
+                if not pc.v.ptr:
+                    continue
+                h_in, w_in = (d.inH >> pc.up_shift, d.inW >> pc.up_shift) if pc.up_shift else (d.inH, d.inW)
+                tot += pc.nch * (4 if pc.v.is_f32 else 2) * h_in * w_in * (d.batch if pc.v.sb else 1)
+            return tot
+
+        def conv_out(d, with_aux=True):
+            tot = 0
+            for sg in range(d.n_segs):
+                g = d.segs[sg]
+                n = sum(d.oct_n[o] for o in range(d.cout_pad // 8) if d.oct_seg[o] == sg)
+                px = d.H * d.W * d.batch * (g.scale * g.scale if g.scale > 1 else 1) // (g.scale * g.scale if g.scale > 1 else 1)
+                tot += n * (4 if g.dst.is_f32 else 2) * px
+                if g.res.ptr:
+                    tot += n * (4 if g.res.is_f32 else 2) * d.H * d.W * (d.batch if g.res.sb else 1)
+                if with_aux and g.aux.ptr:
+                    tot += n * (4 if g.aux.is_f32 else 2) * d.H * d.W * (d.batch if g.aux.sb else 1)
+            if d.pack.ptr:
+                tot += 16 * 2 * d.H * d.W * d.batch
+            return tot
+
+        def weights(d):
+            return sum(d.chunks[c].nks for c in range(d.n_chunks)) * 32 * d.kh * d.kw * d.cout_pad
+        if kind == 'conv':
+            d = self.conv_desc(op.conv)
+            return conv_in(d) + conv_out(d) + weights(d)
+        if kind == 'gru_r':                                       # h, x in; r*h out (the residual IS the h window)
+            d = self.conv_desc(op.conv)
+            return conv_in(d) + 64 * esz * d.H * d.W * d.batch + weights(d)
+        if kind == 'resblock':                                    # input + output once; the intermediate stays in LDS
+            d1, d2 = self.conv_desc(op.conv), self.conv_desc(op.nch)
+            return conv_in(d1) + 64 * esz * d2.H * d2.W * d2.batch + weights(d1) + weights(d2)
+        if kind == 'gru_zq':                                      # h, x, r*h in; h' out; z stays on chip
+            dz, dq = self.conv_desc(op.conv), self.conv_desc(op.nch)
+            return conv_in(dz) + 64 * esz * dq.H * dq.W * dq.batch * 2 + weights(dz) + weights(dq)
+        px = H * W * nb
+        if kind == 'warp':
+            C_ = op.nch
+            e = esz if C_ == 64 else 4
+            shared = C_ == 64 and nb > 1 and not op.bt.a and not op.bt.b     # trunk features shared by the time instants of a window
+            return (2 * C_ * e * H * W * (1 if shared else nb)) + (C_ * e + 20) * px + (8 * esz * px if op.p[4] else 0)
+        if kind == 'cfr':
+            return 32 * px
+        if kind == 'pack':
+            return (sum(1 for i in range(32) if op.p[i]) * 4 + op.nch * esz) * px
+        if kind in ('fgac', 'gate'):
+            return ((2 if kind == 'fgac' else 3) * op.nch * esz + (8 if kind == 'fgac' else 4)) * H * W
+        if kind == 's2d':
+            return 12 * 4 * H * W + 48 * esz * (H // 2) * (W // 2)
+        if kind == 'overlay':
+            return 9 * 4 * H * W
+        if kind == 'viz':
+            return (op.nch * esz * (2 if op.b.ptr else 1) + 4) * H * W if op.conv == 0 else 8 * H * W
+        return 0
+
     def run_op(self, op, stream):
         L.check(self.lib.demfi_run_op(self._ctx, C.byref(op), stream), 'run_op')
 
@@ -410,7 +478,7 @@ class Engine:
         after op with an event between consecutive launches, so every kernel sees the cache state the real pipeline leaves it
         (a kernel timed in a loop of its own re-reads inputs that the 256 MB Infinity Cache kept from the previous repetition:
         warp_blend looked 25 % faster that way).  ``isolated=True`` is that per-op loop (kernel tuning only).
-        Returns a list of (segment, op kind, name, ms, macs, contexts in the launch)."""
+        Returns a list of (segment, op kind, name, ms, macs, contexts in the launch, algorithmic HBM bytes)."""
         stream = torch.cuda.current_stream(self.device)
         h = stream.cuda_stream
         if batched:                                           # the batched per-t plan: every launch covers all n_ctx contexts
@@ -453,7 +521,8 @@ class Engine:
             kind = KIND_NAME.get(op.kind, str(op.kind))
             if kind == 'warp':
                 kind = 'warp_fat' if op.nch == 64 else 'warp_thin'
-            out.append((sname, kind, op.name.decode(), t / reps, int(op.macs), max(1, int(op.bt.nb))))   # [5]: per-t contexts covered by a batched point-wise launch
+            out.append((sname, kind, op.name.decode(), t / reps, int(op.macs), max(1, int(op.bt.nb)),    # [5]: per-t contexts covered by a batched point-wise launch
+                        int(self.op_algorithmic_bytes(op))))                                            # [6]: algorithmic HBM bytes of the launch
         return out
 
     def n_launches(self, n_updates):
