@@ -540,7 +540,7 @@ void alloc_t(Layout& L, BufSet& s)
     L.thin(s, "stnew", 3, H, W);
     // planar flows / logits / frames packed to NHWC once, so the consuming convs stage them with vector loads
     L.fat(s, "misc16", H, W, 16);
-    if (L.c->dtype == DEMFI_F16) { L.fat(s, "ref16", H, W, 16); L.fat(s, "agg16", H, W, 16); }     // per-t planes only (fp16 plan)
+    if (L.c->dtype == DEMFI_F16) L.fat(s, "ref16", H, W, 16);     // per-t planes only (fp16 plan): S0p, S1p, Stp | rflow_t0, rflow_t1, occ logit | occ_0 | 0
     else { L.fat(s, "ref32", H, W, 32); L.fat(s, "agg3s", H, W, 32); }
     L.fat(s, "agg3d", H, W, 8);
     L.fat(s, "delta16", H, W, 16);               // 5 flow / occlusion planes + 11 zero channels: a full 32-byte record (one DMA piece)
@@ -1298,6 +1298,9 @@ struct Builder {
             std::vector<const float*> pl;
             for (int i = 0; i < 9; ++i) pl.push_back(plane(B["sharp1"], i));
             for (int i = 0; i < 5; ++i) pl.push_back(delta_p(0, i));
+            // round 6: channel 14 = occ_0, so that this ONE record also serves Dec_first_2's recursion-invariant per-t planes (rounds 2-5
+            // packed a second record, agg16 = S0p, S1p | occ_0 | rflow, from the same planes: one more launch per window, 0.29 ms)
+            pl.push_back(plane(B["occ"], 0));
             pack(th, pl, B["ref16"]);
             std::vector<int32_t> sel = range(0, 9), m = range(0, 14);
             for (int i = 25; i < 30; ++i) sel.push_back(i);
@@ -1305,12 +1308,8 @@ struct Builder {
             SubW w1 = sub_weight(p + "Mixer.conv_ref1", sel, true);
             conv(th, p + "Mixer.conv_ref1#t", {fsrc_map(B["ref16"], m)}, {D(fview(B["re1"]), range(0, 32), R, DEMFI_MODE_STORE, fview(TB["re1w"]))},
                  H, W, 1, 1, &w1.w, &w1.b, &w1.shape);
-            // iteration-invariant, t-dependent part of Agg3 (DeMFInet.py:151-155): S0p,S1p | occ_0 | rflow_t0,t1
-            std::vector<const float*> pa;
-            for (int i = 0; i < 6; ++i) pa.push_back(plane(B["sharp1"], i));
-            pa.push_back(plane(B["occ"], 0));
-            for (int i = 0; i < 4; ++i) pa.push_back(delta_p(0, i));
-            pack(th, pa, B["agg16"]);
+            // the iteration-invariant, t-dependent part of Agg3 (DeMFInet.py:151-155: S0p,S1p | occ_0 | rflow_t0,t1) is read from ref16
+            // through a channel map (dyn_m16 below)
         } else {
             {
                 std::vector<const float*> pl;
@@ -1343,14 +1342,16 @@ struct Builder {
         SubW w_dyn, w_rec;
         std::vector<int32_t> dyn_m16 = range(0, 11);
         if (c->dtype == DEMFI_F16) {
-            // per recursion: ONE narrow launch over [agg16 (11 t-dependent, recursion-invariant planes) | agg3d (8 planes of this
+            // per recursion: ONE narrow launch over [ref16 (its 11 planes Agg3 holds: t-dependent, recursion-invariant) | agg3d (8 planes of this
             // recursion)] + bias + the window-constant share (g_pw, trunk) -> g_p2; then the F_rec part on the 64 -> 64 kernel
             std::vector<int32_t> sel = range(0, 6);                  // S0p, S1p | occ_0 | rflow_t0, rflow_t1 (agg16 order)
             for (int i = 73; i < 78; ++i) sel.push_back(i);
             sel.insert(sel.end(), a3d_sel.begin(), a3d_sel.end());
             w_dyn = sub_weight("Dec_first_2", sel, true);
             w_rec = sub_weight("Dec_first_2", range(9, 73), false);
-            dyn_m16.insert(dyn_m16.end(), 5, -1);
+            // ref16 channel -> input channel of the sub-layer (sel order): S0p, S1p -> 0..5; Stp unused; rflow_t0, rflow_t1 -> 7..10; the
+            // occlusion logit unused; occ_0 (channel 14) -> 6
+            dyn_m16 = {0, 1, 2, 3, 4, 5, -1, -1, -1, 7, 8, 9, 10, -1, 6, -1};
         }
         // ============================ recursive boosting, one list per iteration ====================================
         // SepConvGRU (838-857): z | r share their input -> one 128-cout conv (fp32 plan, DEMFI_GRU6=0); round 6, fp16: see fuse_gru
@@ -1417,7 +1418,7 @@ struct Builder {
             warp(sg, "warp_thin", 3, tview(B["sharp1"], 0), tview(B["sharp1"], 3), tview(B["stnew"]), delta_p(it + 1, 0), delta_p(it + 1, 2),
                  delta_p(it + 1, 4), plane(B["occ"], it + 1), tp, ptr(B["agg3d"]));
             if (c->dtype == DEMFI_F16) {
-                conv(sg, "Dec_first_2#dyn", {fsrc_map(B["agg16"], dyn_m16), fsrc_map(B["agg3d"], range(11, 19))},
+                conv(sg, "Dec_first_2#dyn", {fsrc_map(B["ref16"], dyn_m16), fsrc_map(B["agg3d"], range(11, 19))},
                      {D(fview(B["g_p2"]), range(0, 64), DEMFI_ACT_NONE, DEMFI_MODE_STORE, fview(TB["g_pw"]))}, H, W, 1, 1, &w_dyn.w, &w_dyn.b,
                      &w_dyn.shape);
                 conv(sg, "Dec_first_2#rec", {fsrc(hout, 0)}, {D(fview(B["g_a"]), range(0, 64), R, DEMFI_MODE_STORE, fview(B["g_p2"]))}, H, W,
@@ -1740,7 +1741,7 @@ extern "C" int demfi_ctx_create(int H, int W, int max_updates, int dtype, const 
         if (c->n_ctx > 1) { per_t_all.push_back(&c->tb_head_ops[0]); for (int it = 0; it < c->N; ++it) per_t_all.push_back(&c->tb_iter_ops[0][it]); }
         const ArenaPlan pt = plan_arena(c, c->t_bufs[0][0], c->n_ctx, per_t, none,
                                         {"Ft", "u1", "u2", "u3", "d0", "d1", "d2", "rF", "dec_a", "dec_t", "dec_b", "frec0", "frec1", "re1", "rd64", "de1",
-                                         "bl1", "xb", "zb", "rh", "h1", "fo1", "g_a", "g_t", "g_b", "g_p2", "misc16", "ref16", "agg16", "ref32", "agg3s"});
+                                         "bl1", "xb", "zb", "rh", "h1", "fo1", "g_a", "g_t", "g_b", "g_p2", "misc16", "ref16", "ref32", "agg3s"});
         const ArenaPlan ptr_ = plan_arena(c, c->tr_bufs[0], 0, tr, per_t_all,
                                           {"s2d", "f1", "x0", "grow", "gffcat", "g0", "g1", "up", "enc_a", "enc_t", "enc_b", "rk", "skk", "rkp", "skp",
                                            "smp", "E", "wg"});

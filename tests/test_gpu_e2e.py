@@ -120,7 +120,7 @@ def test_batch_of_same_window_runs_the_batched_plan_bit_identically(dtype):
         m._engines.pop((H, W, dtype, 'batch'), None)
         d1, fin, flows, occs, ov = m(xb, t, N, **kw)
         batched = (H, W, dtype, 'batch') in m._engines
-        assert batched == (xb.stride(0) == 0 or bool(kw))
+        assert batched == (xb.stride(0) == 0 or bool(kw.get('same_window')))
         if batched:
             assert m._engines[(H, W, dtype, 'batch')].n_ctx == B
         assert tuple(fin[N - 1][2].shape) == (B, 3, H, W) and tuple(ov.shape) == (B, 3, H, W)
