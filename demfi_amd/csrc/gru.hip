@@ -235,9 +235,11 @@ __global__ __launch_bounds__(G_NTHREADS, 1) void gru_sep5_kernel(const GArgs a)
             issue_piece(a.rh, S1, img, P0, L0, false);
             issue_piece(a.x, S2, img, P0, L0, false);
             // A helper's VMEM instruction takes ~400 cycles while the MFMA waves of its SIMD run a matrix phase and 130-220 while they are in
-            // their epilogues (profiles/r06_gru_phase_trace.txt).  Per tile: the previous tile's 8 output stores and the wait for x under
-            // phase A, the next tile's h (12 DMA instructions) under phase B, r*h (12) under the sigmoid / tanh pass, x (12) after the staged
-            // outputs have been read.  Barrier E doubles as "the next tile's h, r*h have landed": no barrier in front of phase A.
+            // their epilogues, and it slows the matrix phase it runs beside (profiles/r06_gru_phase_trace.txt, r06_resblock_store_timing_ab.txt).
+            // Per tile: x (8 DMA instructions; 12 at a strip start) under phase A -- it needs the staged outputs read first --, the next tile's h
+            // (8) under phase B, its r*h (8) under the sigmoid / tanh pass, the previous tile's 8 output stores under the blend (round 6: they
+            // ran under phase A, which took 6 950 cycles with them and 5 870 without).
+            // Barrier E doubles as "the next tile's h, r*h have landed": no barrier in front of phase A.
             u4_t stage[TL];
             bool have_prev = false;
             int pimg = 0, pP0 = 0, pL0 = 0;
@@ -261,27 +263,28 @@ __global__ __launch_bounds__(G_NTHREADS, 1) void gru_sep5_kernel(const GArgs a)
             G_STAMP(wave, trk, 0);
             asm volatile("s_barrier" ::: "memory");             // A0
             for (;;) {
-                // the MFMA waves are in phase A of this tile
+                // the MFMA waves are in phase A of this tile; this tile's x was issued behind barrier E of the previous one
                 const bool more = it + 1 < it1;
-                bool exact = false;
-                if (have_prev) exact = do_stores(pimg, pP0, pL0);                          // the previous tile's outputs, under phase A
-                if (exact) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TL) : "memory");      // x (older than the stores) has landed
-                else       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // x has landed (older: the stores of tile k - 2)
                 G_STAMP(wave, trk, 1);
                 asm volatile("s_barrier" ::: "memory");         // B: x has landed; every MFMA wave is done with h, r*h
                 int nimg = img, nP0 = P0, nL0 = L0;
                 bool carry = false;
-                if (more) {
+                if (more) {                                      // the next tile's h (8 DMA instructions, 12 at a strip start) under phase B ...
                     pos_of(it + 1, nimg, nP0, nL0);
                     carry = nimg == img && nP0 == P0 && nL0 == L0 + TL;
-                    issue_piece(a.h, S0, nimg, nP0, nL0, carry);  // 8 (12 at a strip start) instructions under phase B ...
+                    issue_piece(a.h, S0, nimg, nP0, nL0, carry);
                 }
                 G_STAMP(wave, trk, 2);
                 asm volatile("s_barrier" ::: "memory");         // C: every MFMA wave is done with x
-                if (more) issue_piece(a.rh, S1, nimg, nP0, nL0, carry); // ... 8 under the sigmoid / tanh pass
+                // ... r*h (8) under the sigmoid / tanh pass.  Both there (16) delay barrier D by ~1 400 cycles: measured, profiles/r06_notes.md
+                if (more) issue_piece(a.rh, S1, nimg, nP0, nL0, carry);
                 G_STAMP(wave, trk, 3);
                 asm volatile("s_barrier" ::: "memory");         // D: q~ is in LDS
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the next tile's h, r*h have landed: E tells the MFMA waves
+                bool exact = false;
+                if (have_prev) exact = do_stores(pimg, pP0, pL0);                          // the previous tile's outputs (8 stores) under the blend
+                if (exact) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TL) : "memory");      // the next tile's h, r*h (older than the stores) have landed:
+                else       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // E tells the MFMA waves
                 G_STAMP(wave, trk, 4);
                 asm volatile("s_barrier" ::: "memory");         // E: h' is staged
                 {

@@ -22,8 +22,8 @@
 //   a chain (strip start or workgroup start) opens with a conv1-only step on the 16 rows above to produce the carried lines.
 // Horizontal halo: a strip computes 32 intermediate columns for 30 outputs (conv1 x 1.07, conv2 32/30 of a tile wide).
 // Roles by wave age as in the staged-store kernel: MFMA waves 0-3 (cout half x row half) touch global memory only for their A
-// fragments; helper waves 4-7 issue the window DMA, read the staged outputs back 8 lanes per pixel and store whole 128-byte
-// lines with the streaming hint.  Four raw s_barriers per step of 2 x 288 MFMAs per wave (18 432 matrix-pipe cycles).
+// fragments; helper waves 4-7 issue the window DMA (under conv2's MFMA phase), read the staged outputs back 8 lanes per pixel and store
+// whole 128-byte lines with the streaming hint (round 6: under conv1's epilogue, not its MFMA phase).  Four raw s_barriers per step of 2 x 288 MFMAs per wave (18 432 matrix-pipe cycles).
 #include "common.h"
 #include <type_traits>
 #include <vector>
@@ -49,6 +49,10 @@ constexpr int RB_NIW = (RB_IN_NI + RB_NH - 1) / RB_NH;           // 20 DMA instr
 #define DEMFI_RB_DEPTH 4                                         // A prefetch distance in steps of 8 MFMAs (6: 14 registers spilled at the 256-register limit)
 #endif
 constexpr int RB_DEPTH = DEMFI_RB_DEPTH;
+#ifndef DEMFI_RB_STORE_AT
+#define DEMFI_RB_STORE_AT 1                                      // round 6: the output stores under conv1's EPILOGUE (0: under its MFMA phase, round 5)
+#endif
+constexpr int RB_STORE_AT = DEMFI_RB_STORE_AT;
 constexpr int RB_NSTEP = 36;                                     // (kx, k-step) groups x ky
 static_assert(RB_NSTEP % RB_DEPTH == 0, "static ring indices");
 static_assert(RB_LDS <= 160 * 1024, "LDS budget");
@@ -222,15 +226,22 @@ __global__ __launch_bounds__(RB_NTHREADS, 1) void resblock3x3_c64_kernel(const R
             RB_STAMP(wave, trk, 0);
             asm volatile("s_barrier" ::: "memory");             // A
             RB_STAMP(wave, trk, 1);
-            if (have_prev) { stage_read(); stage_store(p_img, p_x0, p_row0); }
+            // DEMFI_RB_STORE_AT: 0 = the 16 output stores right here, under the conv1 MFMA phase (round 5); 1 (product since round 6) =
+            // behind barrier B, under conv1's EPILOGUE: the stores and the MFMA waves' A-fragment loads share the CU's one memory pipe, and
+            // a matrix phase without the helpers' VMEM traffic runs at 0.93 of the pipe instead of 0.81 (conv1 phase 11 400 -> 9 950
+            // cycles, step 28 900 -> 27 400, launch -3 %: profiles/r06_resblock_store_timing_ab.txt); the epilogue issues no VMEM itself
+            if (have_prev) { stage_read(); if constexpr (RB_STORE_AT == 0) stage_store(p_img, p_x0, p_row0); }
             RB_STAMP(wave, trk, 2);
             asm volatile("s_barrier" ::: "memory");             // B: the staged outputs are in registers -> the M lines are free
+            if constexpr (RB_STORE_AT == 1) { if (have_prev) stage_store(p_img, p_x0, p_row0); }
             RB_STAMP(wave, trk, 3);
             asm volatile("s_barrier" ::: "memory");             // C: every MFMA wave is done with the input window
             RB_STAMP(wave, trk, 4);
             int nit = it;
             bool npro = false, more = true;
             if (!pro) { nit = it + 1; more = nit < it1; npro = more && opens_chain(nit); }
+            // (measured negative, round 6: the window DMA as a burst at s_setprio 3 -- issued in 3 300 instead of 8 300 cycles, conv2's MFMA
+            // phase 11 900 -> 12 750 cycles: profiles/r06_resblock_store_timing_ab.txt)
             if (more) issue_window(nit, npro);
             RB_STAMP(wave, trk, 5);
             asm volatile("s_barrier" ::: "memory");             // D

@@ -6,7 +6,7 @@
 Stamps (shader cycles) per tile of workgroups 0..31.
 ZQ, MFMA waves: 1 start of phase A (released from E of the previous tile), 2 phase A (h resp. r*h) done, 3 released from B, 4 phase B (x) done,
     5 released from C, 6 h prefetch + sigmoid done (z waves) / tanh done + q~ written (q waves), 7 released from D, 8 blend + staging done (z waves).
-ZQ, helpers: 1 previous stores issued + x landed, 2 next h DMA issued (after B), 3 next r*h DMA issued (after C), 4 next h, r*h landed (after D),
+ZQ, helpers: 1 x landed, 2 next h DMA issued (after B), 3 next r*h DMA issued (after C), 4 previous stores issued + next h, r*h landed (after D),
     5 staged outputs read + next x DMA issued (after E).
 R, MFMA waves: 0 arrive A, 1 released, 2 phase A (x) done, 3 released from B, 4 phase B (h) done, 5 epilogue + stores issued.
 R, helpers: 0 x landed, 1 h landed, 2 x' issued, 3 h' issued."""
@@ -86,8 +86,8 @@ def main():
         nx = tr[:, w, lo + 1:hi + 1, :]
         d = lambda i, j: m(s[..., i] - s[..., j])
         if mode == 'zq':
-            print('  helper %d: (E) -> stage read + x\' (12) %6.0f | 8 stores + x landed %6.0f | (B) h\' issued (12) %6.0f | (C) rh\' issued (12) %6.0f | (D) h\', rh\' landed %6.0f | -> released E %6.0f' %
-                  (w - 4, m(s[..., 5] - s[..., 4]), m(nx[..., 1] - s[..., 5]), d(2, 1), d(3, 2), d(4, 3), m(nx[..., 4] - s[..., 4]) - m(s[..., 5] - s[..., 4]) - m(nx[..., 1] - s[..., 5]) - d(2, 1) - d(3, 2) - d(4, 3)))
+            print('  helper %d: (E) -> stage read + x\' (8) %6.0f | x landed %6.0f | (B) h\' issued (8) %6.0f | (C) rh\' issued (8) %6.0f | (D) 8 stores + h\', rh\' landed %6.0f' %
+                  (w - 4, m(s[..., 5] - s[..., 4]), m(nx[..., 1] - s[..., 5]), d(2, 1), d(3, 2), d(4, 3)))
         else:
             print('  helper %d: (x landed) -> h landed %6.0f | -> x\' issued (20) %6.0f | -> h\' issued (after C) %6.0f | -> x landed %6.0f' %
                   (w - 4, d(1, 0), d(2, 1), d(3, 2), m(nx[..., 0] - s[..., 3])))
