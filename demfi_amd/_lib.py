@@ -110,6 +110,8 @@ _SIGS = {
                                            C.c_void_p]),
     'demfi_cfr_flow_align_batched': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                                C.POINTER(Batch), C.c_void_p]),
+    'demfi_cfr_flow_align_pack': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_int, C.POINTER(Batch), C.c_void_p]),
     'demfi_pack_planes_batched': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.POINTER(Batch),
                                             C.c_void_p]),
     'demfi_fgac_gather': (C.c_int, [C.POINTER(View), C.c_void_p, C.POINTER(View), C.c_int, C.c_int, C.c_int,

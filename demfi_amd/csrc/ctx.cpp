@@ -1168,19 +1168,23 @@ struct Builder {
         const Tensor& aF = TB["aF"];
         const Tensor& x = TB["x"];
         const void* tp = ptr(B["t"]);
+        static const bool cfr_pack = !(getenv("DEMFI_CFR_PACK") && atoi(getenv("DEMFI_CFR_PACK")) == 0);
         auto delta_v = [&](int step, int ch) { return tview(B["delta"], 5 * step + ch); };
         auto delta_p = [&](int step, int ch) { return plane(B["delta"], 5 * step + ch); };
         // ============================ per-t head: CFR, FWB, refinement, D1, Ch_Reducer ==============================
         {
             demfi_op o = blank();
             o.p[0] = ptr(ffo); o.p[1] = ptr(ffo) + 2 * hw4; o.p[2] = ptr(B["cfr_acc"]); o.p[3] = ptr(B["ft"]); o.t = tp;
+            // round 6: the finish also writes misc16 = [flow_t0, flow_t1 | flow_01, flow_10, occ logit | 0] (the thin members of Agg1, 77) as the
+            // NHWC record enc1 stages: one plane-pack launch per window less (DEMFI_CFR_PACK=0: the pack launch of rounds 1-5)
+            if (cfr_pack) { o.p[4] = ptr(ffo) + 4 * hw4; o.p[5] = ptr(B["misc16"]); }
             simple(th, DEMFI_OP_CFR, "cfr", o);
         }
         warp(th, "warp_fat", 64, fview(TB["F01"], 0, 0), fview(TB["F01"], 0, 1), fview(B["Ft"], 0, 0), ptr(B["ft"]), ptr(B["ft"]) + 2 * hw4,
              ptr(ffo) + 4 * hw4, nullptr, tp);
         std::string p = "Refine_Module.";
         // Agg1 = cat[aF0, aF1, Ft, flow_t0, flow_t1, flow_01, flow_10, occ_0_logit] (DeMFInet.py:77)
-        {
+        if (!cfr_pack) {
             std::vector<const float*> pl;
             for (int i = 0; i < 4; ++i) pl.push_back(plane(B["ft"], i));
             for (int i = 0; i < 5; ++i) pl.push_back(plane(ffo, i));
@@ -1504,7 +1508,7 @@ void op_accesses(const demfi_ctx* c, const demfi_op& op, std::vector<std::pair<c
     case DEMFI_OP_FGAC_WINDOW: rd(op.a.ptr); rd(op.b.ptr); rd(op.p[0]); wr(op.o.ptr); break;
     case DEMFI_OP_AVG_POOL: rd(op.a.ptr); wr(op.o.ptr); break;
     case DEMFI_OP_GATE: rd(op.p[0]); rd(op.a.ptr); rd(op.b.ptr); wr(op.o.ptr); break;
-    case DEMFI_OP_CFR: rd(op.p[0]); rd(op.p[1]); rd(op.p[2]); wr(op.p[2]); wr(op.p[3]); rd(op.t); break;
+    case DEMFI_OP_CFR: rd(op.p[0]); rd(op.p[1]); rd(op.p[2]); rd(op.p[4]); wr(op.p[2]); wr(op.p[3]); wr(op.p[5]); rd(op.t); break;
     case DEMFI_OP_WARP: rd(op.a.ptr); rd(op.b.ptr); rd(op.p[0]); rd(op.p[1]); rd(op.p[2]); rd(op.t); wr(op.o.ptr); wr(op.p[3]); wr(op.p[4]); break;
     default: break;
     }
@@ -2038,6 +2042,9 @@ extern "C" int demfi_run_op(demfi_ctx* c, const demfi_op* op, void* stream)
     case DEMFI_OP_GATE:
         return demfi_gate_blend((const float*)op->p[0], &op->a, &op->b, &op->o, op->nch, H, W, stream);
     case DEMFI_OP_CFR:
+        if (op->p[5])
+            return demfi_cfr_flow_align_pack((const float*)op->p[0], (const float*)op->p[1], (const float*)op->p[4], (const float*)op->t, H, W,
+                                             (int64_t*)op->p[2], (float*)op->p[3], (void*)op->p[5], c->dtype, op->bt.nb > 1 ? &op->bt : nullptr, stream);
         if (op->bt.nb > 1)
             return demfi_cfr_flow_align_batched((const float*)op->p[0], (const float*)op->p[1], (const float*)op->t, H, W, (int64_t*)op->p[2],
                                                 (float*)op->p[3], &op->bt, stream);

@@ -113,7 +113,11 @@ __device__ __forceinline__ int cfr_target(const CfrSrc& s, int cidx, int y, int 
 __device__ __forceinline__ unsigned long long cfr_fix(float p) { return (unsigned long long)__double2ll_rn((double)p * FIX); }
 
 // One thread per SOURCE pixel and flow: debug index maps for every source, global accumulation for the far ones only.
-struct CfrBatch { int64_t f01, f10, t, acc, out; };          // byte strides between per-t contexts (blockIdx.y)
+struct CfrBatch { int64_t f01, f10, t, acc, out, logit, pack; };   // byte strides between per-t contexts (blockIdx.y)
+// optional packed copy written by the finish (round 6): the NHWC record Refine_Module.enc1 stages with vector loads -- 16 channels of
+// the path dtype = [flow_t0 (2), flow_t1 (2) | flow_01 (2), flow_10 (2), occlusion logit | 7 zeros] (the thin members of Agg1,
+// DeMFInet.py:77), i.e. what a demfi_pack_planes launch over these nine planes produced in rounds 1-5
+struct CfrPack { void* rec; const float* logit; int f32; };
 __global__ void cfr_far_kernel(const float* __restrict__ flow01, const float* __restrict__ flow10,
                                const float* __restrict__ tptr, int H, int W, long long* __restrict__ acc,
                                int* __restrict__ tile_flag, int* __restrict__ dbg, CfrBatch bt)
@@ -154,13 +158,14 @@ __global__ void cfr_far_kernel(const float* __restrict__ flow01, const float* __
 __global__ __launch_bounds__(NT) void cfr_tile_kernel(const float* __restrict__ flow01, const float* __restrict__ flow10,
                                                       const float* __restrict__ tptr, int H, int W,
                                                       long long* __restrict__ acc, int* __restrict__ tile_flag,
-                                                      float* __restrict__ out, CfrBatch bt)
+                                                      float* __restrict__ out, CfrBatch bt, CfrPack pk)
 {
     __shared__ unsigned long long lacc[6][CFR_TH * CFR_TW];       // [flow k][img0, img1, weight] -> 48 KiB
     {
         const int q = blockIdx.y;
         flow01 = bofs(flow01, q * bt.f01); flow10 = bofs(flow10, q * bt.f10); tptr = bofs(tptr, q * bt.t);
         acc = bofs(acc, q * bt.acc); tile_flag = bofs(tile_flag, q * bt.acc); out = bofs(out, q * bt.out);
+        pk.rec = bofs((char*)pk.rec, q * bt.pack); pk.logit = bofs(pk.logit, q * bt.logit);
     }
     const int64_t hw = (int64_t)H * W;
     const int tiles_x = (W + CFR_TW - 1) / CFR_TW;
@@ -252,6 +257,7 @@ __global__ __launch_bounds__(NT) void cfr_tile_kernel(const float* __restrict__ 
         const float norm = omt * n0 + t * n1;                                   // 617
         const float m = norm > 0.0f ? 1.0f : 0.0f;                              // 618
         const float ca = (-omt) * t, cb = t * t, cc = omt * omt, cd = t * omt;
+        float ftv[4];
 #pragma unroll
         for (int ch = 0; ch < 2; ++ch) {
             float ft0 = ca * f01[ch] + cb * f10[ch];                            // 614
@@ -260,6 +266,30 @@ __global__ __launch_bounds__(NT) void cfr_tile_kernel(const float* __restrict__ 
             ft1 = (1.0f - m) * ft1 + m * (ft1 / (norm + (1.0f - m)));           // 620
             out[(int64_t)ch * hw + i] = ft0;
             out[(int64_t)(2 + ch) * hw + i] = ft1;
+            ftv[ch] = ft0; ftv[2 + ch] = ft1;
+        }
+        if (pk.rec) {
+            // [flow_t0, flow_t1 | flow_01, flow_10, logit | zeros]: the same fp32 -> path-dtype conversion as the pack kernel's
+            const float v9[9] = {ftv[0], ftv[1], ftv[2], ftv[3], flow01[i], flow01[hw + i], flow10[i], flow10[hw + i], pk.logit[i]};
+            if (pk.f32) {
+                float* r = (float*)pk.rec + i * 16;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f4_t o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = 4 * q + j < 9 ? v9[4 * q + j] : 0.0f;
+                    *(f4_t*)(r + 4 * q) = o;
+                }
+            } else {
+                half_t* r = (half_t*)pk.rec + i * 16;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    h8_t o;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] = 8 * q + j < 9 ? (half_t)v9[8 * q + j] : (half_t)0.0f;
+                    *(h8_t*)(r + 8 * q) = o;
+                }
+            }
         }
     }
     __syncthreads();
@@ -859,14 +889,17 @@ extern "C" int demfi_cfr_reset(int64_t* acc, int H, int W, void* stream)
 }
 
 static int cfr_impl(const float* flow01, const float* flow10, const float* t, int H, int W, int64_t* acc, float* out, int32_t* dbg_idx,
-                    const demfi_batch* bt, void* stream)
+                    const demfi_batch* bt, void* stream, const float* logit = nullptr, void* pack16 = nullptr, int pack_dtype = DEMFI_F16)
 {
     if (!flow01 || !flow10 || !t || !acc || !out || H <= 0 || W <= 0 || (int64_t)H * W >= (1ll << 31))
         return demfi_set_error(DEMFI_ERR_ARG, "demfi_cfr_flow_align: bad args");
     const int nb = bt && bt->nb > 1 ? bt->nb : 1;
     if (nb > 1 && dbg_idx) return demfi_set_error(DEMFI_ERR_ARG, "demfi_cfr_flow_align_batched: no debug maps in a batched launch");
-    CfrBatch cb = {0, 0, 0, 0, 0};
-    if (nb > 1) { cb.f01 = bt->p[0]; cb.f10 = bt->p[1]; cb.t = bt->t; cb.acc = bt->p[2]; cb.out = bt->p[3]; }
+    if ((pack16 != nullptr) != (logit != nullptr) || (pack_dtype != DEMFI_F16 && pack_dtype != DEMFI_F32))
+        return demfi_set_error(DEMFI_ERR_ARG, "demfi_cfr_flow_align_pack: the packed record needs the occlusion-logit plane (and a path dtype)");
+    CfrBatch cb = {0, 0, 0, 0, 0, 0, 0};
+    if (nb > 1) { cb.f01 = bt->p[0]; cb.f10 = bt->p[1]; cb.t = bt->t; cb.acc = bt->p[2]; cb.out = bt->p[3]; cb.logit = bt->p[4]; cb.pack = bt->p[5]; }
+    const CfrPack pk = {pack16, logit, pack_dtype == DEMFI_F32 ? 1 : 0};
     hipStream_t st = (hipStream_t)stream;
     const int64_t hw = (int64_t)H * W;
     int* tile_flag = (int*)(acc + 6 * hw);                       // behind the six int64 planes (demfi_cfr_workspace_bytes)
@@ -874,9 +907,16 @@ static int cfr_impl(const float* flow01, const float* flow10, const float* t, in
                        (long long*)acc, tile_flag, dbg_idx, cb);
     const int ntile = ((W + CFR_TW - 1) / CFR_TW) * ((H + CFR_TH - 1) / CFR_TH);
     hipLaunchKernelGGL(cfr_tile_kernel, dim3(8 * ((ntile + 7) / 8), nb), dim3(NT), 0, st, flow01, flow10, t, H, W,
-                       (long long*)acc, tile_flag, out, cb);
+                       (long long*)acc, tile_flag, out, cb, pk);
     DEMFI_HIP_CHECK(hipGetLastError());
     return DEMFI_OK;
+}
+
+extern "C" int demfi_cfr_flow_align_pack(const float* flow01, const float* flow10, const float* logit, const float* t, int H, int W, int64_t* acc,
+                                         float* out, void* pack16, int pack_dtype, const demfi_batch* bt, void* stream)
+{
+    if (bt && (bt->nb < 1 || bt->nb > 64)) return demfi_set_error(DEMFI_ERR_ARG, "demfi_cfr_flow_align_pack: batch description");
+    return cfr_impl(flow01, flow10, t, H, W, acc, out, nullptr, bt, stream, logit, pack16, pack_dtype);
 }
 
 extern "C" int demfi_cfr_flow_align(const float* flow01, const float* flow10, const float* t, int H, int W,

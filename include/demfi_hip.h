@@ -284,6 +284,11 @@ int demfi_warp_blend_batched(const demfi_view* A, const float* fa, const demfi_v
 /* p order: flow01, flow10, acc, out (kind CFR) */
 int demfi_cfr_flow_align_batched(const float* flow01, const float* flow10, const float* t, int H, int W, int64_t* acc, float* out,
                                  const demfi_batch* bt, void* stream);
+/* The same with the packed copy the next layer reads (ABI v8; p order of a batched launch: flow01, flow10, acc, out, logit, pack16): the finish
+ * also writes pack16 = NHWC [H,W,16] of pack_dtype holding [flow_t0, flow_t1 | flow_01, flow_10, logit | 7 zeros] -- the thin members of Agg1
+ * (DeMFInet.py:77) as Refine_Module.enc1 stages them -- replacing a demfi_pack_planes launch per window.  logit: planar fp32 [H,W]; bt may be NULL. */
+int demfi_cfr_flow_align_pack(const float* flow01, const float* flow10, const float* logit, const float* t, int H, int W, int64_t* acc,
+                              float* out, void* pack16, int pack_dtype, const demfi_batch* bt, void* stream);
 
 /* bilinear_sampler at ABSOLUTE flow coordinates (FGAC, DeMFInet.py:413-419, 499-514; rr = sr = 0):
  * src, out fat views with C channels; flow planar fp32 [2,H,W]. */

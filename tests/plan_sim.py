@@ -273,6 +273,10 @@ class PlanSim:
                 out = self.planes(op.p[3], 4, H, W)
                 out[0:2].copy_(a[0])
                 out[2:4].copy_(bb[0])
+                if op.p[5] is not None:                                    # round 6: the packed record [ft | flow_01, flow_10, logit | 0] for enc1
+                    pk = self.strided(L.View(op.p[5], 16, W * 16, 1, 0, 1 if f32 else 0, 0), 16, H, W)
+                    pk.copy_(torch.cat([out, self.planes(op.p[0], 2, H, W), self.planes(op.p[1], 2, H, W), self.planes(op.p[4], 1, H, W),
+                                        torch.zeros(7, H, W)], 0).to(pk.dtype))
             elif k == 7:                                                   # warp + blend
                 t = self.planes(op.t, 1, 1, 1).view(1, 1, 1, 1)
                 A = self.strided(op.a, op.nch, H, W).float()[None]

@@ -683,6 +683,45 @@ def test_cfr_vs_reference_goldens(golden_dir):
                 assert np.array_equal(dbg[k, c].cpu().numpy(), exp), (i, k, c)
 
 
+@pytest.mark.parametrize('dtype', [torch.float16, torch.float32])
+def test_cfr_writes_the_packed_record_of_the_next_layer(dtype):
+    """Round 6: demfi_cfr_flow_align_pack -- the finish also writes the NHWC record [flow_t0, flow_t1 | flow_01, flow_10, logit | 7 zeros] that
+    Refine_Module.enc1 stages (the thin members of Agg1, DeMFInet.py:77): bit-identical to demfi_pack_planes over the same nine planes, the
+    planar outputs identical to the plain entry point; single launch and a batched one (two contexts with their own t and strides)."""
+    torch.manual_seed(5)
+    H, W = 72, 136
+    lib = L.load()
+    dt = L.F32 if dtype == torch.float32 else L.F16
+    f01 = (torch.randn(2, H, W, device=DEV) * 7).contiguous()
+    f10 = (torch.randn(2, H, W, device=DEV) * 7).contiguous()
+    logit = torch.randn(H, W, device=DEV)
+    nacc = lib.demfi_cfr_workspace_bytes(H, W) // 8
+    for nb in (1, 2):
+        t = torch.tensor([0.375, 0.75], device=DEV)[:nb].contiguous()
+        acc = torch.zeros(nb, nacc, dtype=torch.int64, device=DEV)
+        out = torch.zeros(nb, 4, H, W, device=DEV)
+        rec = torch.full((nb, H, W, 16), -3.0, dtype=dtype, device=DEV)
+        bt = L.Batch()
+        bt.nb = nb
+        bt.t = 4
+        bt.p[2], bt.p[3], bt.p[5] = nacc * 8, 4 * H * W * 4, H * W * 16 * rec.element_size()      # flows and logit: window-level (stride 0)
+        L.check(lib.demfi_cfr_flow_align_pack(f01.data_ptr(), f10.data_ptr(), logit.data_ptr(), t.data_ptr(), H, W, acc.data_ptr(), out.data_ptr(),
+                                              rec.data_ptr(), dt, C.byref(bt) if nb > 1 else None, _stream()))
+        torch.cuda.synchronize()
+        assert int(acc.abs().max()) == 0                           # the workspace is left all-zero
+        for q in range(nb):
+            acc1 = torch.zeros(nacc, dtype=torch.int64, device=DEV)
+            out1 = torch.zeros(4, H, W, device=DEV)
+            L.check(lib.demfi_cfr_flow_align(f01.data_ptr(), f10.data_ptr(), t[q:q + 1].data_ptr(), H, W, acc1.data_ptr(), out1.data_ptr(), None, _stream()))
+            assert torch.equal(out[q], out1)
+            exp = torch.full((H, W, 16), -3.0, dtype=dtype, device=DEV)
+            planes = [out1[i] for i in range(4)] + [f01[0], f01[1], f10[0], f10[1], logit]
+            ptrs = (C.c_void_p * 16)(*([p_.data_ptr() for p_ in planes] + [None] * 7))
+            L.check(lib.demfi_pack_planes(ptrs, 16, exp.data_ptr(), dt, 16, H, W, _stream()))
+            torch.cuda.synchronize()
+            assert torch.equal(rec[q], exp)
+
+
 def test_cfr_is_deterministic():
     torch.manual_seed(1)
     H, W = 96, 160
