@@ -2047,9 +2047,12 @@ int launch_narrow(const demfi_conv* h, const demfi_conv* dev, hipStream_t st, bo
             if (h->pack.ptr != nullptr) {                        // packed copy: the deltas' producers have 1 or 2 live octets
                 DEMFI_LDS_ATTR((conv3x3_narrow_persist_kernel<1, REC, 2, KS, ND, 1, true>));
                 DEMFI_LDS_ATTR((conv3x3_narrow_persist_kernel<1, REC, 2, KS, ND, 2, true>));
+                DEMFI_LDS_ATTR((conv3x3_narrow_persist_kernel<1, REC, 2, KS, ND, 4, true>));
                 if (noct == 1)      hipLaunchKernelGGL((conv3x3_narrow_persist_kernel<1, REC, 2, KS, ND, 1, true>), dim3(grid), blk, lds, st, dev);
                 else if (noct == 2) hipLaunchKernelGGL((conv3x3_narrow_persist_kernel<1, REC, 2, KS, ND, 2, true>), dim3(grid), blk, lds, st, dev);
-                else return demfi_set_error(DEMFI_ERR_ARG, "demfi_conv2d: packed copy needs 1 or 2 live octets, got %d", noct);
+                // round 6: two column parities of dec3's flow / occlusion planes in one launch (4 live octets, each with its own piece of the record)
+                else if (noct == 4) hipLaunchKernelGGL((conv3x3_narrow_persist_kernel<1, REC, 2, KS, ND, 4, true>), dim3(grid), blk, lds, st, dev);
+                else return demfi_set_error(DEMFI_ERR_ARG, "demfi_conv2d: packed copy needs 1, 2 or 4 live octets, got %d", noct);
             } else
             if (noct == 1)      hipLaunchKernelGGL((conv3x3_narrow_persist_kernel<1, REC, 2, KS, ND, 1>), dim3(grid), blk, lds, st, dev);
             else if (noct == 2) hipLaunchKernelGGL((conv3x3_narrow_persist_kernel<1, REC, 2, KS, ND, 2>), dim3(grid), blk, lds, st, dev);

@@ -1235,7 +1235,11 @@ struct Builder {
             // 64-channel feature halves (tanh + residual aF0 / aF1) go to the staged-store 64 -> 64 kernel and the 5 flow / occlusion
             // planes to a 32-cout launch.
             const Layer l9 = {l3.cout, l3.cin, 3, 3};
-            for (int dy = 0; dy < 2 && status >= 0; ++dy)
+            // round 6: the flow / occlusion planes of the two column parities of a row parity in ONE launch (10 couts = 4 live octets of a
+            // 32-cout subtile that the per-parity launches filled with 5): 4 -> 2 launches of the thin kernel (DEMFI_DEC3F_PAIR=0: one per parity)
+            static const bool f_pair = !(getenv("DEMFI_DEC3F_PAIR") && atoi(getenv("DEMFI_DEC3F_PAIR")) == 0);
+            for (int dy = 0; dy < 2 && status >= 0; ++dy) {
+                std::vector<float> wf2, bf2;
                 for (int dx = 0; dx < 2 && status >= 0; ++dx) {
                     std::vector<float> w9e, b2;
                     if (!dry) {
@@ -1269,6 +1273,11 @@ struct Builder {
                     conv(th, nm + "b", {fsrc(B["d2"], 0)},
                          {D(phase_view(fview(B["rF"], 0, 1), dy, dx), range(0, 64), T, DEMFI_MODE_STORE, phase_view(fview(aF, 0, 1), dy, dx))},
                          H2, W2, 1, 1, &wb, &bb, &l64);
+                    if (f_pair) {
+                        wf2.insert(wf2.end(), wf.begin(), wf.end());
+                        bf2.insert(bf2.end(), bf.begin(), bf.end());
+                        continue;
+                    }
                     // the 5 planes also go, as fp16, into the record Mixer.conv_delta1 stages (delta16): no plane-packing launch
                     pack_next(phase_view(fview(B["delta16"]), dy, dx), 0, 4);
                     conv(th, nm + "f", {fsrc(B["d2"], 0)},
@@ -1276,6 +1285,18 @@ struct Builder {
                           D(phase_view(delta_v(0, 4), dy, dx), {4}, DEMFI_ACT_NONE, DEMFI_MODE_STORE, phase_view(tview(ffo, 4), dy, dx))},
                          H2, W2, 1, 1, &wf, &bf, &l5);
                 }
+                if (f_pair && status >= 0) {
+                    // couts 0..4: column parity 0, 5..9: column parity 1; the packed copy of parity 1 lies one pixel (16 channels) further in delta16
+                    const Layer l10 = {10, l3.cin, 3, 3};
+                    pack_next(phase_view(fview(B["delta16"]), dy, 0), 0, 4, 16, 20);
+                    conv(th, p + "dec3#p" + std::to_string(dy) + "xf", {fsrc(B["d2"], 0)},
+                         {D(phase_view(delta_v(0, 0), dy, 0), range(0, 4), DEMFI_ACT_NONE, DEMFI_MODE_STORE, phase_view(tview(B["ft"]), dy, 0)),
+                          D(phase_view(delta_v(0, 4), dy, 0), {4}, DEMFI_ACT_NONE, DEMFI_MODE_STORE, phase_view(tview(ffo, 4), dy, 0)),
+                          D(phase_view(delta_v(0, 0), dy, 1), range(5, 9), DEMFI_ACT_NONE, DEMFI_MODE_STORE, phase_view(tview(B["ft"]), dy, 1)),
+                          D(phase_view(delta_v(0, 4), dy, 1), {9}, DEMFI_ACT_NONE, DEMFI_MODE_STORE, phase_view(tview(ffo, 4), dy, 1))},
+                         H2, W2, 1, 1, &wf2, &bf2, &l10);
+                }
+            }
         } else
         conv(th, p + "dec3", {fsrc(B["d2"], 0, 0, -1, -1, 1)},
              {D(fview(B["rF"], 0, 0), range(5, 69), T, DEMFI_MODE_STORE, fview(aF, 0, 0)),
