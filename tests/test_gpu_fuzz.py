@@ -68,6 +68,18 @@ def test_fuzz_sep_gru(k, H, W, batch):
     K.test_sep_gru_persistent_kernel(k[0], k[1], H, W, batch)
 
 
+import random as _random                                          # its own stream: the lists above keep their round-5 shapes
+_rng6 = _random.Random(606)
+GRU6 = [((1, 5) if i & 1 else (5, 1), _rng6.randint(1, 20) * 8, _rng6.randint(1, 30) * 8, _rng6.randint(1, 3)) for i in range(12)]
+
+
+@pytest.mark.parametrize('k,H,W,batch', GRU6)
+def test_fuzz_gru_half_step_r_then_zq(k, H, W, batch):
+    """Round 6 (gru.hip): seeded shapes -- strips shorter than a tile, ragged tiles along and across the filter axis, tiles whose halo
+    lines are carried inside LDS and strips that restart, batch > 1."""
+    K.test_gru_half_step_r_then_zq(k[0], k[1], H, W, batch)
+
+
 WS = [(H, W, _rng.randint(1, 2), _rng.choice([L.ACT_TANH, L.ACT_NONE, L.ACT_RELU])) for H, W in _shapes(5, 16, 70, 32, 140)]
 
 
