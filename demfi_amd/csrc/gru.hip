@@ -383,6 +383,11 @@ __global__ __launch_bounds__(G_NTHREADS, 1) void gru_sep5_kernel(const GArgs a)
             // LAST: the ring is re-primed after the epilogue instead (16 registers the epilogue needs)
             if constexpr (t + G_DEPTH < G_NSTEP) A[t % G_DEPTH] = a_load(wcur, std::integral_constant<int, t + G_DEPTH>{});
             else if constexpr (!decltype(LAST)::value) A[t % G_DEPTH] = a_load(wnxt, std::integral_constant<int, t + G_DEPTH - G_NSTEP>{});
+#ifdef DEMFI_GRU_AX
+            // experiment: twice the A-fragment traffic (the other cout half's fragment, unused)
+            const char* wx = wcur + ((cs ^ 1) - cs) * 1024;
+            uint4 axd = a_load(wx, std::integral_constant<int, t>{});
+#endif
             if constexpr (tap < 4 || ks == 3) {
                 g_for<0, 8>([&](auto P) {
                     constexpr int p = decltype(P)::value;
@@ -415,6 +420,9 @@ __global__ __launch_bounds__(G_NTHREADS, 1) void gru_sep5_kernel(const GArgs a)
                     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 }
             }
+#ifdef DEMFI_GRU_AX
+            asm volatile("" ::"v"(__builtin_bit_cast(u4_t, axd)));
+#endif
             __builtin_amdgcn_sched_barrier(0);
         });
     };
