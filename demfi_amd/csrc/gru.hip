@@ -23,6 +23,7 @@
 // and stage h' as fp16 in the same place; the helper waves store it as whole 128-byte lines (streaming) and issue the DMA.
 // R: tile = 32 pixels x 16 lines, wave = cout half x line half, pieces x | h of 20 lines (160 KiB), sigmoid * h from the h window.
 #include "common.h"
+#include <cstdlib>
 #include <type_traits>
 #include <vector>
 
@@ -31,17 +32,24 @@ namespace {
 constexpr int G_LS = 32 * 128;                                   // bytes per window line (32 records of 64 channels)
 constexpr int G_NH = 4;                                          // helper waves
 constexpr int G_NTHREADS = 256 + 64 * G_NH;
+#ifndef DEMFI_ZQS_PRIME_EARLY
+#define DEMFI_ZQS_PRIME_EARLY 0
+#endif
 #ifndef DEMFI_GRU_DEPTH
 #define DEMFI_GRU_DEPTH 4                                        // A prefetch distance in steps of 8 MFMAs
 #endif
 constexpr int G_DEPTH = DEMFI_GRU_DEPTH;
 constexpr int G_NSTEP = 20;                                      // (k-step, tap) steps per 64-channel piece
 static_assert(G_NSTEP % G_DEPTH == 0, "static ring indices");
-enum { GM_ZQ = 0, GM_R = 1 };
+enum { GM_ZQ = 0, GM_R = 1, GM_ZQS = 2 };                        // ZQS: ZQ with both gates of a cout block in one wave (below)
 template <int MODE> struct GCfg;
-template <> struct GCfg<GM_ZQ> { static constexpr int TL = 8, WL = 12, NPIECE = 3, LDS = 3 * 12 * G_LS; };
-template <> struct GCfg<GM_R>  { static constexpr int TL = 16, WL = 20, NPIECE = 2, LDS = 2 * 20 * G_LS; };
-static_assert(GCfg<GM_R>::LDS <= 160 * 1024 && GCfg<GM_ZQ>::LDS <= 160 * 1024, "LDS budget");
+template <> struct GCfg<GM_ZQ>  { static constexpr int TL = 8, WL = 12, NPIECE = 3, LDS = 3 * 12 * G_LS; };
+template <> struct GCfg<GM_R>   { static constexpr int TL = 16, WL = 20, NPIECE = 2, LDS = 2 * 20 * G_LS; };
+template <> struct GCfg<GM_ZQS> { static constexpr int TL = 8, WL = 12, NPIECE = 3, LDS = 3 * 12 * G_LS + 512; };   // + 128 bias floats
+static_assert(GCfg<GM_R>::LDS <= 160 * 1024 && GCfg<GM_ZQS>::LDS <= 160 * 1024, "LDS budget");
+constexpr int ZS_D = 8;                                          // ZQS: A ring depth in fragments
+constexpr int ZS_NA = 80;                                        // ZQS: A fragments per tile and wave: 20 (z . h) + 20 (q . r*h) + 40 (z, q alternating . x)
+static_assert(ZS_NA % ZS_D == 0, "static ring indices");
 
 #ifdef DEMFI_TRACE
 constexpr int GT_WGS = 32, GT_WAVES = 8, GT_TILES = 24, GT_STAMPS = 10;
@@ -85,6 +93,24 @@ __device__ __forceinline__ float g_sub_hi(float c, unsigned a)
     float d = 0.0f;
 #if defined(__HIP_DEVICE_COMPILE__)
     asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(a), "v"(c));
+#endif
+    return d;
+}
+
+// c - b * (fp16 half of a packed pair): (b - 1) - (b + 1) h
+__device__ __forceinline__ float g_nfma_lo(float b, unsigned h, float c)
+{
+    float d = 0.0f;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("v_fma_mix_f32 %0, -%1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h), "v"(b), "v"(c));
+#endif
+    return d;
+}
+__device__ __forceinline__ float g_nfma_hi(float b, unsigned h, float c)
+{
+    float d = 0.0f;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("v_fma_mix_f32 %0, -%1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h), "v"(b), "v"(c));
 #endif
     return d;
 }
@@ -173,6 +199,10 @@ __global__ __launch_bounds__(G_NTHREADS, 1) void gru_sep5_kernel(const GArgs a)
     char* const S1 = smem + PIECE;
     char* const S2 = smem + 2 * PIECE;                           // ZQ only
 
+    if constexpr (MODE == GM_ZQS) {
+        if (tid < 128) ((float*)(smem + 3 * PIECE))[tid] = tid < 64 ? a.b0[tid] : a.b1[tid - 64];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // written before this wave's first (raw) barrier
+    }
     if (wave >= 4) {
         // ================= helper waves: window DMA (+ ZQ: the global stores of the staged outputs) ======================
         const int dw = wave - 4;
@@ -228,7 +258,7 @@ __global__ __launch_bounds__(G_NTHREADS, 1) void gru_sep5_kernel(const GArgs a)
         int img, P0, L0;
         pos_of(it, img, P0, L0);
         [[maybe_unused]] int trk = 0;
-        if constexpr (MODE == GM_ZQ) {
+        if constexpr (MODE != GM_R) {
             // staged outputs (in piece 2): line r = bytes [4096 r, +4096), helper dw owns its chunk dw = pixels 8 dw .. 8 dw + 7
             const unsigned dlane = (unsigned)(px * a.d_sp) + slot16;
             issue_piece(a.h, S0, img, P0, L0, false);
@@ -280,7 +310,7 @@ __global__ __launch_bounds__(G_NTHREADS, 1) void gru_sep5_kernel(const GArgs a)
                 // ... r*h (8) under the sigmoid / tanh pass.  Both there (16) delay barrier D by ~1 400 cycles: measured, profiles/r06_notes.md
                 if (more) issue_piece(a.rh, S1, nimg, nP0, nL0, carry);
                 G_STAMP(wave, trk, 3);
-                asm volatile("s_barrier" ::: "memory");         // D: q~ is in LDS
+                if constexpr (MODE == GM_ZQ) asm volatile("s_barrier" ::: "memory");         // D: q~ is in LDS  (ZQS: wave-local epilogue, no D)
                 bool exact = false;
                 if (have_prev) exact = do_stores(pimg, pP0, pL0);                          // the previous tile's outputs (8 stores) under the blend
                 if (exact) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TL) : "memory");      // the next tile's h, r*h (older than the stores) have landed:
@@ -336,6 +366,209 @@ __global__ __launch_bounds__(G_NTHREADS, 1) void gru_sep5_kernel(const GArgs a)
         return;
     }
 
+    // ================= MFMA waves, ZQS ===========================================================================
+    // Both gates of a cout block in one wave: wave = cout half cs x line half lh, four z and four q accumulators (4 lines x 32 couts each).
+    // What that buys over ZQ (where two waves own z and two own q, 8 lines each): the epilogue is wave-local -- no q~ exchange through LDS and
+    // no barrier D; z and q~ of an output meet in one lane, so h' = h + ((b - 1) - h (b + 1)) / ((b + 1)(1 + a)) with a = e^-z', b = e^2q' takes
+    // THREE transcendentals per output instead of four (the pass sits on the quarter-rate transcendental unit); and the blend runs on all four
+    // SIMDs instead of the z waves' two.  What it costs: one A fragment per four MFMAs instead of eight in the h and r*h phases (the x phase feeds
+    // both gates from the same B fragments: LDS reads per tile unchanged) -- measured beforehand with dummy loads in a second ring: + 4 %.
+    if constexpr (MODE == GM_ZQS) {
+        const int hi = lane >> 5, lx = lane & 31;
+        const int cs = wave & 1, lh = wave >> 1;
+        const unsigned lane16 = lane * 16;
+        const char* const wz0 = a.w0[0] + cs * 1024;             // z . h
+        const char* const wq0 = a.w1[0] + cs * 1024;             // q . r*h
+        const char* const wz1 = a.w0[1] + cs * 1024;             // z . x
+        const char* const wq1 = a.w1[1] + cs * 1024;             // q . x
+        const int boff0 = lx * 128 + ((hi ^ ((lx >> 1) & 7)) << 4);
+        auto boff = [&](auto KS) {
+            int b = boff0;
+            asm volatile("" : "+v"(b));
+            return b ^ (decltype(KS)::value << 5);
+        };
+        int soff[2];
+#pragma unroll
+        for (int m2 = 0; m2 < 2; ++m2) soff[m2] = lx * 128 + (((cs * 4 + m2 * 2 + hi) ^ ((lx >> 1) & 7)) << 4);
+        auto a_loadn = [&](auto N_) {                            // fragment nn of the tile's A stream
+            constexpr int nn = decltype(N_)::value;
+            constexpr int sel = nn < 20 ? 0 : nn < 40 ? 1 : 2 + ((nn - 40) & 1);
+            constexpr int t = nn < 20 ? nn : nn < 40 ? nn - 20 : (nn - 40) >> 1;
+            constexpr int ks = t / 5, tap = t % 5;
+            const char* wb = sel == 0 ? wz0 : sel == 1 ? wq0 : sel == 2 ? wz1 : wq1;
+            asm volatile("" : "+s"(wb));
+            unsigned l16 = lane16;
+            asm volatile("" : "+v"(l16));
+            return __builtin_bit_cast(uint4, *gcp<u4_t>(wb + (unsigned)(((tap * 4 + ks) * 2) * 1024 + l16)));
+        };
+        uint4 A[ZS_D];
+        uint4 B[8];
+        f16x_t accz[4], accq[4];
+        auto prime = [&]() { g_for<0, ZS_D>([&](auto T) { A[decltype(T)::value] = a_loadn(T); }); };
+        auto b_init = [&](const char* tb) {
+            const int o = boff(std::integral_constant<int, 0>{});
+            g_for<0, 4>([&](auto R) { B[decltype(R)::value] = *(const uint4*)(tb + decltype(R)::value * G_LS + o); });
+        };
+        // one 64-channel window: 4 k-steps x 5 taps; WHICH = 0: z (4 MFMAs per step), 1: q, 2: both (8 MFMAs, two A fragments).  This wave's
+        // B window = lines tb + 0 .. 7: step (ks, tap) multiplies output line p with line tap + p; line 4 + tap arrives during tap; during tap 4
+        // the next k-step's lines 0 .. 3 (B[0 .. 3] are dead by then) -- or, at the end of the h window, the first lines of the r*h window
+        auto phase = [&](const char* tb, const char* tbn, auto NB_, auto WHICH_, auto HASNEXT_) {
+            constexpr int NB = decltype(NB_)::value, WHICH = decltype(WHICH_)::value;
+            constexpr bool DUAL = WHICH == 2, HASNEXT = decltype(HASNEXT_)::value;
+            constexpr int PER = DUAL ? 2 : 1;
+            g_for<0, G_NSTEP>([&](auto T_) {
+                constexpr int t = decltype(T_)::value;
+                constexpr int ks = t / 5, tap = t % 5;
+                constexpr int n0 = NB + t * PER, n1 = n0 + PER - 1;
+                const uint4 av0 = A[n0 % ZS_D];
+                const uint4 av1 = A[n1 % ZS_D];
+                if constexpr (tap < 4) B[4 + tap] = *(const uint4*)(tb + (4 + tap) * G_LS + boff(std::integral_constant<int, ks>{}));
+                constexpr bool LA0 = n0 + ZS_D < ZS_NA, LA1 = DUAL && n1 + ZS_D < ZS_NA;
+                if constexpr (LA0) A[n0 % ZS_D] = a_loadn(std::integral_constant<int, LA0 ? n0 + ZS_D : 0>{});
+                if constexpr (LA1) A[n1 % ZS_D] = a_loadn(std::integral_constant<int, LA1 ? n1 + ZS_D : 0>{});
+                constexpr bool NXT = tap == 4 && (ks < 3 || HASNEXT);
+                const f16x_t zero = {};
+                g_for<0, 4>([&](auto P) {
+                    constexpr int p = decltype(P)::value;
+                    if constexpr (WHICH != 1) {
+                        if constexpr (t == 0 && NB != 40) g_mma_c(accz[p], av0, B[tap + p], zero);
+                        else g_mma(accz[p], av0, B[tap + p]);
+                    }
+                    if constexpr (WHICH != 0) {
+                        if constexpr (t == 0 && NB != 40) g_mma_c(accq[p], av1, B[tap + p], zero);
+                        else g_mma(accq[p], av1, B[tap + p]);
+                    }
+                    if constexpr (NXT) B[p] = *(const uint4*)((ks < 3 ? tb : tbn) + p * G_LS + boff(std::integral_constant<int, (ks + 1) & 3>{}));
+                });
+                // issue order: MFMA, LDS read, MFMA, weight load, ...: the loads of a step go out behind its first MFMAs
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if constexpr (tap < 4 || NXT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if constexpr (LA0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                if constexpr (NXT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if constexpr (LA1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                if constexpr (NXT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if constexpr (NXT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                if constexpr (DUAL) __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        };
+        constexpr float KS_SIG = -1.4426950408889634f, KS_TANH = 2.8853900817779268f;
+        typedef float f2_t __attribute__((ext_vector_type(2)));
+        const char* const tbH = S0 + lh * 4 * G_LS;
+        const char* const tbR = S1 + lh * 4 * G_LS;
+        const char* const tbX = S2 + lh * 4 * G_LS;
+        const float* const SB = (const float*)(smem + 3 * PIECE);
+        int it = it0;
+        [[maybe_unused]] int trk = 0;
+        prime();
+        G_STAMP(wave, trk, 0);
+        asm volatile("s_barrier" ::: "memory");                 // A0: the first tile's h, r*h have landed; the bias is in LDS
+        for (;;) {
+            int img, P0, L0;
+            pos_of(it, img, P0, L0);
+            G_STAMP(wave, trk, 1);
+            b_init(tbH);
+            __builtin_amdgcn_sched_barrier(0);
+            phase(tbH, tbR, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::true_type{});
+            phase(tbR, tbR, std::integral_constant<int, 20>{}, std::integral_constant<int, 1>{}, std::false_type{});
+            G_STAMP(wave, trk, 2);
+            asm volatile("s_barrier" ::: "memory");             // B: x has landed; h, r*h are free
+            G_STAMP(wave, trk, 3);
+            b_init(tbX);
+            __builtin_amdgcn_sched_barrier(0);
+            phase(tbX, tbX, std::integral_constant<int, 40>{}, std::integral_constant<int, 2>{}, std::false_type{});
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("" ::"v"(accz[0]), "v"(accz[1]), "v"(accz[2]), "v"(accz[3]), "v"(accq[0]), "v"(accq[1]), "v"(accq[2]), "v"(accq[3]));
+#endif
+            G_STAMP(wave, trk, 4);
+            asm volatile("s_barrier" ::: "memory");             // C: the x piece is free (the staged h' goes there)
+            G_STAMP(wave, trk, 5);
+            // h of this wave's outputs: clamped addresses, unconditional loads, all eight in flight under the first pass of transcendentals
+            const char* hb = a.h.ptr + (int64_t)img * a.h.sb + (int64_t)min(P0 + lx, a.Plen - 1) * a.h.sp + (cs * 32 + hi * 8) * 2;
+            u4_t hreg[4][2];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const char* hp = hb + (int64_t)min(L0 + lh * 4 + p, a.Llen - 1) * a.h.sl;
+                hreg[p][0] = *gcp<u4_t>(hp);
+                hreg[p][1] = *gcp<u4_t>(hp + 32);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                // bias (packed cout order == MFMA row order) folded into the exponent's packed fma
+                f2_t bz[8], bq[8];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f4_t vz = *(const f4_t*)(SB + cs * 32 + g * 8 + hi * 4);
+                    const f4_t vq = *(const f4_t*)(SB + 64 + cs * 32 + g * 8 + hi * 4);
+                    bz[2 * g] = f2_t{vz[0], vz[1]} * KS_SIG;  bz[2 * g + 1] = f2_t{vz[2], vz[3]} * KS_SIG;
+                    bq[2 * g] = f2_t{vq[0], vq[1]} * KS_TANH; bq[2 * g + 1] = f2_t{vq[2], vq[3]} * KS_TANH;
+                }
+                // pass 1 (no h needed): a = e^-z', b = e^2q' (exponent clamped: b stays finite), den = (b + 1)(1 + a); r = 1 / den -> accz, b -> accq
+                g_for<0, 4>([&](auto P) {
+                    constexpr int p = decltype(P)::value;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        f2_t ez = f2_t{accz[p][2 * i], accz[p][2 * i + 1]} * KS_SIG + bz[i];
+                        f2_t eq = f2_t{accq[p][2 * i], accq[p][2 * i + 1]} * KS_TANH + bq[i];
+                        eq = f2_t{__builtin_fminf(eq.x, 60.0f), __builtin_fminf(eq.y, 60.0f)};
+                        const f2_t av = f2_t{__builtin_amdgcn_exp2f(ez.x), __builtin_amdgcn_exp2f(ez.y)} + 1.0f;
+                        const f2_t bv = f2_t{__builtin_amdgcn_exp2f(eq.x), __builtin_amdgcn_exp2f(eq.y)};
+                        const f2_t den = (bv + 1.0f) * av;
+                        accz[p][2 * i] = __builtin_amdgcn_rcpf(den.x);
+                        accz[p][2 * i + 1] = __builtin_amdgcn_rcpf(den.y);
+                        accq[p][2 * i] = bv.x;
+                        accq[p][2 * i + 1] = bv.y;
+                    }
+                });
+#if defined(__HIP_DEVICE_COMPILE__)
+                asm volatile("" ::"v"(accz[0]), "v"(accz[1]), "v"(accz[2]), "v"(accz[3]), "v"(accq[0]), "v"(accq[1]), "v"(accq[2]), "v"(accq[3]));
+#endif
+                __builtin_amdgcn_sched_barrier(0);               // ALL of pass 1 first (interleaved with pass 2, the first h load's latency was exposed)
+                G_STAMP(wave, trk, 6);
+#if DEMFI_ZQS_PRIME_EARLY
+                prime();                                         // the next tile's first A fragments: in flight under pass 2
+                __builtin_amdgcn_sched_barrier(0);
+#endif
+                // pass 2: h' = h + ((b - 1) - h (b + 1)) r, fp16, staged in the x piece (line lh 4 + p) for the helpers' whole-line stores
+                g_for<0, 4>([&](auto P) {
+                    constexpr int p = decltype(P)::value;
+#pragma unroll
+                    for (int m2 = 0; m2 < 2; ++m2) {
+                        const u4_t rr = hreg[p][m2];
+                        u4_t o = {0u, 0u, 0u, 0u};
+#pragma unroll
+                        for (int d = 0; d < 4; ++d) {            // dword d = channels 2 d, 2 d + 1 of the lane's 8 = accumulator elements 8 m2 + 2 d, + 1
+                            const int i0 = 8 * m2 + 2 * d;
+                            const f2_t bv = f2_t{accq[p][i0], accq[p][i0 + 1]};
+                            const f2_t bp = bv + 1.0f, bm = bv - 1.0f;
+                            const float nlo = g_nfma_lo(bp.x, rr[d], bm.x);      // (b - 1) - h (b + 1)
+                            const float nhi = g_nfma_hi(bp.y, rr[d], bm.y);
+                            unsigned pk = 0u;
+                            g_fma16_lo(pk, nlo, accz[p][i0], rr[d]);
+                            g_fma16_hi(pk, nhi, accz[p][i0 + 1], rr[d]);
+                            o[d] = pk;
+                        }
+                        *(u4_t*)(S2 + (lh * 4 + p) * G_LS + soff[m2]) = o;
+                    }
+                });
+            }
+            G_STAMP(wave, trk, 7);
+#if !DEMFI_ZQS_PRIME_EARLY
+            prime();
+#endif
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            G_STAMP(wave, trk, 8);
+            asm volatile("s_barrier" ::: "memory");             // E: h' is staged; the next tile's h, r*h have landed
+            ++trk;
+            ++it;
+            if (it >= it1) break;
+        }
+        return;
+    }
+
     // ================= MFMA waves ================================================================================
     const int hi = lane >> 5, lx = lane & 31;
     const int cs = wave & 1, role = wave >> 1;                   // cout half; ZQ: 0 = z, 1 = q;  R: line half
@@ -383,11 +616,6 @@ __global__ __launch_bounds__(G_NTHREADS, 1) void gru_sep5_kernel(const GArgs a)
             // LAST: the ring is re-primed after the epilogue instead (16 registers the epilogue needs)
             if constexpr (t + G_DEPTH < G_NSTEP) A[t % G_DEPTH] = a_load(wcur, std::integral_constant<int, t + G_DEPTH>{});
             else if constexpr (!decltype(LAST)::value) A[t % G_DEPTH] = a_load(wnxt, std::integral_constant<int, t + G_DEPTH - G_NSTEP>{});
-#ifdef DEMFI_GRU_AX
-            // experiment: twice the A-fragment traffic (the other cout half's fragment, unused)
-            const char* wx = wcur + ((cs ^ 1) - cs) * 1024;
-            uint4 axd = a_load(wx, std::integral_constant<int, t>{});
-#endif
             if constexpr (tap < 4 || ks == 3) {
                 g_for<0, 8>([&](auto P) {
                     constexpr int p = decltype(P)::value;
@@ -420,9 +648,6 @@ __global__ __launch_bounds__(G_NTHREADS, 1) void gru_sep5_kernel(const GArgs a)
                     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 }
             }
-#ifdef DEMFI_GRU_AX
-            asm volatile("" ::"v"(__builtin_bit_cast(u4_t, axd)));
-#endif
             __builtin_amdgcn_sched_barrier(0);
         });
     };
@@ -758,7 +983,9 @@ extern "C" int demfi_gru_zq(const demfi_conv* hz, const demfi_conv* hq, void* st
     a.w0[0] = g_wchunk(hz, 0); a.w0[1] = g_wchunk(hz, 1);
     a.w1[0] = g_wchunk(hq, 0); a.w1[1] = g_wchunk(hq, 1);
     a.b0 = hz->bias; a.b1 = hq->bias;
-    return g_launch<GM_ZQ>(a, hq, hq->segs[hq->sub_seg[0]], stream);
+    // DEMFI_GRU_ZQS=0: the round-6a form (z waves and q waves, q~ through LDS)
+    static const bool zqs = [] { const char* e = getenv("DEMFI_GRU_ZQS"); return !(e && e[0] == '0'); }();
+    return zqs ? g_launch<GM_ZQS>(a, hq, hq->segs[hq->sub_seg[0]], stream) : g_launch<GM_ZQ>(a, hq, hq->segs[hq->sub_seg[0]], stream);
 }
 
 #ifdef DEMFI_TRACE
