@@ -152,3 +152,17 @@ RDB = [(_rng5.randint(8, 200), _rng5.randint(8, 330), q) for q in (0, 1, 2, 3, 1
 def test_fuzz_rdb_growth_conv(H, W, q):
     """32 x 32-pixel tiles of the 3x3 streamed-weight instantiation at pseudo-random frame sizes, 3 .. 6 units of 32 channels"""
     K.test_rdb_growth_conv_streamed_weights(H, W, q)
+
+
+def test_gru_first_form_of_the_zq_launch_in_its_own_process():
+    """DEMFI_GRU_ZQS=0 selects the first round-6 form of the ZQ launch (z waves and q waves, q~ through LDS) -- the A/B arm of
+    profiles/r06_notes.md.  The switch is read once per process, so the kernel tests run again in a child with it set."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DEMFI_GRU_ZQS='0')
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(root, 'tests', 'test_gpu_kernels.py'), '-m', 'gpu', '-x', '-q', '-k', 'gru_half_step'],
+                       env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert '14 passed' in r.stdout, r.stdout[-500:]
