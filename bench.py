@@ -500,7 +500,7 @@ def main():
             g_ms = sum(p[3] for p in gr)
             g_fl = 2.0 * sum(p[4] for p in gr)
             g_by = sum(p[6] for p in gr)
-            out['gru'] = {'kernel': 'gru_sep5_kernel<R> + gru_sep5_kernel<ZQ> (gru.hip, round 6: z stays on chip)' if any(p[1] == 'gru_zq' for p in gr)
+            out['gru'] = {'kernel': 'gru_sep5_kernel<R> + gru_sep5_kernel<ZQS> (gru.hip, round 6: z stays on chip; both gates of a cout block in one wave)' if any(p[1] == 'gru_zq' for p in gr)
                                     else 'conv_sep5_c128_persist_kernel: z|r launch + q launch (round 5)',
                           'launches_per_window': len(gr), 'ms_per_window': round(g_ms, 3), 'TFLOPs': round(g_fl / g_ms / 1e9, 1),
                           'frac_mfma': round(g_fl / g_ms / 1e9 / peak, 4), 'algorithmic_bytes_per_px_per_half_step': round(g_by / (px * nb * 2 * a.n_tst), 1),

@@ -82,7 +82,7 @@ def main():
                                  'time_instants_per_launch': 7}
     gk = [k for k in allk if 'gru_sep5' in k]
     for k in gk:
-        out.setdefault('gru', {})['zq' if '<0>' in k else 'r'] = allk[k]
+        out.setdefault('gru', {})['r' if '<1>' in k else 'zq'] = allk[k]
     sk = [k for k in allk if 'conv_sep5' in k]
     if sk:
         out.setdefault('gru', {})['round5_kernel'] = allk[sk[0]]
