@@ -13,6 +13,7 @@ SRCS_CPP="abi.cpp"
 [ -f resblock.hip ] && SRCS_HIP="$SRCS_HIP resblock.hip"
 [ -f gru.hip ] && SRCS_HIP="$SRCS_HIP gru.hip"
 [ -f viz.hip ] && SRCS_HIP="$SRCS_HIP viz.hip"
+[ -f wsconv.hip ] && SRCS_HIP="$SRCS_HIP wsconv.hip"
 [ -f ctx.cpp ] && SRCS_CPP="$SRCS_CPP ctx.cpp"
 [ -f png_codec.cpp ] && SRCS_CPP="$SRCS_CPP png_codec.cpp"
 # stale objects must never be linked: a failed compile has to fail the build
@@ -24,7 +25,7 @@ objs=()
 CONV_FLAGS="-fno-slp-vectorize"
 for s in $SRCS_HIP; do
   o="${s%.hip}.o"; objs+=("$o")
-  xf=""; { [ "$s" = conv.hip ] || [ "$s" = resblock.hip ] || [ "$s" = gru.hip ]; } && xf="$CONV_FLAGS"
+  xf=""; { [ "$s" = conv.hip ] || [ "$s" = resblock.hip ] || [ "$s" = gru.hip ] || [ "$s" = wsconv.hip ]; } && xf="$CONV_FLAGS"
   $HIPCC $FLAGS $xf -c "$s" -o "$o" & pids+=($!)
 done
 for s in $SRCS_CPP; do

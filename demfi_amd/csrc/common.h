@@ -16,6 +16,8 @@ int demfi_set_error(int code, const char* fmt, ...);
 
 struct demfi_conv;
 bool demfi_persist_eligible(const demfi_conv* h);   // conv.hip: the descriptor belongs to the persistent 64-channel 3x3 kernel
+bool demfi_ws2_eligible(const demfi_conv* h);       // wsconv.hip: 3x3 s1 / 4x4 s2 over 32-channel units, 64-cout blocks (streamed weights, helper-wave DMA)
+int demfi_ws2_launch(const demfi_conv* h, const demfi_conv* dev, void* stream);
 #define DEMFI_HIP_CHECK(expr)                                                                   \
     do {                                                                                        \
         hipError_t e__ = (expr);                                                                \

@@ -2998,7 +2998,8 @@ int dispatch(const demfi_conv* h, const demfi_conv* dev, hipStream_t st, size_t 
 // 3x3 kernel, the narrow kernel with an NHWC destination, the SepConvGRU kernel.  Their layers are packed with cout_perm.
 bool demfi_persist_eligible(const demfi_conv* h)
 {
-    return sep_eligible(h) || wstream_eligible(h) || (wstream3_on() && wstream_eligible(h, 3, 1)) || persist_eligible(h) || (narrow_eligible(h) && persist_out_eligible(h));
+    return sep_eligible(h) || wstream_eligible(h) || (wstream3_on() && wstream_eligible(h, 3, 1)) || persist_eligible(h) || (narrow_eligible(h) && persist_out_eligible(h)) ||
+           demfi_ws2_eligible(h);
 }
 
 extern "C" int64_t demfi_conv_lds_bytes(const demfi_conv* h)
@@ -3094,6 +3095,7 @@ extern "C" int demfi_conv2d(const demfi_conv* h, const demfi_conv* dev, void* st
     }
     if (wstream_eligible(h)) return launch_wstream(h, dev, st);
     if (wstream3_on() && wstream_eligible(h, 3, 1)) return launch_wstream3(h, dev, st);
+    if (!persist_eligible(h) && !narrow_eligible(h) && demfi_ws2_eligible(h)) return demfi_ws2_launch(h, dev, st);      // wsconv.hip (round 6)
     if (persist_eligible(h)) {
 #ifdef DEMFI_ABLATION
         static const int var = getenv("DEMFI_PERSIST_VARIANT") ? atoi(getenv("DEMFI_PERSIST_VARIANT")) : 0;

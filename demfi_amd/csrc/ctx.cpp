@@ -47,8 +47,19 @@ int build_conv(int dtype, int H, int W, int stride, int batch, const float* w, c
     int n_oct = 0;
     for (int i = 0; i < n_dsts; ++i) n_oct += (dsts[i].n + 7) / 8;
     const int sub = (n_oct + 3) / 4;
-    const int nco = sub <= 5 ? sub : 4;
+    int nco = sub <= 5 ? sub : 4;
     int rec = 128;
+    // round 6: the stride-2 4x4 layers (UNet encoders, DeMFInet.py:575-577) whose inputs are NHWC pieces of 32-channel multiples (+ at
+    // most one 16-channel tail) and whose outputs are 64-channel blocks of one NHWC tensor belong to the phase-decomposed streamed-weight
+    // kernel (wsconv.hip): units of 32 channels (64-byte records, a 16-channel tail padded to a whole unit), two 32-cout subtiles per
+    // work item
+    static const bool ws2 = !(getenv("DEMFI_WS2") && atoi(getenv("DEMFI_WS2")) == 0);
+    bool ws2_shape = ws2 && esz == 2 && stride == 2 && kh == 4 && kw == 4 && pad_y < 0 && pad_x < 0 && n_dsts == 1 && dsts[0].n % 64 == 0 &&
+                     dsts[0].mode == DEMFI_MODE_STORE && (dsts[0].act == DEMFI_ACT_NONE || dsts[0].act == DEMFI_ACT_RELU) &&
+                     dsts[0].dst.sc == 1 && !dsts[0].dst.is_f32 && (!dsts[0].res.ptr || (dsts[0].res.sc == 1 && !dsts[0].res.is_f32));
+    for (int i = 0; ws2_shape && i < n_srcs; ++i)
+        ws2_shape = srcs[i].fat && !srcs[i].up_shift && !srcs[i].v.is_f32 && (srcs[i].nch % 32 == 0 || (srcs[i].nch == 16 && i == n_srcs - 1));
+    if (ws2_shape) nco = 2;
     // the SepConvGRU layers (1x5 / 5x1 over two 64-channel NHWC pieces) run on their own persistent kernel, which wants
     // the two pieces as two 64-channel chunks whatever the general kernel's LDS budget says
     bool sep = esz == 2 && stride == 1 && ((kh == 1 && kw == 5) || (kh == 5 && kw == 1)) && n_srcs == 2 && (cout == 64 || cout == 128);
@@ -70,7 +81,7 @@ int build_conv(int dtype, int H, int W, int stride, int batch, const float* w, c
         static const bool ws3 = !(getenv("DEMFI_WS3") && atoi(getenv("DEMFI_WS3")) == 0);
         bool rdb_shape = ws3 && !sep && esz == 2 && kh == 3 && kw == 3 && stride == 1 && sub == 1 && n_dsts == 1 && dsts[0].n == 32 && cin >= 96 && pad_y < 0 && pad_x < 0;
         for (int i = 0; rdb_shape && i < n_srcs; ++i) rdb_shape = srcs[i].fat && !srcs[i].up_shift && srcs[i].nch % 32 == 0;
-        if (rdb_shape) rec = 64;
+        if (rdb_shape || ws2_shape) rec = 64;
     }
 
     // ---- every original input channel must be fed exactly once ------------------------------------------------
@@ -95,7 +106,8 @@ int build_conv(int dtype, int H, int W, int stride, int batch, const float* w, c
     const demfi_view null_view = {nullptr, 0, 0, 0, 0, 0, 0};
     auto close_chunk = [&]() {
         if (fill == 0) return;
-        const int padb = (32 - fill % 32) % 32;
+        const int unit = ws2_shape ? 64 : 32;                     // wsconv.hip walks whole 32-channel units
+        const int padb = (unit - fill % unit) % unit;
         if (padb) {
             pieces.push_back({null_view, padb / esz, fill / esz, 0, 0});
             cin_map.insert(cin_map.end(), padb / esz, -1);

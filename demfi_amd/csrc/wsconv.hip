@@ -1,0 +1,412 @@
+// Streamed-weight convolution, second family (round 6): 64 output channels per work item over ANY number of 32-channel input units,
+//   * 3x3 stride 1 (+ optional NHWC residual)        -- layers whose K is not one 64-channel record;
+//   * 4x4 stride 2 as FOUR PHASES of 2x2 taps        -- the UNet encoders (Refine_Module.enc1/2/3, DeMFInet.py:575-577, 588-590).
+// What it replaces: the general kernel (conv_kernel) ran the stride-2 layers at 0.09-0.16 of the matrix peak -- one workgroup per
+// 8 x 32 tile, a VGPR-staged gather of a 18 x 66-pixel window per chunk and one barrier per tap (16 per chunk).
+//
+// Stride 2 by phases: output (y, x) = sum_{ky, kx < 4} W[ky][kx] . In(2y - 1 + ky, 2x - 1 + kx).  Input rows of parity py are touched by
+// the taps ky = 1 - py and 3 - py only, i.e. the phase image P_py,px(r, q) = In(2r + py, 2q + px) -- a view with doubled strides -- sees a
+// 2 x 2 stride-1 filter whose window starts at r = y - py.  A (32-channel chunk, phase) pair is one UNIT: its haloed tile
+// (17 lines x 33 records of 64 bytes) goes to LDS by DMA, its 2 x 2 x 2 k-steps are 8 steps of 8 MFMAs per wave.  No tap is multiplied
+// by zero (the embedded-3x3 form would do 2.25x the work) and nothing is gathered through registers.
+//
+// Structure (resblock.hip's roles): MFMA waves 0-3 = cout half x row half, eight 32x32 accumulators each (8 rows x 32 pixels x 32
+// couts); their only VMEM is the A fragment of a step -- one global_load_dwordx4 from the packed, L2-resident weights into a register
+// ring (saddr form) -- so the compiler's vmcnt bookkeeping is exact.  Helper waves 4-7 issue the unit DMA NBUF - 1 units ahead into a
+// ring of NBUF unit buffers (3x3: 3 x 40 KiB, 2x2: 4 x 36 KiB: a 2x2 unit is only 2 048 matrix-pipe cycles, less than the HBM latency)
+// and count their own vmcnt.  ONE s_barrier per unit: "unit u has landed" and "the buffer of unit u - 1 is free".
+// Inside a unit the steps are (kx, k-step, ky) with ky innermost and a rolling window of B lines (line l serves output row p at
+// ky = l - p): per step 8 MFMAs, one or two ds_read_b128, one A load.
+// Epilogue: the accumulators START at bias + residual (the residual of the NEXT item is fetched in front of this item's stores), so
+// the end of an item is activation, conversion and 16-byte stores of 8 consecutive channels per lane (cout_perm packing).
+#include "common.h"
+#include <type_traits>
+#include <stdlib.h>
+
+namespace {
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void ws_for(F&& f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        ws_for<I + 1, N>(f);
+    }
+}
+__device__ __forceinline__ void ws_mma(f16x_t& acc, const uint4& a, const uint4& b)
+{
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8_t, a), __builtin_bit_cast(h8_t, b), acc, 0, 0, 0);
+}
+
+template <bool S2> struct Ws2Cfg {
+    static constexpr int KSE = S2 ? 2 : 3;                       // taps per dimension a unit sees
+    static constexpr int TH = 16, TWP = 32, RPW = 8;             // output tile, rows per MFMA wave
+    static constexpr int LH = TH + KSE - 1, LL = TWP + KSE - 1;  // lines / records per line of a unit's tile
+    static constexpr int NHW = 4;                                // helper (DMA) waves
+    static constexpr int NI = (LH * LL + 15) / 16;               // DMA instructions per unit (16 records of 64 bytes each)
+    static constexpr int NIW = (NI + NHW - 1) / NHW;             // per helper wave: every helper issues exactly NIW (the surplus ones land in the buffer's pad)
+    static constexpr int BUF_BYTES = NIW * NHW * 1024;
+    static constexpr int NBUF = S2 ? 4 : 3;
+    static constexpr int LDS_BYTES = NBUF * BUF_BYTES;
+    static constexpr int NG = 2 * KSE;                           // (kx, k-step) groups per unit
+    static constexpr int NSTEP = NG * KSE;
+#ifndef DEMFI_WS2_DEPTH3
+#define DEMFI_WS2_DEPTH3 6
+#endif
+    static constexpr int DEPTH = S2 ? 4 : DEMFI_WS2_DEPTH3;      // A prefetch distance in steps
+    static constexpr int BL = KSE + RPW - 1;                     // lines of a wave's B window
+    static constexpr int NTHREADS = 256 + 64 * NHW;
+    static_assert(NSTEP % DEPTH == 0, "static ring indices");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+    static_assert((NBUF - 1) * NIW <= 63, "a helper's units in flight must be countable in vmcnt");
+};
+
+// everything a wave needs to know about one unit; all wave-uniform
+struct WsUnit {
+    const char* src;            // address of record (line 0, column 0) of the unit's tile (may lie outside the buffer: such records are never loaded)
+    const char* w;              // A fragments of this unit, cout half 0: + (step constant + cs) KiB + lane * 16
+    int iy0, ix0;               // input coordinates of record (0, 0)
+    int sx, sy;                 // byte strides between the tile's records / lines
+    int half;                   // 1: only the first 16 channels of the unit are real (the rest reads the zero page)
+    bool interior;
+};
+
+template <bool S2>
+__global__ __launch_bounds__(Ws2Cfg<S2>::NTHREADS, 1) void conv_ws2_kernel(const demfi_conv* __restrict__ d)
+{
+    using C = Ws2Cfg<S2>;
+    constexpr int KSE = C::KSE, RPW = C::RPW;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int H = d->H, W = d->W, inH = d->inH, inW = d->inW;
+    const int tiles_x = (W + C::TWP - 1) / C::TWP, tiles_y = (H + C::TH - 1) / C::TH, tiles_img = tiles_x * tiles_y;
+    const int nblk = d->cout_pad >> 6;                           // 64-cout blocks: the innermost index of an item (they share the input tile)
+    const int total = tiles_img * d->batch * nblk;
+    // contiguous run of items per workgroup, the workgroups of an XCD (blockIdx % 8) share a contiguous band
+    int it0, it1;
+    {
+        const int G = gridDim.x;
+        if ((G & 7) == 0 && total >= G) {
+            const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, nw = G >> 3;
+            const int q = total >> 3, r = total & 7;
+            const int lo = xcd * q + min(xcd, r), n = q + (xcd < r ? 1 : 0);
+            it0 = lo + (int)(((int64_t)n * idx) / nw);
+            it1 = lo + (int)(((int64_t)n * (idx + 1)) / nw);
+        } else {
+            it0 = (int)(((int64_t)total * blockIdx.x) / G);
+            it1 = (int)(((int64_t)total * (blockIdx.x + 1)) / G);
+        }
+    }
+    if (it0 >= it1) return;                                      // uniform per workgroup
+    const int upi = d->n_chunks * (S2 ? 4 : 1);                  // units per item
+    const int n_units = (it1 - it0) * upi;
+    const char* const zeros = (const char*)d->zero_page;
+
+    auto item_pos = [&](int it, int& blk, int& img, int& ty, int& tx) {
+        blk = it % nblk;
+        const int tl = it / nblk;
+        img = tl / tiles_img;
+        const int rem = tl - img * tiles_img;
+        ty = rem / tiles_x;
+        tx = rem - ty * tiles_x;
+    };
+    // walks the units of this workgroup in order; the divisions of item_pos happen once per item
+    struct Cursor { int it, ph, cu, blk, img, ty, tx; };
+    auto cursor_at = [&](int it) {
+        Cursor c;
+        c.it = it; c.ph = 0; c.cu = 0;
+        item_pos(it, c.blk, c.img, c.ty, c.tx);
+        return c;
+    };
+    auto advance = [&](Cursor& c) {
+        if (++c.cu < d->n_chunks) return;                        // chunk innermost: the two halves of a 128-byte line follow each other
+        c.cu = 0;
+        if (S2 && ++c.ph < 4) return;
+        c.ph = 0;
+        if (c.it + 1 < it1) { ++c.it; item_pos(c.it, c.blk, c.img, c.ty, c.tx); }      // past the last unit: stays on the last item (never used for data)
+    };
+    auto unit_info = [&](const Cursor& c) {
+        WsUnit r;
+        const int py = c.ph >> 1, px = c.ph & 1;
+        const demfi_chunk& ch = d->chunks[c.cu];
+        const demfi_piece& pc = d->pieces[ch.first_piece];
+        const int st = S2 ? 2 : 1;
+        r.sx = (int)(pc.v.sx * 2) * st;
+        r.sy = (int)(pc.v.sy * 2) * st;
+        r.iy0 = S2 ? 2 * c.ty * C::TH - py : c.ty * C::TH - 1;
+        r.ix0 = S2 ? 2 * c.tx * C::TWP - px : c.tx * C::TWP - 1;
+        r.src = (const char*)pc.v.ptr + (int64_t)c.img * pc.v.sb * 2 + (int64_t)r.iy0 * (pc.v.sy * 2) + (int64_t)r.ix0 * (pc.v.sx * 2);
+        r.half = pc.nch == 16;
+        // packed weights: [cout block][chunk][tap][k-step][cout half] KiB; S2: tap (ky, kx) = (2 ky2 + 1 - py, 2 kx2 + 1 - px)
+        r.w = (const char*)d->wpack + ((int64_t)c.blk * d->w_blk_stride + ch.w_off) * 16 + (S2 ? ((4 * (1 - py) + (1 - px)) * 4) * 1024 : 0);
+        const int ly = S2 ? 2 * (C::LH - 1) : C::LH - 1, lx_ = S2 ? 2 * (C::LL - 1) : C::LL - 1;
+        r.interior = r.iy0 >= 0 && r.iy0 + ly < inH && r.ix0 >= 0 && r.ix0 + lx_ < inW;
+        return r;
+    };
+
+    if (wave >= 4) {
+        // ================= helper waves: the unit DMA, NBUF - 1 units ahead ==============================================
+        const int dw = wave - 4;
+        __builtin_assume(dw >= 0 && dw < C::NHW);
+        // instruction i = dw + 4 j covers records 16 i .. 16 i + 15; lane -> (record 16 i + lane / 4, physical slot lane % 4), logical slot
+        // (8 channels) = physical ^ ((column >> 2) & 3)
+        int dl[C::NIW], dc[C::NIW], dslot[C::NIW];
+#pragma unroll
+        for (int j = 0; j < C::NIW; ++j) {
+            const int rec = min((dw + C::NHW * j) * 16 + (lane >> 2), C::LH * C::LL - 1);      // lanes past the tile re-read its last record
+            const int l = rec / C::LL, c = rec - l * C::LL;
+            dl[j] = l; dc[j] = c;
+            dslot[j] = (lane & 3) ^ ((c >> 2) & 3);
+        }
+        Cursor dcur = cursor_at(it0);
+        auto issue_unit = [&](int u) {
+            const WsUnit un = unit_info(dcur);
+            advance(dcur);
+            char* const buf = smem + (u % C::NBUF) * C::BUF_BYTES;
+#pragma unroll
+            for (int j = 0; j < C::NIW; ++j) {
+                const int i = dw + C::NHW * j;
+                const char* g = un.src + (dl[j] * un.sy + dc[j] * un.sx + (dslot[j] << 4));
+                bool ok = !((un.half != 0) & (dslot[j] >= 2));
+                if (!un.interior) {                              // wave-uniform
+                    const int iy = un.iy0 + dl[j] * (S2 ? 2 : 1), ix = un.ix0 + dc[j] * (S2 ? 2 : 1);
+                    ok = ok & ((unsigned)iy < (unsigned)inH) & ((unsigned)ix < (unsigned)inW);
+                }
+                if (!ok) g = zeros;
+                __builtin_amdgcn_global_load_lds((const DEMFI_GLOBAL void*)g, (__attribute__((address_space(3))) void*)(buf + i * 1024), 16, 0, 0);
+            }
+        };
+        const int pre = min(C::NBUF - 1, n_units);
+        for (int u = 0; u < pre; ++u) issue_unit(u);
+        for (int u = 0; u < n_units; ++u) {
+            // units u .. min(u + NBUF - 2, n_units - 1) are in flight; unit u must have landed
+            const int behind = min(C::NBUF - 2, n_units - 1 - u);
+            if (behind >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * C::NIW) : "memory");
+            else if (behind == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::NIW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_barrier" ::: "memory");             // unit u is in LDS; the MFMA waves are done with unit u - 1
+            if (u + C::NBUF - 1 < n_units) issue_unit(u + C::NBUF - 1);      // into the buffer of unit u - 1
+        }
+        return;
+    }
+
+    // ================= MFMA waves ====================================================================================
+    const int hi = lane >> 5, lx = lane & 31;
+    const int cs = wave & 1, rh = wave >> 1;                    // cout half, row half
+    const unsigned lane16 = lane * 16;
+    // B fragment of (group g = (kx, k-step), line l): record (lx + kx) of line rh * 8 + l, 16-byte slot (2 ksl + hi) swizzled by the column
+    int boff[C::NG];
+#pragma unroll
+    for (int g = 0; g < C::NG; ++g) {
+        const int col = lx + (g >> 1);
+        boff[g] = (rh * RPW * C::LL + col) * 64 + ((((g & 1) * 2 + hi) ^ ((col >> 2) & 3)) << 4);
+    }
+    auto a_load = [&](const WsUnit& un, auto T) {
+        constexpr int t = decltype(T)::value;
+        constexpr int g = t / KSE, ky = t - g * KSE, kx = g >> 1, ksl = g & 1;
+        constexpr int tap = S2 ? 8 * ky + 2 * kx : ky * 3 + kx;  // S2: + the phase's (4 (1 - py) + (1 - px)), folded into un.w
+        const char* wb = un.w + cs * 1024;
+        asm volatile("" : "+s"(wb));                             // opaque uniform base + one 32-bit lane offset: the saddr form, nothing hoisted
+        unsigned l16 = lane16;
+        asm volatile("" : "+v"(l16));
+        return __builtin_bit_cast(uint4, *gcp<u4_t>(wb + (unsigned)(((tap * 2 + ksl) * 2) * 1024 + l16)));
+    };
+
+    f16x_t acc[RPW];
+    uint4 A[C::DEPTH];
+    // accumulators of an item start at bias + residual
+    auto res_fetch = [&](const Cursor& io, u4_t (&rr)[RPW][2]) {
+        const demfi_seg& sg = d->segs[d->sub_seg[io.blk * 2]];
+        const half_t* const rp = (const half_t*)sg.res.ptr;
+        const u4_t z = {0u, 0u, 0u, 0u};
+        if (!rp) {                                               // wave-uniform
+#pragma unroll
+            for (int p = 0; p < RPW; ++p) { rr[p][0] = z; rr[p][1] = z; }
+            return;
+        }
+        const int ch0 = d->oct_ch[io.blk * 8];
+        const int ox = io.tx * C::TWP + lx;
+        // uniform base (image, first row, first channel) + ONE 32-bit lane offset: the saddr form, no per-load 64-bit address registers
+        const char* const rb = (const char*)(rp + io.img * sg.res.sb + (int64_t)(io.ty * C::TH + rh * RPW) * sg.res.sy + ch0 + cs * 32);
+        const unsigned loff = (unsigned)(ox * (int)sg.res.sx + hi * 8) * 2;
+        const int rsy = (int)sg.res.sy * 2;
+        const int oy0 = io.ty * C::TH + rh * RPW;
+#pragma unroll
+        for (int p = 0; p < RPW; ++p) {
+            // pixels outside the image read the zero page: every load is unconditional, all sixteen are in flight together
+            const bool ok = oy0 + p < H && ox < W;
+            const char* base = ok ? rb + p * rsy : zeros;       // (row: uniform)
+            const unsigned lo_ = ok ? loff : 0u;
+#pragma unroll
+            for (int m2 = 0; m2 < 2; ++m2) rr[p][m2] = *gcp<u4_t>(base + (lo_ + (ok ? m2 * 32 : 0)));
+        }
+    };
+    auto acc_init = [&](const Cursor& io, const u4_t (&rr)[RPW][2]) {
+        f4_t bq[4];                                              // bias in MFMA-row order: quads 0..3 of this lane
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) bq[qd] = *gcp<f4_t>(d->bias + io.blk * 64 + cs * 32 + qd * 8 + hi * 4);
+#pragma unroll
+        for (int p = 0; p < RPW; ++p) {
+#pragma unroll
+            for (int m2 = 0; m2 < 2; ++m2) {
+                const h8_t r8 = __builtin_bit_cast(h8_t, rr[p][m2]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[p][(2 * m2) * 4 + j] = bq[2 * m2][j] + (float)r8[j];
+                    acc[p][(2 * m2 + 1) * 4 + j] = bq[2 * m2 + 1][j] + (float)r8[4 + j];
+                }
+            }
+        }
+    };
+    auto item_store = [&](const Cursor& io) {
+        const demfi_seg& sg = d->segs[d->sub_seg[io.blk * 2]];
+        half_t* const dstp = (half_t*)sg.dst.ptr;
+        const float lo = sg.act == DEMFI_ACT_RELU ? 0.0f : -__builtin_inff();      // ReLU or nothing (eligibility), branch-free
+        const int ch0 = d->oct_ch[io.blk * 8];
+        const int ox = io.tx * C::TWP + lx;
+        const int oy0 = io.ty * C::TH + rh * RPW;
+        char* const ob = (char*)(dstp + io.img * sg.dst.sb + (int64_t)oy0 * sg.dst.sy + ch0 + cs * 32);      // uniform
+        const unsigned loff = (unsigned)(ox * (int)sg.dst.sx + hi * 8) * 2;
+        const int dsy = (int)sg.dst.sy * 2;
+#pragma unroll
+        for (int p = 0; p < RPW; ++p) {
+#pragma unroll
+            for (int m2 = 0; m2 < 2; ++m2) {
+                h8_t o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    o[j] = (half_t)fmaxf(acc[p][(2 * m2) * 4 + j], lo);
+                    o[4 + j] = (half_t)fmaxf(acc[p][(2 * m2 + 1) * 4 + j], lo);
+                }
+                if (oy0 + p < H && ox < W) *gp<h8_t>(ob + p * dsy + (loff + m2 * 32)) = o;
+            }
+        }
+    };
+
+    Cursor ccur = cursor_at(it0);                               // the unit on the matrix cores
+    Cursor io = ccur;                                            // its item (blk, img, ty, tx)
+    {
+        u4_t rr[RPW][2];
+        res_fetch(io, rr);
+        acc_init(io, rr);
+    }
+    WsUnit cur = unit_info(ccur);
+    ws_for<0, C::DEPTH>([&](auto T) { A[decltype(T)::value] = a_load(cur, T); });
+
+    for (int u = 0; u < n_units; ++u) {
+        const bool last_of_item = ccur.cu == d->n_chunks - 1 && (!S2 || ccur.ph == 3);
+        advance(ccur);                                           // past the end: stays on the last item, its A fragments are loaded and dropped
+        const WsUnit nxt = unit_info(ccur);
+        const char* const tb = smem + (u % C::NBUF) * C::BUF_BYTES;
+        asm volatile("s_barrier" ::: "memory");                 // unit u has landed
+        uint4 B[C::BL];
+        ws_for<0, RPW>([&](auto R) { B[decltype(R)::value] = *(const uint4*)(tb + boff[0] + decltype(R)::value * (C::LL * 64)); });
+        __builtin_amdgcn_sched_barrier(0);
+        ws_for<0, C::NSTEP>([&](auto T_) {
+            constexpr int t = decltype(T_)::value;
+            constexpr int g = t / KSE, ky = t % KSE;
+            const uint4 av = A[t % C::DEPTH];
+            // lines RPW .. BL - 1 of a group arrive during its steps 0 .. KSE - 2; the NEXT group's lines 0 .. RPW - 1 are read during its
+            // last step, each right behind the MFMA that uses line KSE - 1 + p for the last time
+            if constexpr (ky < KSE - 1) B[ky + RPW] = *(const uint4*)(tb + boff[g] + (ky + RPW) * (C::LL * 64));
+            if constexpr (t + C::DEPTH < C::NSTEP) A[t % C::DEPTH] = a_load(cur, std::integral_constant<int, t + C::DEPTH>{});
+            else                                   A[t % C::DEPTH] = a_load(nxt, std::integral_constant<int, t + C::DEPTH - C::NSTEP>{});
+            if constexpr (ky < KSE - 1 || g + 1 == C::NG) {
+                ws_for<0, RPW>([&](auto P) { ws_mma(acc[decltype(P)::value], av, B[ky + decltype(P)::value]); });
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if constexpr (ky < KSE - 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+            } else {
+                uint4 Bn[RPW];
+                ws_for<0, RPW>([&](auto P) {
+                    constexpr int p = decltype(P)::value;
+                    ws_mma(acc[p], av, B[KSE - 1 + p]);
+                    Bn[p] = *(const uint4*)(tb + boff[g + 1 < C::NG ? g + 1 : 0] + p * (C::LL * 64));
+                });
+                ws_for<0, RPW>([&](auto P) { B[decltype(P)::value] = Bn[decltype(P)::value]; });
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#pragma unroll
+                for (int q = 0; q < 6; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        if (last_of_item) {
+            // ---- end of an item: the next item's residual is requested in front of this item's stores
+            const bool more = u + 1 < n_units;                  // then ccur already stands on the next item's first unit
+            u4_t rr[RPW][2];
+            if (more) res_fetch(ccur, rr);
+            item_store(io);
+            if (more) acc_init(ccur, rr);
+            io = ccur;
+        }
+        cur = nxt;
+    }
+}
+
+static bool ws2_on()
+{
+    static const bool on = !(getenv("DEMFI_WS2") && atoi(getenv("DEMFI_WS2")) == 0);      // A/B: 0 = these layers stay on the kernels of rounds 1-5
+    return on;
+}
+
+}  // namespace
+
+// 3x3 stride 1 / 4x4 stride 2, fp16, units of 32 channels (64-byte records; a unit = one NHWC piece of 32 channels, or of 16 + zero
+// padding), 64-cout blocks each routed to 64 consecutive channels of one NHWC fp16 destination (optional NHWC fp16 residual)
+bool demfi_ws2_eligible(const demfi_conv* h)
+{
+    if (!ws2_on() || h->dtype != DEMFI_F16 || !h->zero_page || h->rec_bytes != 64 || h->nco != 2 || h->cout_pad % 64) return false;
+    const bool s2 = h->stride == 2;
+    if (s2) {
+        if (h->kh != 4 || h->kw != 4 || h->pad_y != 1 || h->pad_x != 1 || h->inH != 2 * h->H || h->inW != 2 * h->W) return false;
+    } else {
+        if (h->stride != 1 || h->kh != 3 || h->kw != 3 || h->pad_y != 1 || h->pad_x != 1 || h->inH != h->H || h->inW != h->W) return false;
+    }
+    if (h->n_chunks < 1) return false;
+    for (int c = 0; c < h->n_chunks; ++c) {
+        const demfi_chunk& ch = h->chunks[c];
+        if (ch.nks != 2 || ch.n_pieces < 1 || ch.n_pieces > 2) return false;
+        const demfi_piece& p = h->pieces[ch.first_piece];
+        if (!p.fat || p.up_shift || !p.v.ptr || p.v.sc != 1 || p.v.is_f32 || p.lds_ch != 0) return false;
+        if (ch.n_pieces == 1 ? p.nch != 32 : (p.nch != 16 || h->pieces[ch.first_piece + 1].v.ptr != nullptr || h->pieces[ch.first_piece + 1].nch != 16)) return false;
+        if (p.v.sy * 4 * 20 + p.v.sx * 4 * 40 >= (int64_t)1 << 31) return false;       // 32-bit per-lane offsets inside a tile
+    }
+    for (int b = 0; b < h->cout_pad / 64; ++b) {
+        const int sgi = h->sub_seg[2 * b];
+        if (sgi < 0 || h->sub_seg[2 * b + 1] != sgi) return false;
+        for (int o = 0; o < 8; ++o)
+            if (h->oct_seg[8 * b + o] != sgi || h->oct_n[8 * b + o] != 8 || h->oct_ch[8 * b + o] != h->oct_ch[8 * b] + 8 * o) return false;
+        const demfi_seg& sg = h->segs[sgi];
+        if (sg.mode != DEMFI_MODE_STORE || sg.scale != 1 || sg.dy || sg.dx || !sg.dst.ptr || sg.dst.is_f32 || sg.dst.sc != 1 || sg.aux.ptr) return false;
+        if (sg.res.ptr && (sg.res.is_f32 || sg.res.sc != 1)) return false;
+    }
+    if (h->u8_sink || h->pack.ptr) return false;
+    return true;
+}
+
+int demfi_ws2_launch(const demfi_conv* h, const demfi_conv* dev, void* stream)
+{
+    const int64_t total = (int64_t)((h->W + 31) / 32) * ((h->H + 15) / 16) * h->batch * (h->cout_pad / 64);
+    if (total <= 0 || total >= (int64_t)1 << 30) return demfi_set_error(DEMFI_ERR_ARG, "demfi_conv2d (streamed-weight 64-cout kernel): empty or oversized launch");
+    const int grid = total >= 256 ? 256 : (int)total;
+    if (h->stride == 2) {
+        DEMFI_LDS_ATTR(conv_ws2_kernel<true>);
+        hipLaunchKernelGGL(conv_ws2_kernel<true>, dim3(grid), dim3(Ws2Cfg<true>::NTHREADS), Ws2Cfg<true>::LDS_BYTES, (hipStream_t)stream, dev);
+    } else {
+        DEMFI_LDS_ATTR(conv_ws2_kernel<false>);
+        hipLaunchKernelGGL(conv_ws2_kernel<false>, dim3(grid), dim3(Ws2Cfg<false>::NTHREADS), Ws2Cfg<false>::LDS_BYTES, (hipStream_t)stream, dev);
+    }
+    DEMFI_HIP_CHECK(hipGetLastError());
+    return DEMFI_OK;
+}

@@ -389,6 +389,71 @@ def test_streamed_weight_conv_7x7_192_to_64(H, W, batch, act):
     assert err < 4e-3 * max(1.0, ref.abs().max().item()), err
 
 
+WS2_S2_CASES = [
+    # (input pieces as (channels of the buffer, channels taken), cout, residual?, act)
+    ([(64, 64), (16, 16)], 64, True, L.ACT_RELU),                # Refine_Module.enc1#t: Ft | the 16-channel record of the thin planes, + the hoisted aF part
+    ([(64, 64), (64, 64)], 64, False, L.ACT_NONE),               # enc1#aF
+    ([(64, 64)], 128, False, L.ACT_RELU),                        # enc2: two 64-cout blocks
+    ([(128, 128)], 256, False, L.ACT_RELU),                      # enc3: four
+]
+
+
+@pytest.mark.parametrize('case', WS2_S2_CASES)
+@pytest.mark.parametrize('H,W,batch', [(16, 32, 1), (37, 75, 2), (23, 40, 1), (184, 320, 2)])
+def test_stride2_4x4_conv_by_phases(case, H, W, batch):
+    """Round 6 (wsconv.hip): the 4x4 stride-2 layers of the UNet encoder (DeMFInet.py:575-577, 588-590) as four phases of 2x2 taps over
+    32-channel units -- every tap of every phase against torch's strided convolution (fp64 on the same fp16 operands): interior and
+    ragged tiles, odd output sizes (the input is 2H x 2W), a 16-channel tail piece padded to a unit, several 64-cout blocks, a batch
+    stride, the NHWC residual, more items than workgroups (184 x 320 x 2)."""
+    pieces, cout, with_res, act = case
+    if H * W * batch > 50000 and cout > 64:
+        pytest.skip('the large grid is covered by the 64-cout cases')
+    torch.manual_seed(H * 7 + W + cout)
+    pl = Plan(H, W, torch.float16, DEV)
+    bufs, srcs, cin = [], [], 0
+    for ct, take in pieces:
+        b = pl._fat(2 * H, 2 * W, ct, batch)
+        b.copy_(torch.randn(b.shape, device=DEV))
+        bufs.append((b, take))
+        if take == 16:
+            m = list(range(cin, cin + 9)) + [-1] * 7             # 9 real channels of a 16-channel record (misc16)
+            srcs.append(pl.fsrc_map(b, m, b=None))
+            cin += 9
+        else:
+            srcs.append(pl.fsrc(b, cin, 0, take))
+            cin += take
+    out = pl._fat(H, W, cout, batch)
+    res = pl._fat(H, W, cout, batch)
+    res.copy_(torch.randn(res.shape, device=DEV))
+    wt = torch.randn(cout, cin, 4, 4) * (1.0 / (cin * 16) ** 0.5)
+    bs = torch.randn(cout) * 0.1
+    pl.conv([], 'enc', srcs, [_Dst(pl.fview(out), range(cout), act, res=pl.fview(res) if with_res else None)], H, W, stride=2, batch=batch,
+            weight=wt, bias=bs)
+    d = pl._descs[0]
+    assert d.rec_bytes == 64 and d.nco == 2 and d.cout_perm == 1 and d.n_chunks == sum((t + 31) // 32 for _, t in pieces)      # the shape wsconv.hip owns
+    pl._upload()
+    for rep in range(2):
+        out.fill_(7.0)
+        pl.launch_conv(0, _stream())
+    torch.cuda.synchronize()
+    xs = []
+    for b, take in bufs:
+        xs.append(b[..., :9] if take == 16 else b[..., :take])
+    x = torch.cat(xs, 3).permute(0, 3, 1, 2)
+    big = H * W * batch > 50000
+    if big:
+        ref = torch.nn.functional.conv2d(x.float(), wt.half().float().to(DEV), bs.to(DEV), stride=2, padding=1).double().cpu()
+    else:
+        ref = torch.nn.functional.conv2d(x.double().cpu(), wt.half().double(), bs.double(), stride=2, padding=1)
+    if with_res:
+        ref = ref + res.permute(0, 3, 1, 2).double().cpu()
+    if act == L.ACT_RELU:
+        ref = torch.relu(ref)
+    got = out.permute(0, 3, 1, 2).double().cpu()
+    err = (got - ref).abs().max().item()
+    assert err < 4e-3 * max(1.0, ref.abs().max().item()), (case, H, W, batch, err)
+
+
 THIN_CASES = [
     # cin, list of (n couts, residual?) per destination tensor, act, batch
     (64, [(3, True), (3, True), (3, True)], L.ACT_NONE, 1),      # Dec_last2_2: three frames, each + its own residual
