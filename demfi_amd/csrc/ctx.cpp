@@ -54,11 +54,15 @@ int build_conv(int dtype, int H, int W, int stride, int batch, const float* w, c
     // kernel (wsconv.hip): units of 32 channels (64-byte records, a 16-channel tail padded to a whole unit), two 32-cout subtiles per
     // work item
     static const bool ws2 = !(getenv("DEMFI_WS2") && atoi(getenv("DEMFI_WS2")) == 0);
-    bool ws2_shape = ws2 && esz == 2 && stride == 2 && kh == 4 && kw == 4 && pad_y < 0 && pad_x < 0 && n_dsts == 1 && dsts[0].n % 64 == 0 &&
-                     dsts[0].mode == DEMFI_MODE_STORE && (dsts[0].act == DEMFI_ACT_NONE || dsts[0].act == DEMFI_ACT_RELU) &&
+    // ... and so do the 3x3 stride-1 layers of that output shape with >= 96 input channels (the UNet decoders dec0 / dec1 / dec2 with their
+    // upsampled pieces, FGAC's w_gen): the 64 -> 64 and the narrow layers keep their own kernels
+    const bool ws2_s2 = stride == 2 && kh == 4 && kw == 4, ws2_s1 = stride == 1 && kh == 3 && kw == 3 && cin >= 96;
+    bool ws2_shape = ws2 && esz == 2 && (ws2_s2 || ws2_s1) && pad_y < 0 && pad_x < 0 && n_dsts == 1 && dsts[0].n % 64 == 0 &&
+                     dsts[0].mode == DEMFI_MODE_STORE && (dsts[0].act == DEMFI_ACT_NONE || dsts[0].act == DEMFI_ACT_RELU) && dsts[0].scale <= 1 &&
                      dsts[0].dst.sc == 1 && !dsts[0].dst.is_f32 && (!dsts[0].res.ptr || (dsts[0].res.sc == 1 && !dsts[0].res.is_f32));
     for (int i = 0; ws2_shape && i < n_srcs; ++i)
-        ws2_shape = srcs[i].fat && !srcs[i].up_shift && !srcs[i].v.is_f32 && (srcs[i].nch % 32 == 0 || (srcs[i].nch == 16 && i == n_srcs - 1));
+        ws2_shape = srcs[i].fat && !srcs[i].v.is_f32 && (srcs[i].nch % 32 == 0 || (srcs[i].nch == 16 && i == n_srcs - 1)) &&
+                    (srcs[i].up_shift == 0 || (srcs[i].up_shift == 1 && ws2_s1 && H % 2 == 0 && W % 2 == 0));
     if (ws2_shape) nco = 2;
     // the SepConvGRU layers (1x5 / 5x1 over two 64-channel NHWC pieces) run on their own persistent kernel, which wants
     // the two pieces as two 64-channel chunks whatever the general kernel's LDS budget says

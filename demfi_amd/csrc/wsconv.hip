@@ -1,5 +1,6 @@
 // Streamed-weight convolution, second family (round 6): 64 output channels per work item over ANY number of 32-channel input units,
-//   * 3x3 stride 1 (+ optional NHWC residual)        -- layers whose K is not one 64-channel record;
+//   * 3x3 stride 1 (+ optional NHWC residual; units may be read through the x2 nearest-neighbour upsample of the UNet decoder,
+//     DeMFInet.py:592-601)                           -- layers whose K is not one 64-channel record;
 //   * 4x4 stride 2 as FOUR PHASES of 2x2 taps        -- the UNet encoders (Refine_Module.enc1/2/3, DeMFInet.py:575-577, 588-590).
 // What it replaces: the general kernel (conv_kernel) ran the stride-2 layers at 0.09-0.16 of the matrix peak -- one workgroup per
 // 8 x 32 tile, a VGPR-staged gather of a 18 x 66-pixel window per chunk and one barrier per tap (16 per chunk).
@@ -68,6 +69,7 @@ struct WsUnit {
     int iy0, ix0;               // input coordinates of record (0, 0)
     int sx, sy;                 // byte strides between the tile's records / lines
     int half;                   // 1: only the first 16 channels of the unit are real (the rest reads the zero page)
+    int up;                     // 1: the piece is read through a nearest-neighbour x2 upsample (3x3 only): src = the image, record (l, c) = pixel ((iy0 + l) >> 1, (ix0 + c) >> 1)
     bool interior;
 };
 
@@ -137,7 +139,9 @@ __global__ __launch_bounds__(Ws2Cfg<S2>::NTHREADS, 1) void conv_ws2_kernel(const
         r.sy = (int)(pc.v.sy * 2) * st;
         r.iy0 = S2 ? 2 * c.ty * C::TH - py : c.ty * C::TH - 1;
         r.ix0 = S2 ? 2 * c.tx * C::TWP - px : c.tx * C::TWP - 1;
-        r.src = (const char*)pc.v.ptr + (int64_t)c.img * pc.v.sb * 2 + (int64_t)r.iy0 * (pc.v.sy * 2) + (int64_t)r.ix0 * (pc.v.sx * 2);
+        r.up = S2 ? 0 : pc.up_shift;
+        r.src = (const char*)pc.v.ptr + (int64_t)c.img * pc.v.sb * 2;
+        if (!r.up) r.src += (int64_t)r.iy0 * (pc.v.sy * 2) + (int64_t)r.ix0 * (pc.v.sx * 2);
         r.half = pc.nch == 16;
         // packed weights: [cout block][chunk][tap][k-step][cout half] KiB; S2: tap (ky, kx) = (2 ky2 + 1 - py, 2 kx2 + 1 - px)
         r.w = (const char*)d->wpack + ((int64_t)c.blk * d->w_blk_stride + ch.w_off) * 16 + (S2 ? ((4 * (1 - py) + (1 - px)) * 4) * 1024 : 0);
@@ -168,7 +172,8 @@ __global__ __launch_bounds__(Ws2Cfg<S2>::NTHREADS, 1) void conv_ws2_kernel(const
 #pragma unroll
             for (int j = 0; j < C::NIW; ++j) {
                 const int i = dw + C::NHW * j;
-                const char* g = un.src + (dl[j] * un.sy + dc[j] * un.sx + (dslot[j] << 4));
+                const int ll = un.up ? (un.iy0 + dl[j]) >> 1 : dl[j], cc = un.up ? (un.ix0 + dc[j]) >> 1 : dc[j];      // (un.up: wave-uniform)
+                const char* g = un.src + (ll * un.sy + cc * un.sx + (dslot[j] << 4));
                 bool ok = !((un.half != 0) & (dslot[j] >= 2));
                 if (!un.interior) {                              // wave-uniform
                     const int iy = un.iy0 + dl[j] * (S2 ? 2 : 1), ix = un.ix0 + dc[j] * (S2 ? 2 : 1);
@@ -378,7 +383,8 @@ bool demfi_ws2_eligible(const demfi_conv* h)
         const demfi_chunk& ch = h->chunks[c];
         if (ch.nks != 2 || ch.n_pieces < 1 || ch.n_pieces > 2) return false;
         const demfi_piece& p = h->pieces[ch.first_piece];
-        if (!p.fat || p.up_shift || !p.v.ptr || p.v.sc != 1 || p.v.is_f32 || p.lds_ch != 0) return false;
+        if (!p.fat || !p.v.ptr || p.v.sc != 1 || p.v.is_f32 || p.lds_ch != 0) return false;
+        if (p.up_shift != 0 && (p.up_shift != 1 || s2 || (h->H & 1) || (h->W & 1))) return false;      // x2 nearest-neighbour upsample: 3x3 only
         if (ch.n_pieces == 1 ? p.nch != 32 : (p.nch != 16 || h->pieces[ch.first_piece + 1].v.ptr != nullptr || h->pieces[ch.first_piece + 1].nch != 16)) return false;
         if (p.v.sy * 4 * 20 + p.v.sx * 4 * 40 >= (int64_t)1 << 31) return false;       // 32-bit per-lane offsets inside a tile
     }

@@ -454,6 +454,60 @@ def test_stride2_4x4_conv_by_phases(case, H, W, batch):
     assert err < 4e-3 * max(1.0, ref.abs().max().item()), (case, H, W, batch, err)
 
 
+WS2_S1_CASES = [
+    # (pieces as (channels, upsampled?), cout, residual?, act)
+    ([(128, True), (64, False)], 64, False, L.ACT_RELU),         # Refine_Module.dec2: cat[up(d1), u1]
+    ([(256, True), (128, False)], 128, False, L.ACT_RELU),       # dec1: two 64-cout blocks
+    ([(256, False)], 256, False, L.ACT_RELU),                    # dec0
+    ([(64, False), (64, False)], 64, False, L.ACT_RELU),         # FGAC w_gen
+    ([(64, False), (32, False)], 64, True, L.ACT_RELU),          # 96 channels + NHWC residual (the shape of a fused Dec_first_2)
+]
+
+
+@pytest.mark.parametrize('case', WS2_S1_CASES)
+@pytest.mark.parametrize('H,W,batch', [(16, 32, 1), (38, 76, 2), (22, 40, 1), (184, 320, 2)])
+def test_conv3x3_over_32_channel_units(case, H, W, batch):
+    """Round 6 (wsconv.hip), the 3x3 form: K walked in 32-channel units from several NHWC pieces, some of them read through the x2
+    nearest-neighbour upsample of the UNet decoder (DeMFInet.py:592-601: cat[up(d), skip]), 64-cout blocks, optional residual --
+    against torch (upsample + conv2d, fp64 on the same fp16 operands) on interior / ragged tiles and more items than workgroups."""
+    pieces, cout, with_res, act = case
+    if H * W * batch > 50000 and cout > 64:
+        pytest.skip('the large grid is covered by the 64-cout cases')
+    torch.manual_seed(H * 5 + W + cout)
+    pl = Plan(H, W, torch.float16, DEV)
+    srcs, xs, cin = [], [], 0
+    for ch, up in pieces:
+        b = pl._fat(H // 2, W // 2, ch, batch) if up else pl._fat(H, W, ch, batch)
+        b.copy_(torch.randn(b.shape, device=DEV))
+        srcs.append(pl.fsrc(b, cin, 0, ch, up=1 if up else 0))
+        x = b.permute(0, 3, 1, 2)
+        xs.append(torch.nn.functional.interpolate(x.float(), scale_factor=2, mode='nearest').half() if up else x)
+        cin += ch
+    out = pl._fat(H, W, cout, batch)
+    res = pl._fat(H, W, cout, batch)
+    res.copy_(torch.randn(res.shape, device=DEV))
+    wt = torch.randn(cout, cin, 3, 3) * (1.0 / (cin * 9) ** 0.5)
+    bs = torch.randn(cout) * 0.1
+    pl.conv([], 'dec', srcs, [_Dst(pl.fview(out), range(cout), act, res=pl.fview(res) if with_res else None)], H, W, batch=batch, weight=wt, bias=bs)
+    d = pl._descs[0]
+    assert d.rec_bytes == 64 and d.nco == 2 and d.cout_perm == 1 and d.n_chunks == cin // 32
+    pl._upload()
+    for rep in range(2):
+        out.fill_(7.0)
+        pl.launch_conv(0, _stream())
+    torch.cuda.synchronize()
+    x = torch.cat(xs, 1)
+    if H * W * batch > 50000:
+        ref = torch.nn.functional.conv2d(x.float(), wt.half().float().to(DEV), bs.to(DEV), padding=1).double().cpu()
+    else:
+        ref = torch.nn.functional.conv2d(x.double().cpu(), wt.half().double(), bs.double(), padding=1)
+    if with_res:
+        ref = ref + res.permute(0, 3, 1, 2).double().cpu()
+    ref = torch.relu(ref)
+    err = (out.permute(0, 3, 1, 2).double().cpu() - ref).abs().max().item()
+    assert err < 4e-3 * max(1.0, ref.abs().max().item()), (case, H, W, batch, err)
+
+
 THIN_CASES = [
     # cin, list of (n couts, residual?) per destination tensor, act, batch
     (64, [(3, True), (3, True), (3, True)], L.ACT_NONE, 1),      # Dec_last2_2: three frames, each + its own residual
