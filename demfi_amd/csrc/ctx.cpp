@@ -56,12 +56,17 @@ int build_conv(int dtype, int H, int W, int stride, int batch, const float* w, c
     static const bool ws2 = !(getenv("DEMFI_WS2") && atoi(getenv("DEMFI_WS2")) == 0);
     // ... and so do the 3x3 stride-1 layers of that output shape with >= 96 input channels (the UNet decoders dec0 / dec1 / dec2 with their
     // upsampled pieces, FGAC's w_gen): the 64 -> 64 and the narrow layers keep their own kernels
-    const bool ws2_s2 = stride == 2 && kh == 4 && kw == 4, ws2_s1 = stride == 1 && kh == 3 && kw == 3 && cin >= 96;
+    int src_nch = 0;
+    for (int i = 0; i < n_srcs; ++i) src_nch += srcs[i].nch;
+    const bool ws2_s2 = stride == 2 && kh == 4 && kw == 4, ws2_s1 = stride == 1 && kh == 3 && kw == 3 && src_nch > 64;
     bool ws2_shape = ws2 && esz == 2 && (ws2_s2 || ws2_s1) && pad_y < 0 && pad_x < 0 && n_dsts == 1 && dsts[0].n % 64 == 0 &&
                      dsts[0].mode == DEMFI_MODE_STORE && (dsts[0].act == DEMFI_ACT_NONE || dsts[0].act == DEMFI_ACT_RELU) && dsts[0].scale <= 1 &&
                      dsts[0].dst.sc == 1 && !dsts[0].dst.is_f32 && (!dsts[0].res.ptr || (dsts[0].res.sc == 1 && !dsts[0].res.is_f32));
     for (int i = 0; ws2_shape && i < n_srcs; ++i)
-        ws2_shape = srcs[i].fat && !srcs[i].v.is_f32 && (srcs[i].nch % 32 == 0 || (srcs[i].nch == 16 && i == n_srcs - 1)) &&
+        // a tail unit at the end: a 16-channel piece, optionally followed by an 8-channel one (Dec_first_2: ref16 | agg3d)
+        ws2_shape = srcs[i].fat && !srcs[i].v.is_f32 &&
+                    (srcs[i].nch % 32 == 0 || (srcs[i].nch == 16 && !srcs[i].up_shift && (i == n_srcs - 1 || (i == n_srcs - 2 && srcs[n_srcs - 1].nch == 8))) ||
+                     (srcs[i].nch == 8 && !srcs[i].up_shift && i == n_srcs - 1 && i > 0 && srcs[i - 1].nch == 16)) &&
                     (srcs[i].up_shift == 0 || (srcs[i].up_shift == 1 && ws2_s1 && H % 2 == 0 && W % 2 == 0));
     if (ws2_shape) nco = 2;
     // the SepConvGRU layers (1x5 / 5x1 over two 64-channel NHWC pieces) run on their own persistent kernel, which wants
@@ -1380,8 +1385,25 @@ struct Builder {
         // Dec_first_2 = relu(conv3x3(Agg3)) with Agg3 = cat[F_rec (64, changes per recursion) | 27 recursion-invariant planes |
         // 8 planes of the current recursion] (DeMFInet.py:151-157), split by linearity in the fp16 plan (see below).
         const std::vector<int32_t> a3d_sel = {6, 7, 8, 82, 83, 84, 85, 86};
-        SubW w_dyn, w_rec;
-        std::vector<int32_t> dyn_m16 = range(0, 11);
+        SubW w_dyn, w_rec, w_df2;
+        std::vector<int32_t> dyn_m16 = range(0, 11), df2_m16, df2_m8;
+        // round 6 EXPERIMENT (DEMFI_DF2_FUSE=1; the product keeps the two launches of rounds 2-5): ONE launch per recursion on the
+        // streamed-weight kernel (wsconv.hip): units [F_rec lo | F_rec hi | ref16 + agg3d + 0], the window-constant share (g_pw) as the
+        // residual, so that the partial sum g_p2 makes no round trip through HBM (256 B per pixel and recursion).  Built, parity-green,
+        // measured 0.98 ms against 0.44 + 0.51 ms (same box): the kernel's epilogue (16-byte-per-lane residual loads and stores: 32
+        // quarter lines per instruction) costs 15 000 of an item's 33 000 cycles (profiles/r06_notes.md section 6, the phase stamps).
+        static const bool df2_fuse = getenv("DEMFI_DF2_FUSE") && atoi(getenv("DEMFI_DF2_FUSE")) != 0 &&
+                                     !(getenv("DEMFI_WS2") && atoi(getenv("DEMFI_WS2")) == 0);
+        if (c->dtype == DEMFI_F16 && df2_fuse) {
+            std::vector<int32_t> sel = range(9, 73);                 // F_rec -> sub-layer inputs 0..63
+            for (int i = 0; i < 6; ++i) sel.push_back(i);            // S0p, S1p -> 64..69
+            for (int i = 73; i < 78; ++i) sel.push_back(i);          // occ_0 -> 70; rflow_t0, rflow_t1 -> 71..74
+            sel.insert(sel.end(), a3d_sel.begin(), a3d_sel.end());   // the 8 planes of the recursion -> 75..82
+            w_df2 = sub_weight("Dec_first_2", sel, true);
+            // ref16 = [S0p, S1p, Stp | rflow_t0, rflow_t1, occ logit | occ_0 | 0]
+            df2_m16 = {64, 65, 66, 67, 68, 69, -1, -1, -1, 71, 72, 73, 74, -1, 70, -1};
+            df2_m8 = range(75, 83);
+        } else
         if (c->dtype == DEMFI_F16) {
             // per recursion: ONE narrow launch over [ref16 (its 11 planes Agg3 holds: t-dependent, recursion-invariant) | agg3d (8 planes of this
             // recursion)] + bias + the window-constant share (g_pw, trunk) -> g_p2; then the F_rec part on the 64 -> 64 kernel
@@ -1458,6 +1480,10 @@ struct Builder {
             // (DeMFInet.py:151-155) as the NHWC record Dec_first_2 reads (agg3d): no plane-packing launch
             warp(sg, "warp_thin", 3, tview(B["sharp1"], 0), tview(B["sharp1"], 3), tview(B["stnew"]), delta_p(it + 1, 0), delta_p(it + 1, 2),
                  delta_p(it + 1, 4), plane(B["occ"], it + 1), tp, ptr(B["agg3d"]));
+            if (c->dtype == DEMFI_F16 && df2_fuse) {
+                conv(sg, "Dec_first_2#t", {fsrc(hout, 0), fsrc_map(B["ref16"], df2_m16), fsrc_map(B["agg3d"], df2_m8)},
+                     {D(fview(B["g_a"]), range(0, 64), R, DEMFI_MODE_STORE, fview(TB["g_pw"]))}, H, W, 1, 1, &w_df2.w, &w_df2.b, &w_df2.shape);
+            } else
             if (c->dtype == DEMFI_F16) {
                 conv(sg, "Dec_first_2#dyn", {fsrc_map(B["ref16"], dyn_m16), fsrc_map(B["agg3d"], range(11, 19))},
                      {D(fview(B["g_p2"]), range(0, 64), DEMFI_ACT_NONE, DEMFI_MODE_STORE, fview(TB["g_pw"]))}, H, W, 1, 1, &w_dyn.w, &w_dyn.b,

@@ -23,6 +23,7 @@
 #include "common.h"
 #include <type_traits>
 #include <stdlib.h>
+#include <string.h>
 
 namespace {
 
@@ -48,7 +49,7 @@ template <bool S2> struct Ws2Cfg {
     static constexpr int NIW = (NI + NHW - 1) / NHW;             // per helper wave: every helper issues exactly NIW (the surplus ones land in the buffer's pad)
     static constexpr int BUF_BYTES = NIW * NHW * 1024;
     static constexpr int NBUF = S2 ? 4 : 3;
-    static constexpr int LDS_BYTES = NBUF * BUF_BYTES;
+    static constexpr int LDS_BYTES = NBUF * BUF_BYTES + 1024;    // + the biases of up to four cout blocks
     static constexpr int NG = 2 * KSE;                           // (kx, k-step) groups per unit
     static constexpr int NSTEP = NG * KSE;
 #ifndef DEMFI_WS2_DEPTH3
@@ -69,12 +70,58 @@ struct WsUnit {
     int iy0, ix0;               // input coordinates of record (0, 0)
     int sx, sy;                 // byte strides between the tile's records / lines
     int half;                   // 1: only the first 16 channels of the unit are real (the rest reads the zero page)
+    const char* src2;           // half: an optional second piece of 8 channels (one 16-byte slot) behind the first 16
+    int sx2, sy2, has2;
     int up;                     // 1: the piece is read through a nearest-neighbour x2 upsample (3x3 only): src = the image, record (l, c) = pixel ((iy0 + l) >> 1, (ix0 + c) >> 1)
     bool interior;
 };
 
+// The launch description is a KERNEL ARGUMENT (by value), not the device copy of the descriptor: kernarg memory is invariant to the
+// compiler, so nothing is re-read behind the kernel's barriers, and a unit's description is one scalar load instead of the dependent
+// chain chunk -> piece -> view (the first version walked the descriptor: ~13 us of scalar-load latency chains per item).
+constexpr int WS_MAX_CHUNKS = 16, WS_MAX_BLOCKS = 4;
+struct WsChunk {
+    const char* src; const char* src2;      // piece base (image 0); second piece of a tail unit (or NULL)
+    int64_t sb, sb2;                        // bytes between images
+    int sx, sy, sx2, sy2;                   // bytes between pixels / rows (of the piece itself)
+    int flags;                              // 1: tail unit (16 real channels [+ 8 of src2]), 2: read through the x2 upsample
+    int w_off;                              // bytes: this chunk's packed weights inside a cout block
+};
+struct WsBlock {
+    char* dst; const char* res;             // first of the block's 64 channels
+    int64_t d_sb, r_sb;
+    int d_sx, d_sy, r_sx, r_sy;             // bytes
+    int relu, _pad;
+};
+struct WsArgs {
+    const char* wpack; const float* bias; const char* zeros;
+    int64_t w_blk_stride;                   // bytes between cout blocks
+    int H, W, inH, inW, batch, n_chunks, nblk, _pad;
+    unsigned long long* trace;              // phase stamps of workgroup 0 (DEMFI_WS2_TRACE=1, a debugging aid; NULL in the product)
+    WsBlock blk[WS_MAX_BLOCKS];
+    WsChunk ch[WS_MAX_CHUNKS];
+};
+
+// (fp16 half of a packed pair) * 1.0 + c in one VALU op: bias + residual -> the accumulator's initial value
+__device__ __forceinline__ float ws_mix_lo(unsigned a, float c)
+{
+    float d = 0.0f;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(a), "v"(c));
+#endif
+    return d;
+}
+__device__ __forceinline__ float ws_mix_hi(unsigned a, float c)
+{
+    float d = 0.0f;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(a), "v"(c));
+#endif
+    return d;
+}
+
 template <bool S2>
-__global__ __launch_bounds__(Ws2Cfg<S2>::NTHREADS, 1) void conv_ws2_kernel(const demfi_conv* __restrict__ d)
+__global__ __launch_bounds__(Ws2Cfg<S2>::NTHREADS, 1) void conv_ws2_kernel(const WsArgs a)
 {
     using C = Ws2Cfg<S2>;
     constexpr int KSE = C::KSE, RPW = C::RPW;
@@ -82,10 +129,10 @@ __global__ __launch_bounds__(Ws2Cfg<S2>::NTHREADS, 1) void conv_ws2_kernel(const
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int H = d->H, W = d->W, inH = d->inH, inW = d->inW;
+    const int H = a.H, W = a.W, inH = a.inH, inW = a.inW;
     const int tiles_x = (W + C::TWP - 1) / C::TWP, tiles_y = (H + C::TH - 1) / C::TH, tiles_img = tiles_x * tiles_y;
-    const int nblk = d->cout_pad >> 6;                           // 64-cout blocks: the innermost index of an item (they share the input tile)
-    const int total = tiles_img * d->batch * nblk;
+    const int nblk = a.nblk;                                     // 64-cout blocks: the innermost index of an item (they share the input tile)
+    const int total = tiles_img * a.batch * nblk;
     // contiguous run of items per workgroup, the workgroups of an XCD (blockIdx % 8) share a contiguous band
     int it0, it1;
     {
@@ -102,9 +149,14 @@ __global__ __launch_bounds__(Ws2Cfg<S2>::NTHREADS, 1) void conv_ws2_kernel(const
         }
     }
     if (it0 >= it1) return;                                      // uniform per workgroup
-    const int upi = d->n_chunks * (S2 ? 4 : 1);                  // units per item
+    const int upi = a.n_chunks * (S2 ? 4 : 1);                   // units per item
     const int n_units = (it1 - it0) * upi;
-    const char* const zeros = (const char*)d->zero_page;
+    const char* const zeros = a.zeros;
+    int tr_n = 0;
+    auto stamp = [&](int tag) {                                  // [wave][512] of (tag << 56 | s_memtime), workgroup 0 only
+        if (a.trace && blockIdx.x == 0 && tr_n < 512 && lane == 0) a.trace[wave * 512 + tr_n] = ((unsigned long long)tag << 56) | (__builtin_readcyclecounter() & 0xffffffffffffffull);
+        ++tr_n;
+    };
 
     auto item_pos = [&](int it, int& blk, int& img, int& ty, int& tx) {
         blk = it % nblk;
@@ -123,7 +175,7 @@ __global__ __launch_bounds__(Ws2Cfg<S2>::NTHREADS, 1) void conv_ws2_kernel(const
         return c;
     };
     auto advance = [&](Cursor& c) {
-        if (++c.cu < d->n_chunks) return;                        // chunk innermost: the two halves of a 128-byte line follow each other
+        if (++c.cu < a.n_chunks) return;                        // chunk innermost: the two halves of a 128-byte line follow each other
         c.cu = 0;
         if (S2 && ++c.ph < 4) return;
         c.ph = 0;
@@ -132,19 +184,22 @@ __global__ __launch_bounds__(Ws2Cfg<S2>::NTHREADS, 1) void conv_ws2_kernel(const
     auto unit_info = [&](const Cursor& c) {
         WsUnit r;
         const int py = c.ph >> 1, px = c.ph & 1;
-        const demfi_chunk& ch = d->chunks[c.cu];
-        const demfi_piece& pc = d->pieces[ch.first_piece];
+        const WsChunk& ch = a.ch[c.cu];
         const int st = S2 ? 2 : 1;
-        r.sx = (int)(pc.v.sx * 2) * st;
-        r.sy = (int)(pc.v.sy * 2) * st;
+        r.sx = ch.sx * st;
+        r.sy = ch.sy * st;
         r.iy0 = S2 ? 2 * c.ty * C::TH - py : c.ty * C::TH - 1;
         r.ix0 = S2 ? 2 * c.tx * C::TWP - px : c.tx * C::TWP - 1;
-        r.up = S2 ? 0 : pc.up_shift;
-        r.src = (const char*)pc.v.ptr + (int64_t)c.img * pc.v.sb * 2;
-        if (!r.up) r.src += (int64_t)r.iy0 * (pc.v.sy * 2) + (int64_t)r.ix0 * (pc.v.sx * 2);
-        r.half = pc.nch == 16;
+        r.up = S2 ? 0 : (ch.flags >> 1) & 1;
+        r.src = ch.src + c.img * ch.sb;
+        if (!r.up) r.src += (int64_t)r.iy0 * ch.sy + (int64_t)r.ix0 * ch.sx;
+        r.half = ch.flags & 1;
+        r.has2 = ch.src2 != nullptr;
+        r.sx2 = ch.sx2 * st;
+        r.sy2 = ch.sy2 * st;
+        r.src2 = ch.src2 + c.img * ch.sb2 + (int64_t)r.iy0 * ch.sy2 + (int64_t)r.ix0 * ch.sx2;      // only used when has2
         // packed weights: [cout block][chunk][tap][k-step][cout half] KiB; S2: tap (ky, kx) = (2 ky2 + 1 - py, 2 kx2 + 1 - px)
-        r.w = (const char*)d->wpack + ((int64_t)c.blk * d->w_blk_stride + ch.w_off) * 16 + (S2 ? ((4 * (1 - py) + (1 - px)) * 4) * 1024 : 0);
+        r.w = a.wpack + c.blk * a.w_blk_stride + ch.w_off + (S2 ? ((4 * (1 - py) + (1 - px)) * 4) * 1024 : 0);
         const int ly = S2 ? 2 * (C::LH - 1) : C::LH - 1, lx_ = S2 ? 2 * (C::LL - 1) : C::LL - 1;
         r.interior = r.iy0 >= 0 && r.iy0 + ly < inH && r.ix0 >= 0 && r.ix0 + lx_ < inW;
         return r;
@@ -175,6 +230,11 @@ __global__ __launch_bounds__(Ws2Cfg<S2>::NTHREADS, 1) void conv_ws2_kernel(const
                 const int ll = un.up ? (un.iy0 + dl[j]) >> 1 : dl[j], cc = un.up ? (un.ix0 + dc[j]) >> 1 : dc[j];      // (un.up: wave-uniform)
                 const char* g = un.src + (ll * un.sy + cc * un.sx + (dslot[j] << 4));
                 bool ok = !((un.half != 0) & (dslot[j] >= 2));
+                if (un.has2) {                                   // wave-uniform: slot 2 of a tail unit comes from the second piece
+                    const bool s2nd = dslot[j] == 2;
+                    g = s2nd ? un.src2 + (dl[j] * un.sy2 + dc[j] * un.sx2) : g;
+                    ok = ok | s2nd;
+                }
                 if (!un.interior) {                              // wave-uniform
                     const int iy = un.iy0 + dl[j] * (S2 ? 2 : 1), ix = un.ix0 + dc[j] * (S2 ? 2 : 1);
                     ok = ok & ((unsigned)iy < (unsigned)inH) & ((unsigned)ix < (unsigned)inW);
@@ -191,8 +251,11 @@ __global__ __launch_bounds__(Ws2Cfg<S2>::NTHREADS, 1) void conv_ws2_kernel(const
             if (behind >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * C::NIW) : "memory");
             else if (behind == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::NIW) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            stamp(1);
             asm volatile("s_barrier" ::: "memory");             // unit u is in LDS; the MFMA waves are done with unit u - 1
+            stamp(2);
             if (u + C::NBUF - 1 < n_units) issue_unit(u + C::NBUF - 1);      // into the buffer of unit u - 1
+            stamp(3);
         }
         return;
     }
@@ -221,60 +284,69 @@ __global__ __launch_bounds__(Ws2Cfg<S2>::NTHREADS, 1) void conv_ws2_kernel(const
 
     f16x_t acc[RPW];
     uint4 A[C::DEPTH];
+    // biases of all cout blocks to LDS once (behind the unit buffers); an item's four quads per lane are four ds_read_b128
+    float* const bias_lds = (float*)(smem + C::LDS_BYTES - 1024);
+    if (wave == 0)
+        for (int i = lane; i < nblk * 64; i += 64) bias_lds[i] = a.bias[i];
     // accumulators of an item start at bias + residual
     auto res_fetch = [&](const Cursor& io, u4_t (&rr)[RPW][2]) {
-        const demfi_seg& sg = d->segs[d->sub_seg[io.blk * 2]];
-        const half_t* const rp = (const half_t*)sg.res.ptr;
-        const u4_t z = {0u, 0u, 0u, 0u};
-        if (!rp) {                                               // wave-uniform
-#pragma unroll
-            for (int p = 0; p < RPW; ++p) { rr[p][0] = z; rr[p][1] = z; }
-            return;
-        }
-        const int ch0 = d->oct_ch[io.blk * 8];
+        const WsBlock& bk = a.blk[io.blk];
+        if (!bk.res) return;                                     // wave-uniform; acc_init does not read rr then
         const int ox = io.tx * C::TWP + lx;
-        // uniform base (image, first row, first channel) + ONE 32-bit lane offset: the saddr form, no per-load 64-bit address registers
-        const char* const rb = (const char*)(rp + io.img * sg.res.sb + (int64_t)(io.ty * C::TH + rh * RPW) * sg.res.sy + ch0 + cs * 32);
-        const unsigned loff = (unsigned)(ox * (int)sg.res.sx + hi * 8) * 2;
-        const int rsy = (int)sg.res.sy * 2;
         const int oy0 = io.ty * C::TH + rh * RPW;
+        // uniform base (image, first row, first channel) + ONE 32-bit lane offset: the saddr form, no per-load 64-bit address registers
+        const char* const rb = bk.res + io.img * bk.r_sb + (int64_t)oy0 * bk.r_sy + cs * 64;
+        const unsigned loff = (unsigned)(ox * bk.r_sx + hi * 16);
 #pragma unroll
         for (int p = 0; p < RPW; ++p) {
             // pixels outside the image read the zero page: every load is unconditional, all sixteen are in flight together
             const bool ok = oy0 + p < H && ox < W;
-            const char* base = ok ? rb + p * rsy : zeros;       // (row: uniform)
+            const char* base = ok ? rb + p * bk.r_sy : zeros;   // (row: uniform)
             const unsigned lo_ = ok ? loff : 0u;
 #pragma unroll
             for (int m2 = 0; m2 < 2; ++m2) rr[p][m2] = *gcp<u4_t>(base + (lo_ + (ok ? m2 * 32 : 0)));
         }
     };
-    auto acc_init = [&](const Cursor& io, const u4_t (&rr)[RPW][2]) {
+    auto acc_init = [&](const Cursor& io, const u4_t (&rr)[RPW][2], auto FIRST) {
         f4_t bq[4];                                              // bias in MFMA-row order: quads 0..3 of this lane
 #pragma unroll
-        for (int qd = 0; qd < 4; ++qd) bq[qd] = *gcp<f4_t>(d->bias + io.blk * 64 + cs * 32 + qd * 8 + hi * 4);
+        for (int qd = 0; qd < 4; ++qd) {
+            if constexpr (decltype(FIRST)::value) bq[qd] = *gcp<f4_t>(a.bias + io.blk * 64 + cs * 32 + qd * 8 + hi * 4);      // no barrier yet: from global
+            else bq[qd] = *(const f4_t*)(bias_lds + io.blk * 64 + cs * 32 + qd * 8 + hi * 4);
+        }
+        if (a.blk[io.blk].res) {
 #pragma unroll
-        for (int p = 0; p < RPW; ++p) {
+            for (int p = 0; p < RPW; ++p) {
 #pragma unroll
-            for (int m2 = 0; m2 < 2; ++m2) {
-                const h8_t r8 = __builtin_bit_cast(h8_t, rr[p][m2]);
+                for (int m2 = 0; m2 < 2; ++m2) {
+                    const u4_t r = rr[p][m2];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    acc[p][(2 * m2) * 4 + j] = bq[2 * m2][j] + (float)r8[j];
-                    acc[p][(2 * m2 + 1) * 4 + j] = bq[2 * m2 + 1][j] + (float)r8[4 + j];
+                    for (int q = 0; q < 2; ++q) {
+                        acc[p][(2 * m2) * 4 + 2 * q] = ws_mix_lo(r[q], bq[2 * m2][2 * q]);
+                        acc[p][(2 * m2) * 4 + 2 * q + 1] = ws_mix_hi(r[q], bq[2 * m2][2 * q + 1]);
+                        acc[p][(2 * m2 + 1) * 4 + 2 * q] = ws_mix_lo(r[2 + q], bq[2 * m2 + 1][2 * q]);
+                        acc[p][(2 * m2 + 1) * 4 + 2 * q + 1] = ws_mix_hi(r[2 + q], bq[2 * m2 + 1][2 * q + 1]);
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int p = 0; p < RPW; ++p) {
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[p][qd * 4 + j] = bq[qd][j];
                 }
             }
         }
     };
     auto item_store = [&](const Cursor& io) {
-        const demfi_seg& sg = d->segs[d->sub_seg[io.blk * 2]];
-        half_t* const dstp = (half_t*)sg.dst.ptr;
-        const float lo = sg.act == DEMFI_ACT_RELU ? 0.0f : -__builtin_inff();      // ReLU or nothing (eligibility), branch-free
-        const int ch0 = d->oct_ch[io.blk * 8];
+        const WsBlock& bk = a.blk[io.blk];
         const int ox = io.tx * C::TWP + lx;
         const int oy0 = io.ty * C::TH + rh * RPW;
-        char* const ob = (char*)(dstp + io.img * sg.dst.sb + (int64_t)oy0 * sg.dst.sy + ch0 + cs * 32);      // uniform
-        const unsigned loff = (unsigned)(ox * (int)sg.dst.sx + hi * 8) * 2;
-        const int dsy = (int)sg.dst.sy * 2;
+        char* const ob = bk.dst + io.img * bk.d_sb + (int64_t)oy0 * bk.d_sy + cs * 64;      // uniform
+        const unsigned loff = (unsigned)(ox * bk.d_sx + hi * 16);
+        const h8_t z8 = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
         for (int p = 0; p < RPW; ++p) {
 #pragma unroll
@@ -282,10 +354,11 @@ __global__ __launch_bounds__(Ws2Cfg<S2>::NTHREADS, 1) void conv_ws2_kernel(const
                 h8_t o;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    o[j] = (half_t)fmaxf(acc[p][(2 * m2) * 4 + j], lo);
-                    o[4 + j] = (half_t)fmaxf(acc[p][(2 * m2 + 1) * 4 + j], lo);
+                    o[j] = (half_t)acc[p][(2 * m2) * 4 + j];
+                    o[4 + j] = (half_t)acc[p][(2 * m2 + 1) * 4 + j];
                 }
-                if (oy0 + p < H && ox < W) *gp<h8_t>(ob + p * dsy + (loff + m2 * 32)) = o;
+                if (bk.relu) o = __builtin_elementwise_max(o, z8);     // wave-uniform; on the packed halves
+                if (oy0 + p < H && ox < W) *gp<h8_t>(ob + p * bk.d_sy + (loff + m2 * 32)) = o;
             }
         }
     };
@@ -295,17 +368,19 @@ __global__ __launch_bounds__(Ws2Cfg<S2>::NTHREADS, 1) void conv_ws2_kernel(const
     {
         u4_t rr[RPW][2];
         res_fetch(io, rr);
-        acc_init(io, rr);
+        acc_init(io, rr, std::true_type{});
     }
     WsUnit cur = unit_info(ccur);
     ws_for<0, C::DEPTH>([&](auto T) { A[decltype(T)::value] = a_load(cur, T); });
 
     for (int u = 0; u < n_units; ++u) {
-        const bool last_of_item = ccur.cu == d->n_chunks - 1 && (!S2 || ccur.ph == 3);
+        const bool last_of_item = ccur.cu == a.n_chunks - 1 && (!S2 || ccur.ph == 3);
         advance(ccur);                                           // past the end: stays on the last item, its A fragments are loaded and dropped
         const WsUnit nxt = unit_info(ccur);
         const char* const tb = smem + (u % C::NBUF) * C::BUF_BYTES;
+        stamp(1);
         asm volatile("s_barrier" ::: "memory");                 // unit u has landed
+        stamp(2);
         uint4 B[C::BL];
         ws_for<0, RPW>([&](auto R) { B[decltype(R)::value] = *(const uint4*)(tb + boff[0] + decltype(R)::value * (C::LL * 64)); });
         __builtin_amdgcn_sched_barrier(0);
@@ -346,14 +421,18 @@ __global__ __launch_bounds__(Ws2Cfg<S2>::NTHREADS, 1) void conv_ws2_kernel(const
             }
             __builtin_amdgcn_sched_barrier(0);
         });
+        stamp(3);
         if (last_of_item) {
             // ---- end of an item: the next item's residual is requested in front of this item's stores
             const bool more = u + 1 < n_units;                  // then ccur already stands on the next item's first unit
             u4_t rr[RPW][2];
             if (more) res_fetch(ccur, rr);
+            stamp(4);
             item_store(io);
-            if (more) acc_init(ccur, rr);
+            stamp(5);
+            if (more) acc_init(ccur, rr, std::false_type{});
             io = ccur;
+            stamp(6);
         }
         cur = nxt;
     }
@@ -378,14 +457,28 @@ bool demfi_ws2_eligible(const demfi_conv* h)
     } else {
         if (h->stride != 1 || h->kh != 3 || h->kw != 3 || h->pad_y != 1 || h->pad_x != 1 || h->inH != h->H || h->inW != h->W) return false;
     }
-    if (h->n_chunks < 1) return false;
+    if (h->n_chunks < 1 || h->n_chunks > WS_MAX_CHUNKS || h->cout_pad / 64 > WS_MAX_BLOCKS) return false;
+    if (h->w_blk_stride * 16 * (h->cout_pad / 64) >= (int64_t)1 << 31) return false;
     for (int c = 0; c < h->n_chunks; ++c) {
         const demfi_chunk& ch = h->chunks[c];
-        if (ch.nks != 2 || ch.n_pieces < 1 || ch.n_pieces > 2) return false;
+        if (ch.nks != 2 || ch.n_pieces < 1 || ch.n_pieces > 3) return false;
         const demfi_piece& p = h->pieces[ch.first_piece];
         if (!p.fat || !p.v.ptr || p.v.sc != 1 || p.v.is_f32 || p.lds_ch != 0) return false;
         if (p.up_shift != 0 && (p.up_shift != 1 || s2 || (h->H & 1) || (h->W & 1))) return false;      // x2 nearest-neighbour upsample: 3x3 only
-        if (ch.n_pieces == 1 ? p.nch != 32 : (p.nch != 16 || h->pieces[ch.first_piece + 1].v.ptr != nullptr || h->pieces[ch.first_piece + 1].nch != 16)) return false;
+        if (ch.n_pieces == 1) {
+            if (p.nch != 32) return false;
+        } else {
+            // a tail unit: 16 channels [+ 8 channels of a second NHWC piece] + zero padding
+            const demfi_piece& q = h->pieces[ch.first_piece + 1];
+            if (p.nch != 16 || p.up_shift) return false;
+            if (ch.n_pieces == 2) {
+                if (q.v.ptr != nullptr || q.nch != 16) return false;
+            } else {
+                const demfi_piece& z = h->pieces[ch.first_piece + 2];
+                if (!q.v.ptr || !q.fat || q.nch != 8 || q.up_shift || q.v.sc != 1 || q.v.is_f32 || z.v.ptr != nullptr || z.nch != 8) return false;
+                if (q.v.sy * 4 * 20 + q.v.sx * 4 * 40 >= (int64_t)1 << 31) return false;
+            }
+        }
         if (p.v.sy * 4 * 20 + p.v.sx * 4 * 40 >= (int64_t)1 << 31) return false;       // 32-bit per-lane offsets inside a tile
     }
     for (int b = 0; b < h->cout_pad / 64; ++b) {
@@ -401,18 +494,68 @@ bool demfi_ws2_eligible(const demfi_conv* h)
     return true;
 }
 
-int demfi_ws2_launch(const demfi_conv* h, const demfi_conv* dev, void* stream)
+int demfi_ws2_launch(const demfi_conv* h, const demfi_conv* /*dev*/, void* stream)
 {
     const int64_t total = (int64_t)((h->W + 31) / 32) * ((h->H + 15) / 16) * h->batch * (h->cout_pad / 64);
     if (total <= 0 || total >= (int64_t)1 << 30) return demfi_set_error(DEMFI_ERR_ARG, "demfi_conv2d (streamed-weight 64-cout kernel): empty or oversized launch");
+    if (!h->wpack || !h->bias) return demfi_set_error(DEMFI_ERR_ARG, "demfi_conv2d (streamed-weight 64-cout kernel): weights / bias not bound");
+    WsArgs a;
+    memset(&a, 0, sizeof(a));
+    a.wpack = (const char*)h->wpack; a.bias = h->bias; a.zeros = (const char*)h->zero_page;
+    a.w_blk_stride = h->w_blk_stride * 16;
+    a.H = h->H; a.W = h->W; a.inH = h->inH; a.inW = h->inW; a.batch = h->batch; a.n_chunks = h->n_chunks; a.nblk = h->cout_pad / 64;
+    for (int b = 0; b < a.nblk; ++b) {
+        const demfi_seg& sg = h->segs[h->sub_seg[2 * b]];
+        const int ch0 = h->oct_ch[8 * b];
+        WsBlock& k = a.blk[b];
+        k.dst = (char*)sg.dst.ptr + (int64_t)ch0 * 2; k.d_sb = sg.dst.sb * 2; k.d_sx = (int)(sg.dst.sx * 2); k.d_sy = (int)(sg.dst.sy * 2);
+        k.res = sg.res.ptr ? (const char*)sg.res.ptr + (int64_t)ch0 * 2 : nullptr;
+        k.r_sb = sg.res.sb * 2; k.r_sx = (int)(sg.res.sx * 2); k.r_sy = (int)(sg.res.sy * 2);
+        k.relu = sg.act == DEMFI_ACT_RELU;
+    }
+    for (int c = 0; c < h->n_chunks; ++c) {
+        const demfi_chunk& ch = h->chunks[c];
+        const demfi_piece& p = h->pieces[ch.first_piece];
+        WsChunk& k = a.ch[c];
+        k.src = (const char*)p.v.ptr; k.sb = p.v.sb * 2; k.sx = (int)(p.v.sx * 2); k.sy = (int)(p.v.sy * 2);
+        k.flags = (p.nch == 16 ? 1 : 0) | (p.up_shift ? 2 : 0);
+        k.w_off = (int)(ch.w_off * 16);
+        if (ch.n_pieces == 3) {
+            const demfi_piece& q = h->pieces[ch.first_piece + 1];
+            k.src2 = (const char*)q.v.ptr; k.sb2 = q.v.sb * 2; k.sx2 = (int)(q.v.sx * 2); k.sy2 = (int)(q.v.sy * 2);
+        }
+    }
     const int grid = total >= 256 ? 256 : (int)total;
+    static const bool tracing = getenv("DEMFI_WS2_TRACE") && atoi(getenv("DEMFI_WS2_TRACE")) != 0;
+    static unsigned long long* trbuf = nullptr;
+    if (tracing) {
+        if (!trbuf) { DEMFI_HIP_CHECK(hipMalloc(&trbuf, 8 * 512 * 8)); }
+        DEMFI_HIP_CHECK(hipMemset(trbuf, 0, 8 * 512 * 8));
+        a.trace = trbuf;
+    }
     if (h->stride == 2) {
         DEMFI_LDS_ATTR(conv_ws2_kernel<true>);
-        hipLaunchKernelGGL(conv_ws2_kernel<true>, dim3(grid), dim3(Ws2Cfg<true>::NTHREADS), Ws2Cfg<true>::LDS_BYTES, (hipStream_t)stream, dev);
+        hipLaunchKernelGGL(conv_ws2_kernel<true>, dim3(grid), dim3(Ws2Cfg<true>::NTHREADS), Ws2Cfg<true>::LDS_BYTES, (hipStream_t)stream, a);
     } else {
         DEMFI_LDS_ATTR(conv_ws2_kernel<false>);
-        hipLaunchKernelGGL(conv_ws2_kernel<false>, dim3(grid), dim3(Ws2Cfg<false>::NTHREADS), Ws2Cfg<false>::LDS_BYTES, (hipStream_t)stream, dev);
+        hipLaunchKernelGGL(conv_ws2_kernel<false>, dim3(grid), dim3(Ws2Cfg<false>::NTHREADS), Ws2Cfg<false>::LDS_BYTES, (hipStream_t)stream, a);
     }
     DEMFI_HIP_CHECK(hipGetLastError());
+    if (tracing) {
+        // debugging aid: the stamps of workgroup 0 (MFMA wave 0, helper wave 4) as deltas in cycles, one line per stamp
+        static unsigned long long host[8 * 512];
+        DEMFI_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+        DEMFI_HIP_CHECK(hipMemcpy(host, trbuf, sizeof(host), hipMemcpyDeviceToHost));
+        for (int w : {0, 4}) {
+            fprintf(stderr, "[ws2 trace] stride %d chunks %d blocks %d wave %d:", h->stride, h->n_chunks, h->cout_pad / 64, w);
+            unsigned long long prev = 0;
+            for (int i = 0; i < 512 && host[w * 512 + i]; ++i) {
+                const unsigned long long t = host[w * 512 + i] & 0xffffffffffffffull;
+                fprintf(stderr, " %d:%lld", (int)(host[w * 512 + i] >> 56), prev ? (long long)(t - prev) : 0ll);
+                prev = t;
+            }
+            fprintf(stderr, "\n");
+        }
+    }
     return DEMFI_OK;
 }

@@ -508,6 +508,48 @@ def test_conv3x3_over_32_channel_units(case, H, W, batch):
     assert err < 4e-3 * max(1.0, ref.abs().max().item()), (case, H, W, batch, err)
 
 
+@pytest.mark.parametrize('H,W,batch', [(16, 32, 1), (37, 75, 2), (184, 320, 2)])
+def test_conv3x3_units_with_a_two_piece_tail(H, W, batch):
+    """The fused Dec_first_2 of the fp16 plan (DeMFInet.py:151-158, round 6): units [F_rec lo | F_rec hi | 16 channels of ref16 through a
+    channel map + the 8-channel record of the recursion + zero padding], the window-constant partial sum as a residual WITHOUT batch
+    stride (one image shared by all time instants), ReLU -- against torch on the same fp16 operands."""
+    torch.manual_seed(H + W)
+    pl = Plan(H, W, torch.float16, DEV)
+    h = pl._fat(H, W, 64, batch)
+    r16 = pl._fat(H, W, 16, batch)
+    a8 = pl._fat(H, W, 8, batch)
+    for b in (h, r16, a8):
+        b.copy_(torch.randn(b.shape, device=DEV))
+    gw = pl._fat(H, W, 64, 1)
+    gw.copy_(torch.randn(gw.shape, device=DEV))
+    out = pl._fat(H, W, 64, batch)
+    m16 = [64, 65, 66, 67, 68, 69, -1, -1, -1, 71, 72, 73, 74, -1, 70, -1]
+    cin = 83
+    wt = torch.randn(64, cin, 3, 3) * (1.0 / (cin * 9) ** 0.5)
+    bs = torch.randn(64) * 0.1
+    res = pl.fview(gw)
+    res.sb = 0
+    pl.conv([], 'Dec_first_2#t', [pl.fsrc(h, 0), pl.fsrc_map(r16, m16, b=None), pl.fsrc_map(a8, list(range(75, 83)), b=None)],
+            [_Dst(pl.fview(out), range(64), L.ACT_RELU, res=res)], H, W, batch=batch, weight=wt, bias=bs)
+    d = pl._descs[0]
+    assert d.rec_bytes == 64 and d.nco == 2 and d.cout_perm == 1 and d.n_chunks == 3 and d.chunks[2].n_pieces == 3
+    pl._upload()
+    for rep in range(2):
+        out.fill_(7.0)
+        pl.launch_conv(0, _stream())
+    torch.cuda.synchronize()
+    x = torch.zeros(batch, cin, H, W, dtype=torch.float16, device=DEV)
+    x[:, :64] = h.permute(0, 3, 1, 2)
+    for ch, ci in enumerate(m16):
+        if ci >= 0:
+            x[:, ci] = r16[..., ch]
+    x[:, 75:83] = a8.permute(0, 3, 1, 2)
+    ref = torch.nn.functional.conv2d(x.float(), wt.half().float().to(DEV), bs.to(DEV), padding=1) + gw.permute(0, 3, 1, 2).float()
+    ref = torch.relu(ref).double().cpu()
+    err = (out.permute(0, 3, 1, 2).double().cpu() - ref).abs().max().item()
+    assert err < 4e-3 * max(1.0, ref.abs().max().item()), (H, W, batch, err)
+
+
 THIN_CASES = [
     # cin, list of (n couts, residual?) per destination tensor, act, batch
     (64, [(3, True), (3, True), (3, True)], L.ACT_NONE, 1),      # Dec_last2_2: three frames, each + its own residual

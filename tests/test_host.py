@@ -231,6 +231,67 @@ def test_ch_reducer_descriptor_is_the_streamed_weight_kernels(synthetic_sd):
     assert e32.conv_desc(op.conv).cout_perm == 0
 
 
+def test_unet_layers_carry_the_shape_of_the_phase_kernel(synthetic_sd):
+    """Round 6: the 4x4 stride-2 encoders and the >= 96-channel 3x3 layers of the refinement UNet (DeMFInet.py:575-603) and FGAC's w_gen
+    run on wsconv.hip only if the plan hands them the shape that kernel owns -- 64-byte records, one 32-channel NHWC piece (or a
+    16-channel tail + zero padding) per chunk, two 32-cout subtiles per work item, permuted cout order.  A builder change that made them
+    ineligible would silently put them back on the general kernel (2-3x slower, invisible to the parity tests): pin the descriptors."""
+    from demfi_amd.engine import SEG_HEAD, SEG_TB_HEAD, SEG_TRUNK
+    eng = Engine(synthetic_sd, 64, 96, torch.float16, 'cpu', max_updates=1, n_ctx=2)
+    want = {'Refine_Module.enc1#aF': (4, 2, 4, 64), 'Refine_Module.enc1#t': (4, 2, 3, 64), 'Refine_Module.enc2': (4, 2, 2, 128),
+            'Refine_Module.enc3': (4, 2, 4, 256), 'Refine_Module.dec0': (3, 1, 8, 256), 'Refine_Module.dec1': (3, 1, 12, 128),
+            'Refine_Module.dec2': (3, 1, 6, 64), 'FAC_FB_Module.shared_FGAC.w_gen': (3, 1, 4, 64)}
+    seen = set()
+    for seg in (SEG_TRUNK, SEG_HEAD, SEG_TB_HEAD):
+        for op in eng.ops(seg):
+            n = op.name.decode()
+            if n not in want or op.kind != 0:
+                continue
+            d = eng.conv_desc(op.conv)
+            k, stride, n_chunks, cout_pad = want[n]
+            assert (d.kh, d.kw, d.stride, d.n_chunks, d.cout_pad) == (k, k, stride, n_chunks, cout_pad), n
+            assert d.rec_bytes == 64 and d.nco == 2 and d.cout_perm == 1, n
+            for c in range(d.n_chunks):
+                ch = d.chunks[c]
+                pc = d.pieces[ch.first_piece]
+                assert ch.nks == 2 and pc.fat == 1 and pc.lds_ch == 0 and ((ch.n_pieces == 1 and pc.nch == 32) or (ch.n_pieces == 2 and pc.nch == 16)), (n, c)
+            seen.add(n)
+    assert seen == set(want)
+    up = [eng.conv_desc(o.conv) for o in eng.ops(SEG_HEAD) if o.name.decode() == 'Refine_Module.dec1'][0]
+    assert [up.pieces[up.chunks[c].first_piece].up_shift for c in range(12)] == [1] * 8 + [0] * 4      # cat[up(d0), u2]
+    # the fp32 plan keeps them on the general kernel
+    e32 = Engine(synthetic_sd, 64, 96, torch.float32, 'cpu', max_updates=1)
+    op = [o for o in e32.ops(SEG_HEAD) if o.name.decode() == 'Refine_Module.enc2'][0]
+    assert e32.conv_desc(op.conv).cout_perm == 0
+
+
+def test_fused_dec_first_2_experiment_is_still_the_network(synthetic_sd):
+    """DEMFI_DF2_FUSE=1 (round-6 experiment, measured neutral, not the product): Dec_first_2's per-recursion part as ONE launch whose third
+    unit is [16 channels of ref16 through a channel map | the recursion's 8-channel record | 0].  The switch is read once per process:
+    a child interprets that plan on the CPU against the oracle."""
+    import subprocess
+    import sys
+    code = (
+        "import torch\n"
+        "from demfi_amd.engine import Engine\n"
+        "from demfi_amd.weights import synthetic_state_dict, synthetic_window\n"
+        "from tests.plan_sim import PlanSim\n"
+        "from oracle import demfi_oracle as O\n"
+        "sd = synthetic_state_dict(0)\n"
+        "eng = Engine(sd, 32, 64, torch.float16, 'cpu', max_updates=2)\n"
+        "names = [op.name.decode() for op in eng.ops(2, 0)]\n"
+        "assert 'Dec_first_2#t' in names and 'Dec_first_2#rec' not in names, names\n"
+        "x = synthetic_window(32, 64, 4)\n"
+        "PlanSim(eng).forward(x, 0.375, 2)\n"
+        "ref = O.forward(sd, x, torch.tensor([[0.375]]), 2)\n"
+        "for i in range(3):\n"
+        "    assert O.psnr(eng.finals[1, i].float().numpy(), ref[1][1][i][0].numpy()) > 42.0\n"
+        "print('ok')\n")
+    e = dict(os.environ, DEMFI_DF2_FUSE='1')
+    r = subprocess.run([sys.executable, '-c', code], cwd=ROOT, env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and 'ok' in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
+
 @pytest.mark.parametrize('dtype', [torch.float16, torch.float32])
 def test_batched_per_t_plan_equals_per_context_plans(synthetic_sd, dtype):
     """demfi_forward_tb: ONE op list for all per-t contexts (convolutions batched over the contexts through the contiguous
