@@ -820,6 +820,25 @@ struct Builder {
     // input channels, so conv(cat[A, B]) = conv_A(A) + conv_B(B); the fp16 plan uses it to hoist the part of a layer whose
     // inputs do not change (per window / per recursion) and to bring the rest onto the persistent kernels.
     struct SubW { std::vector<float> w, b; Layer shape; };
+    // rows [co0, co0 + n) of a layer's weight / bias: one launch per group of output channels (UPNet.2)
+    SubW sub_weight_cout(const std::string& name, int co0, int n)
+    {
+        SubW o;
+        auto it = c->table.find(name);
+        if (it == c->table.end()) { status = demfi_set_error(DEMFI_ERR_ARG, "unknown layer '%s'", name.c_str()); return o; }
+        const Layer& l = it->second;
+        o.shape = {n, l.cin, l.kh, l.kw};
+        if (dry) return o;
+        auto iw = c->weights.find(name + ".weight"), ib = c->weights.find(name + ".bias");
+        if (iw == c->weights.end() || ib == c->weights.end()) {
+            status = demfi_set_error(DEMFI_ERR_ARG, "demfi_ctx_bind: weight '%s' was not loaded", name.c_str());
+            return o;
+        }
+        const size_t row = (size_t)l.cin * l.kh * l.kw;
+        o.w.assign(iw->second.data.begin() + co0 * row, iw->second.data.begin() + (co0 + n) * row);
+        o.b.assign(ib->second.data.begin() + co0, ib->second.data.begin() + co0 + n);
+        return o;
+    }
     SubW sub_weight(const std::string& name, const std::vector<int32_t>& sel, bool with_bias)
     {
         SubW o;
@@ -1075,6 +1094,16 @@ struct Builder {
                 }
             conv(tr, p + "UPNet.0", {fsrc(B["g1"], 0)}, ds, H2, W2);
         }
+        // UPNet.2 (3x3, 64 -> 133 = F0 | F1 | flow_01, flow_10, occlusion logit; DeMFInet.py:231, 247-253).  Round 6, fp16 plan: one launch per
+        // output group -- the two tanh feature halves on the staged-store 64 -> 64 kernel, the 5 planes on the thin-output kernel -- instead
+        // of ONE 160-cout launch of the general kernel (0.32 ms at 0.18 of the matrix peak).  DEMFI_UP2_SPLIT=0: the single launch.
+        static const bool up2_split = !(getenv("DEMFI_UP2_SPLIT") && atoi(getenv("DEMFI_UP2_SPLIT")) == 0);
+        if (c->dtype == DEMFI_F16 && up2_split) {
+            SubW w0 = sub_weight_cout(p + "UPNet.2", 0, 64), w1 = sub_weight_cout(p + "UPNet.2", 64, 64), w2 = sub_weight_cout(p + "UPNet.2", 128, 5);
+            conv(tr, p + "UPNet.2#F0", {fsrc(B["up"], 0)}, {D(fview(B["F01"], 0, 0), range(0, 64), T)}, H, W, 1, 1, &w0.w, &w0.b, &w0.shape);
+            conv(tr, p + "UPNet.2#F1", {fsrc(B["up"], 0)}, {D(fview(B["F01"], 0, 1), range(0, 64), T)}, H, W, 1, 1, &w1.w, &w1.b, &w1.shape);
+            conv(tr, p + "UPNet.2#f", {fsrc(B["up"], 0)}, {D(tview(B["ffo"]), range(0, 5))}, H, W, 1, 1, &w2.w, &w2.b, &w2.shape);
+        } else
         conv(tr, p + "UPNet.2", {fsrc(B["up"], 0)},
              {D(fview(B["F01"], 0, 0), range(0, 64), T), D(fview(B["F01"], 0, 1), range(64, 128), T), D(tview(B["ffo"]), range(128, 133))}, H, W);
         // ============================ trunk: FAC-FB (DeMFInet.py:335-358, 386-452) ================================

@@ -31,7 +31,7 @@ try:
 except Exception as e:
     head = 'bench failed: %s' % e
 sel = ['warp_fat', 'warp_thin', 'pack', 'cfr', 'fgac', 'Dec_last2', 'Dec_last2_2', 'Booster_Module.flow_occ.conv2', 'Decoder_res.0.conv1',
-       'Decoder_res.0.conv2', 'Decoder_res.0', 'Decoder_res_2.0', 'Booster_Module.GB.convzr1', 'Booster_Module.GB.convq1', 'Booster_Module.GB.convr1', 'Booster_Module.GB.step1.convzq', 'Booster_Module.GB.convr2', 'Booster_Module.GB.step2.convzq', 'Ch_Reducer', 'Refine_Module.enc1#t', 'Refine_Module.enc1#aF', 'Refine_Module.enc2', 'Refine_Module.enc3', 'FAC_FB_Module.shared_FGAC.w_gen', 'Dec_first_2#dyn', 'Dec_first_2#rec', 'Dec_first_2', 'Refine_Module.dec0', 'Refine_Module.dec1', 'Refine_Module.dec2']
+       'Decoder_res.0.conv2', 'Decoder_res.0', 'Decoder_res_2.0', 'Booster_Module.GB.convzr1', 'Booster_Module.GB.convq1', 'Booster_Module.GB.convr1', 'Booster_Module.GB.step1.convzq', 'Booster_Module.GB.convr2', 'Booster_Module.GB.step2.convzq', 'Ch_Reducer', 'Refine_Module.enc1#t', 'Refine_Module.enc1#aF', 'Refine_Module.enc2', 'Refine_Module.enc3', 'FAC_FB_Module.shared_FGAC.w_gen', 'Dec_first_2#dyn', 'Dec_first_2#rec', 'Dec_first_2', 'Refine_Module.dec0', 'Refine_Module.dec1', 'Refine_Module.dec2', 'FF_RDB_Module.UPNet.2', 'FF_RDB_Module.UPNet.2#F0', 'FF_RDB_Module.UPNet.2#F1', 'FF_RDB_Module.UPNet.2#f']
 short = lambda k: k.split('.')[-1] if k.count('.') > 1 else k
 print('[%s] %s' % (tag or 'product', head))
 print('    ' + '  '.join('%s %.4f x%d' % (short(k), sum(acc[k]) / len(acc[k]), len(acc[k])) for k in sel if acc[k]))
