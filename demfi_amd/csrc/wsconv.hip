@@ -209,6 +209,8 @@ __global__ __launch_bounds__(Ws2Cfg<S2>::NTHREADS, 1) void conv_ws2_kernel(const
         // ================= helper waves: the unit DMA, NBUF - 1 units ahead ==============================================
         const int dw = wave - 4;
         __builtin_assume(dw >= 0 && dw < C::NHW);
+        // (measured, round 6: the 2x2 form is bound by the helpers' DMA issue -- 9 instructions of ~400 cycles per 2 048-cycle unit; s_setprio 3
+        // on the helpers changes nothing: enc1#t 0.400 / 0.401 ms same box)
         // instruction i = dw + 4 j covers records 16 i .. 16 i + 15; lane -> (record 16 i + lane / 4, physical slot lane % 4), logical slot
         // (8 channels) = physical ^ ((column >> 2) & 3)
         int dl[C::NIW], dc[C::NIW], dslot[C::NIW];
