@@ -1419,8 +1419,8 @@ struct Builder {
         // round 6 EXPERIMENT (DEMFI_DF2_FUSE=1; the product keeps the two launches of rounds 2-5): ONE launch per recursion on the
         // streamed-weight kernel (wsconv.hip): units [F_rec lo | F_rec hi | ref16 + agg3d + 0], the window-constant share (g_pw) as the
         // residual, so that the partial sum g_p2 makes no round trip through HBM (256 B per pixel and recursion).  Built, parity-green,
-        // measured 0.98 ms against 0.44 + 0.51 ms (same box): the kernel's epilogue (16-byte-per-lane residual loads and stores: 32
-        // quarter lines per instruction) costs 15 000 of an item's 33 000 cycles (profiles/r06_notes.md section 6, the phase stamps).
+        // measured 0.98 ms against 0.44 + 0.51 ms (same box): the kernel's epilogue (64 KiB of residual loads + 64 KiB of stores issued by
+        // the MFMA waves themselves) costs 15 000 of an item's 33 000 cycles (profiles/r06_notes.md section 6, the phase stamps).
         static const bool df2_fuse = getenv("DEMFI_DF2_FUSE") && atoi(getenv("DEMFI_DF2_FUSE")) != 0 &&
                                      !(getenv("DEMFI_WS2") && atoi(getenv("DEMFI_WS2")) == 0);
         if (c->dtype == DEMFI_F16 && df2_fuse) {
