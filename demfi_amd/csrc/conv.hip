@@ -3094,8 +3094,8 @@ extern "C" int demfi_conv2d(const demfi_conv* h, const demfi_conv* dev, void* st
         return launch_sep(h, dev, st);
     }
     if (wstream_eligible(h)) return launch_wstream(h, dev, st);
-    if (wstream3_on() && wstream_eligible(h, 3, 1)) return launch_wstream3(h, dev, st);
     if (!persist_eligible(h) && !narrow_eligible(h) && demfi_ws2_eligible(h)) return demfi_ws2_launch(h, dev, st);      // wsconv.hip (round 6)
+    if (wstream3_on() && wstream_eligible(h, 3, 1)) return launch_wstream3(h, dev, st);
     if (persist_eligible(h)) {
 #ifdef DEMFI_ABLATION
         static const int var = getenv("DEMFI_PERSIST_VARIANT") ? atoi(getenv("DEMFI_PERSIST_VARIANT")) : 0;

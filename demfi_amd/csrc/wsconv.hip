@@ -40,15 +40,16 @@ __device__ __forceinline__ void ws_mma(f16x_t& acc, const uint4& a, const uint4&
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8_t, a), __builtin_bit_cast(h8_t, b), acc, 0, 0, 0);
 }
 
-template <bool S2> struct Ws2Cfg {
+template <bool S2, int NCH = 2> struct Ws2Cfg {                // NCH: 32-cout subtiles per work item (2: waves = cout half x row half; 1: four row groups)
     static constexpr int KSE = S2 ? 2 : 3;                       // taps per dimension a unit sees
-    static constexpr int TH = 16, TWP = 32, RPW = 8;             // output tile, rows per MFMA wave
+    static constexpr int RPW = 8;                                // rows per MFMA wave
+    static constexpr int TH = RPW * (4 / NCH), TWP = 32;         // output tile: 16 x 32 (NCH 2) or 32 x 32 (NCH 1)
     static constexpr int LH = TH + KSE - 1, LL = TWP + KSE - 1;  // lines / records per line of a unit's tile
     static constexpr int NHW = 4;                                // helper (DMA) waves
     static constexpr int NI = (LH * LL + 15) / 16;               // DMA instructions per unit (16 records of 64 bytes each)
     static constexpr int NIW = (NI + NHW - 1) / NHW;             // per helper wave: every helper issues exactly NIW (the surplus ones land in the buffer's pad)
     static constexpr int BUF_BYTES = NIW * NHW * 1024;
-    static constexpr int NBUF = S2 ? 4 : 3;
+    static constexpr int NBUF = S2 ? 4 : (NCH == 2 ? 3 : 2);
     static constexpr int LDS_BYTES = NBUF * BUF_BYTES + 1024;    // + the biases of up to four cout blocks
     static constexpr int NG = 2 * KSE;                           // (kx, k-step) groups per unit
     static constexpr int NSTEP = NG * KSE;
@@ -58,6 +59,9 @@ template <bool S2> struct Ws2Cfg {
     static constexpr int DEPTH = S2 ? 4 : DEMFI_WS2_DEPTH3;      // A prefetch distance in steps
     static constexpr int BL = KSE + RPW - 1;                     // lines of a wave's B window
     static constexpr int NTHREADS = 256 + 64 * NHW;
+    static constexpr int CB = 64 * NCH;                          // bytes of a block's channels in an output record
+    static_assert(NCH == 1 || NCH == 2, "one or two 32-cout subtiles");
+    static_assert(!(S2 && NCH == 1), "the 2x2 phase form is built for 64-cout blocks");
     static_assert(NSTEP % DEPTH == 0, "static ring indices");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
     static_assert((NBUF - 1) * NIW <= 63, "a helper's units in flight must be countable in vmcnt");
@@ -120,10 +124,12 @@ __device__ __forceinline__ float ws_mix_hi(unsigned a, float c)
     return d;
 }
 
-template <bool S2>
-__global__ __launch_bounds__(Ws2Cfg<S2>::NTHREADS, 1) void conv_ws2_kernel(const WsArgs a)
+constexpr int WS_NTHREADS = 512;                                 // 4 MFMA + 4 helper waves (== Ws2Cfg::NTHREADS: a macro argument cannot hold the template's comma)
+template <bool S2, int NCH>
+__global__ __launch_bounds__(WS_NTHREADS, 1) void conv_ws2_kernel(const WsArgs a)
 {
-    using C = Ws2Cfg<S2>;
+    using C = Ws2Cfg<S2, NCH>;
+    static_assert(C::NTHREADS == WS_NTHREADS, "launch bounds");
     constexpr int KSE = C::KSE, RPW = C::RPW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -131,7 +137,7 @@ __global__ __launch_bounds__(Ws2Cfg<S2>::NTHREADS, 1) void conv_ws2_kernel(const
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int H = a.H, W = a.W, inH = a.inH, inW = a.inW;
     const int tiles_x = (W + C::TWP - 1) / C::TWP, tiles_y = (H + C::TH - 1) / C::TH, tiles_img = tiles_x * tiles_y;
-    const int nblk = a.nblk;                                     // 64-cout blocks: the innermost index of an item (they share the input tile)
+    const int nblk = a.nblk;                                     // cout blocks (32 NCH couts): the innermost index of an item (they share the input tile)
     const int total = tiles_img * a.batch * nblk;
     // contiguous run of items per workgroup, the workgroups of an XCD (blockIdx % 8) share a contiguous band
     int it0, it1;
@@ -264,7 +270,7 @@ __global__ __launch_bounds__(Ws2Cfg<S2>::NTHREADS, 1) void conv_ws2_kernel(const
 
     // ================= MFMA waves ====================================================================================
     const int hi = lane >> 5, lx = lane & 31;
-    const int cs = wave & 1, rh = wave >> 1;                    // cout half, row half
+    const int cs = NCH == 2 ? (wave & 1) : 0, rh = NCH == 2 ? (wave >> 1) : wave;      // cout half, row group (RPW rows each)
     const unsigned lane16 = lane * 16;
     // B fragment of (group g = (kx, k-step), line l): record (lx + kx) of line rh * 8 + l, 16-byte slot (2 ksl + hi) swizzled by the column
     int boff[C::NG];
@@ -281,7 +287,7 @@ __global__ __launch_bounds__(Ws2Cfg<S2>::NTHREADS, 1) void conv_ws2_kernel(const
         asm volatile("" : "+s"(wb));                             // opaque uniform base + one 32-bit lane offset: the saddr form, nothing hoisted
         unsigned l16 = lane16;
         asm volatile("" : "+v"(l16));
-        return __builtin_bit_cast(uint4, *gcp<u4_t>(wb + (unsigned)(((tap * 2 + ksl) * 2) * 1024 + l16)));
+        return __builtin_bit_cast(uint4, *gcp<u4_t>(wb + (unsigned)(((tap * 2 + ksl) * NCH) * 1024 + l16)));
     };
 
     f16x_t acc[RPW];
@@ -289,7 +295,7 @@ __global__ __launch_bounds__(Ws2Cfg<S2>::NTHREADS, 1) void conv_ws2_kernel(const
     // biases of all cout blocks to LDS once (behind the unit buffers); an item's four quads per lane are four ds_read_b128
     float* const bias_lds = (float*)(smem + C::LDS_BYTES - 1024);
     if (wave == 0)
-        for (int i = lane; i < nblk * 64; i += 64) bias_lds[i] = a.bias[i];
+        for (int i = lane; i < nblk * 32 * NCH; i += 64) bias_lds[i] = a.bias[i];
     // accumulators of an item start at bias + residual
     auto res_fetch = [&](const Cursor& io, u4_t (&rr)[RPW][2]) {
         const WsBlock& bk = a.blk[io.blk];
@@ -313,8 +319,8 @@ __global__ __launch_bounds__(Ws2Cfg<S2>::NTHREADS, 1) void conv_ws2_kernel(const
         f4_t bq[4];                                              // bias in MFMA-row order: quads 0..3 of this lane
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd) {
-            if constexpr (decltype(FIRST)::value) bq[qd] = *gcp<f4_t>(a.bias + io.blk * 64 + cs * 32 + qd * 8 + hi * 4);      // no barrier yet: from global
-            else bq[qd] = *(const f4_t*)(bias_lds + io.blk * 64 + cs * 32 + qd * 8 + hi * 4);
+            if constexpr (decltype(FIRST)::value) bq[qd] = *gcp<f4_t>(a.bias + io.blk * 32 * NCH + cs * 32 + qd * 8 + hi * 4);      // no barrier yet: from global
+            else bq[qd] = *(const f4_t*)(bias_lds + io.blk * 32 * NCH + cs * 32 + qd * 8 + hi * 4);
         }
         if (a.blk[io.blk].res) {
 #pragma unroll
@@ -452,15 +458,21 @@ static bool ws2_on()
 // padding), 64-cout blocks each routed to 64 consecutive channels of one NHWC fp16 destination (optional NHWC fp16 residual)
 bool demfi_ws2_eligible(const demfi_conv* h)
 {
-    if (!ws2_on() || h->dtype != DEMFI_F16 || !h->zero_page || h->rec_bytes != 64 || h->nco != 2 || h->cout_pad % 64) return false;
+    if (!ws2_on() || h->dtype != DEMFI_F16 || !h->zero_page || h->rec_bytes != 64 || (h->nco != 2 && h->nco != 1) || h->cout_pad % (32 * h->nco)) return false;
+    const int nco = h->nco, nblk = h->cout_pad / (32 * nco);
     const bool s2 = h->stride == 2;
+    if (nco == 1) {
+        // 32-cout blocks (the RDB growth convolutions, DeMFInet.py:266-281): 3x3 only; DEMFI_WS2_RDB=0 leaves them on the round-5 kernel
+        static const bool rdb = !(getenv("DEMFI_WS2_RDB") && atoi(getenv("DEMFI_WS2_RDB")) == 0);
+        if (!rdb || s2) return false;
+    }
     if (s2) {
         if (h->kh != 4 || h->kw != 4 || h->pad_y != 1 || h->pad_x != 1 || h->inH != 2 * h->H || h->inW != 2 * h->W) return false;
     } else {
         if (h->stride != 1 || h->kh != 3 || h->kw != 3 || h->pad_y != 1 || h->pad_x != 1 || h->inH != h->H || h->inW != h->W) return false;
     }
-    if (h->n_chunks < 1 || h->n_chunks > WS_MAX_CHUNKS || h->cout_pad / 64 > WS_MAX_BLOCKS) return false;
-    if (h->w_blk_stride * 16 * (h->cout_pad / 64) >= (int64_t)1 << 31) return false;
+    if (h->n_chunks < (nco == 1 ? 2 : 1) || h->n_chunks > WS_MAX_CHUNKS || nblk > WS_MAX_BLOCKS) return false;
+    if (h->w_blk_stride * 16 * nblk >= (int64_t)1 << 31) return false;
     for (int c = 0; c < h->n_chunks; ++c) {
         const demfi_chunk& ch = h->chunks[c];
         if (ch.nks != 2 || ch.n_pieces < 1 || ch.n_pieces > 3) return false;
@@ -478,18 +490,19 @@ bool demfi_ws2_eligible(const demfi_conv* h)
             } else {
                 const demfi_piece& z = h->pieces[ch.first_piece + 2];
                 if (!q.v.ptr || !q.fat || q.nch != 8 || q.up_shift || q.v.sc != 1 || q.v.is_f32 || z.v.ptr != nullptr || z.nch != 8) return false;
-                if (q.v.sy * 4 * 20 + q.v.sx * 4 * 40 >= (int64_t)1 << 31) return false;
+                if (q.v.sy * 4 * 40 + q.v.sx * 4 * 40 >= (int64_t)1 << 31) return false;
             }
         }
-        if (p.v.sy * 4 * 20 + p.v.sx * 4 * 40 >= (int64_t)1 << 31) return false;       // 32-bit per-lane offsets inside a tile
+        if (p.v.sy * 4 * 40 + p.v.sx * 4 * 40 >= (int64_t)1 << 31) return false;       // 32-bit per-lane offsets inside a tile
     }
-    for (int b = 0; b < h->cout_pad / 64; ++b) {
-        const int sgi = h->sub_seg[2 * b];
-        if (sgi < 0 || h->sub_seg[2 * b + 1] != sgi) return false;
-        for (int o = 0; o < 8; ++o)
-            if (h->oct_seg[8 * b + o] != sgi || h->oct_n[8 * b + o] != 8 || h->oct_ch[8 * b + o] != h->oct_ch[8 * b] + 8 * o) return false;
+    for (int b = 0; b < nblk; ++b) {
+        const int sgi = h->sub_seg[nco * b];
+        if (sgi < 0 || (nco == 2 && h->sub_seg[2 * b + 1] != sgi)) return false;
+        for (int o = 0; o < 4 * nco; ++o)
+            if (h->oct_seg[4 * nco * b + o] != sgi || h->oct_n[4 * nco * b + o] != 8 || h->oct_ch[4 * nco * b + o] != h->oct_ch[4 * nco * b] + 8 * o) return false;
         const demfi_seg& sg = h->segs[sgi];
         if (sg.mode != DEMFI_MODE_STORE || sg.scale != 1 || sg.dy || sg.dx || !sg.dst.ptr || sg.dst.is_f32 || sg.dst.sc != 1 || sg.aux.ptr) return false;
+        if (sg.act != DEMFI_ACT_NONE && sg.act != DEMFI_ACT_RELU) return false;
         if (sg.res.ptr && (sg.res.is_f32 || sg.res.sc != 1)) return false;
     }
     if (h->u8_sink || h->pack.ptr) return false;
@@ -498,17 +511,18 @@ bool demfi_ws2_eligible(const demfi_conv* h)
 
 int demfi_ws2_launch(const demfi_conv* h, const demfi_conv* /*dev*/, void* stream)
 {
-    const int64_t total = (int64_t)((h->W + 31) / 32) * ((h->H + 15) / 16) * h->batch * (h->cout_pad / 64);
+    const int nco = h->nco, th = nco == 2 ? 16 : 32;
+    const int64_t total = (int64_t)((h->W + 31) / 32) * ((h->H + th - 1) / th) * h->batch * (h->cout_pad / (32 * nco));
     if (total <= 0 || total >= (int64_t)1 << 30) return demfi_set_error(DEMFI_ERR_ARG, "demfi_conv2d (streamed-weight 64-cout kernel): empty or oversized launch");
     if (!h->wpack || !h->bias) return demfi_set_error(DEMFI_ERR_ARG, "demfi_conv2d (streamed-weight 64-cout kernel): weights / bias not bound");
     WsArgs a;
     memset(&a, 0, sizeof(a));
     a.wpack = (const char*)h->wpack; a.bias = h->bias; a.zeros = (const char*)h->zero_page;
     a.w_blk_stride = h->w_blk_stride * 16;
-    a.H = h->H; a.W = h->W; a.inH = h->inH; a.inW = h->inW; a.batch = h->batch; a.n_chunks = h->n_chunks; a.nblk = h->cout_pad / 64;
+    a.H = h->H; a.W = h->W; a.inH = h->inH; a.inW = h->inW; a.batch = h->batch; a.n_chunks = h->n_chunks; a.nblk = h->cout_pad / (32 * nco);
     for (int b = 0; b < a.nblk; ++b) {
-        const demfi_seg& sg = h->segs[h->sub_seg[2 * b]];
-        const int ch0 = h->oct_ch[8 * b];
+        const demfi_seg& sg = h->segs[h->sub_seg[nco * b]];
+        const int ch0 = h->oct_ch[4 * nco * b];
         WsBlock& k = a.blk[b];
         k.dst = (char*)sg.dst.ptr + (int64_t)ch0 * 2; k.d_sb = sg.dst.sb * 2; k.d_sx = (int)(sg.dst.sx * 2); k.d_sy = (int)(sg.dst.sy * 2);
         k.res = sg.res.ptr ? (const char*)sg.res.ptr + (int64_t)ch0 * 2 : nullptr;
@@ -535,12 +549,16 @@ int demfi_ws2_launch(const demfi_conv* h, const demfi_conv* /*dev*/, void* strea
         DEMFI_HIP_CHECK(hipMemset(trbuf, 0, 8 * 512 * 8));
         a.trace = trbuf;
     }
+    constexpr int lds_s2 = Ws2Cfg<true, 2>::LDS_BYTES, lds_3 = Ws2Cfg<false, 2>::LDS_BYTES, lds_31 = Ws2Cfg<false, 1>::LDS_BYTES;
     if (h->stride == 2) {
-        DEMFI_LDS_ATTR(conv_ws2_kernel<true>);
-        hipLaunchKernelGGL(conv_ws2_kernel<true>, dim3(grid), dim3(Ws2Cfg<true>::NTHREADS), Ws2Cfg<true>::LDS_BYTES, (hipStream_t)stream, a);
+        DEMFI_LDS_ATTR((conv_ws2_kernel<true, 2>));
+        hipLaunchKernelGGL((conv_ws2_kernel<true, 2>), dim3(grid), dim3(WS_NTHREADS), lds_s2, (hipStream_t)stream, a);
+    } else if (nco == 2) {
+        DEMFI_LDS_ATTR((conv_ws2_kernel<false, 2>));
+        hipLaunchKernelGGL((conv_ws2_kernel<false, 2>), dim3(grid), dim3(WS_NTHREADS), lds_3, (hipStream_t)stream, a);
     } else {
-        DEMFI_LDS_ATTR(conv_ws2_kernel<false>);
-        hipLaunchKernelGGL(conv_ws2_kernel<false>, dim3(grid), dim3(Ws2Cfg<false>::NTHREADS), Ws2Cfg<false>::LDS_BYTES, (hipStream_t)stream, a);
+        DEMFI_LDS_ATTR((conv_ws2_kernel<false, 1>));
+        hipLaunchKernelGGL((conv_ws2_kernel<false, 1>), dim3(grid), dim3(WS_NTHREADS), lds_31, (hipStream_t)stream, a);
     }
     DEMFI_HIP_CHECK(hipGetLastError());
     if (tracing) {
@@ -549,7 +567,7 @@ int demfi_ws2_launch(const demfi_conv* h, const demfi_conv* /*dev*/, void* strea
         DEMFI_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
         DEMFI_HIP_CHECK(hipMemcpy(host, trbuf, sizeof(host), hipMemcpyDeviceToHost));
         for (int w : {0, 4}) {
-            fprintf(stderr, "[ws2 trace] stride %d chunks %d blocks %d wave %d:", h->stride, h->n_chunks, h->cout_pad / 64, w);
+            fprintf(stderr, "[ws2 trace] stride %d chunks %d blocks %d wave %d:", h->stride, h->n_chunks, h->cout_pad / (32 * nco), w);
             unsigned long long prev = 0;
             for (int i = 0; i < 512 && host[w * 512 + i]; ++i) {
                 const unsigned long long t = host[w * 512 + i] & 0xffffffffffffffull;
