@@ -166,3 +166,30 @@ def test_gru_first_form_of_the_zq_launch_in_its_own_process():
                        env=env, capture_output=True, text=True, timeout=600, cwd=root)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert '14 passed' in r.stdout, r.stdout[-500:]
+
+
+def _even(v):
+    return (v + 1) & ~1
+
+
+WS2_S2 = [(K.WS2_S2_CASES[i % len(K.WS2_S2_CASES)], H, W, _rng.randint(1, 2)) for i, (H, W) in enumerate(_shapes(8, 4, 60, 4, 120))]
+
+
+@pytest.mark.parametrize('case,H,W,batch', WS2_S2)
+def test_fuzz_stride2_by_phases(case, H, W, batch):
+    """wsconv.hip, 4x4 stride 2 as four phases of 2x2 taps: ragged 16 x 32 tiles in both directions, odd output sizes, one to four 64-cout blocks"""
+    K.test_stride2_4x4_conv_by_phases(case, H, W, batch)
+
+
+WS2_S1 = [(K.WS2_S1_CASES[i % len(K.WS2_S1_CASES)], _even(H), _even(W), _rng.randint(1, 2)) for i, (H, W) in enumerate(_shapes(10, 4, 60, 4, 120))]
+
+
+@pytest.mark.parametrize('case,H,W,batch', WS2_S1)
+def test_fuzz_conv3x3_over_units(case, H, W, batch):
+    """wsconv.hip, 3x3 over 32-channel units, some read through the x2 upsample (even sizes), with and without residual"""
+    K.test_conv3x3_over_32_channel_units(case, H, W, batch)
+
+
+@pytest.mark.parametrize('H,W,batch', [(H, W, _rng.randint(1, 3)) for H, W in _shapes(4, 4, 50, 4, 100)])
+def test_fuzz_conv3x3_units_two_piece_tail(H, W, batch):
+    K.test_conv3x3_units_with_a_two_piece_tail(H, W, batch)
