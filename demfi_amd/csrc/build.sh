@@ -6,7 +6,10 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -I../../include -Wno-unused-result -Wno-pass-failed -Werror=inline-asm -Werror=unused-value"
 # experiment builds only (--ablation / --trace below) take extra flags from the environment; the product compile line is fixed
 XFLAGS="$DEMFI_EXTRA_FLAGS"
-SRCS_HIP="conv.hip pointwise.hip"
+# conv.hip = the dispatcher (demfi_conv2d); the convolution kernels are units of their own (round 6: they compile in parallel, 2 min -> 1 min)
+CONV_UNITS="conv conv_general conv_c64 conv_narrow conv_sep conv_wstream"
+SRCS_HIP="pointwise.hip"
+for u in $CONV_UNITS; do SRCS_HIP="$SRCS_HIP $u.hip"; done
 SRCS_CPP="abi.cpp"
 [ -f metrics.hip ] && SRCS_HIP="$SRCS_HIP metrics.hip"
 [ -f fgac_window.hip ] && SRCS_HIP="$SRCS_HIP fgac_window.hip"
@@ -25,7 +28,7 @@ objs=()
 CONV_FLAGS="-fno-slp-vectorize"
 for s in $SRCS_HIP; do
   o="${s%.hip}.o"; objs+=("$o")
-  xf=""; { [ "$s" = conv.hip ] || [ "$s" = resblock.hip ] || [ "$s" = gru.hip ] || [ "$s" = wsconv.hip ]; } && xf="$CONV_FLAGS"
+  xf=""; case "$s" in conv*.hip|resblock.hip|gru.hip|wsconv.hip) xf="$CONV_FLAGS" ;; esac
   $HIPCC $FLAGS $xf -c "$s" -o "$o" & pids+=($!)
 done
 for s in $SRCS_CPP; do
@@ -39,21 +42,28 @@ echo "built $(pwd)/libdemfi_hip.so"
 # DEMFI_CONV_Z, ...); use it with DEMFI_HIP_LIB=$(pwd)/libdemfi_hip_abl.so.  Never loaded by default.
 # --trace: third library whose persistent 64->64 kernels stamp s_memtime at their phase boundaries (tools/phase_trace.py)
 if [ "$1" = "--trace" ]; then
-  $HIPCC $FLAGS $XFLAGS $CONV_FLAGS -DDEMFI_TRACE -c conv.hip -o conv_trace.o &
-  $HIPCC $FLAGS $XFLAGS $CONV_FLAGS -DDEMFI_TRACE -c gru.hip -o gru_trace.o &
-  $HIPCC $FLAGS $XFLAGS $CONV_FLAGS -DDEMFI_TRACE -c resblock.hip -o resblock_trace.o
-  wait
+  tp=()
+  for u in $CONV_UNITS gru resblock; do
+    $HIPCC $FLAGS $XFLAGS $CONV_FLAGS -DDEMFI_TRACE -c $u.hip -o ${u}_trace.o & tp+=($!)
+  done
+  for p in "${tp[@]}"; do wait "$p"; done
   trc=()
   for o in "${objs[@]}"; do
-    if [ "$o" = conv.o ]; then trc+=(conv_trace.o); elif [ "$o" = resblock.o ]; then trc+=(resblock_trace.o); elif [ "$o" = gru.o ]; then trc+=(gru_trace.o); else trc+=("$o"); fi
+    case "$o" in conv*.o|resblock.o|gru.o) trc+=("${o%.o}_trace.o") ;; *) trc+=("$o") ;; esac
   done
   $HIPCC --offload-arch=gfx950 -shared -fPIC "${trc[@]}" -o libdemfi_hip_trace.so -lz -lpthread
   echo "built $(pwd)/libdemfi_hip_trace.so"
 fi
 if [ "$1" = "--ablation" ]; then
-  $HIPCC $FLAGS $XFLAGS $CONV_FLAGS -DDEMFI_ABLATION -c conv.hip -o conv_abl.o
+  ap=()
+  for u in $CONV_UNITS; do
+    $HIPCC $FLAGS $XFLAGS $CONV_FLAGS -DDEMFI_ABLATION -c $u.hip -o ${u}_abl.o & ap+=($!)
+  done
+  for p in "${ap[@]}"; do wait "$p"; done
   abl=()
-  for o in "${objs[@]}"; do [ "$o" = conv.o ] && abl+=(conv_abl.o) || abl+=("$o"); done
+  for o in "${objs[@]}"; do
+    case "$o" in conv*.o) abl+=("${o%.o}_abl.o") ;; *) abl+=("$o") ;; esac
+  done
   $HIPCC --offload-arch=gfx950 -shared -fPIC "${abl[@]}" -o libdemfi_hip_abl.so -lz -lpthread
   echo "built $(pwd)/libdemfi_hip_abl.so"
 fi
