@@ -80,9 +80,15 @@ __device__ __forceinline__ void quad_transpose4(float (&a)[4], int lane)
 #ifndef DEMFI_THIN_REGW_G128
 #define DEMFI_THIN_REGW_G128 6
 #endif
-template <int NCO, int REC, int EPI, int KS = 3, int NDMA = NarrowCfg<REC, KS>::NDMA, int NOCT = 4, bool PACK = false>
+// P7 (7x7 only, round 6): PAIRED TAPS.  Mixer.conv_delta1 feeds 5 real channels: the upper 8 of a tap's 16-channel k-step multiply zeros.  When the
+// chunk is [8-channel piece | 8 zero channels], the upper-half lanes of the B operand read the NEXT column's first 8 channels instead, and the A
+// fragment of the step is assembled (in the weight copy to LDS) from the lower halves of the taps (ky, 2j) and (ky, 2j + 1): one MFMA = two taps,
+// 28 k-steps instead of 49; with ky innermost the 8 input rows of a column pair serve both output rows at all 7 ky (15 LDS reads per 14 MFMAs
+// instead of 21).
+template <int NCO, int REC, int EPI, int KS = 3, int NDMA = NarrowCfg<REC, KS>::NDMA, int NOCT = 4, bool PACK = false, bool P7 = false>
 __global__ __launch_bounds__(NT + 64 * NDMA, 1) void conv3x3_narrow_persist_kernel(const demfi_conv* __restrict__ d)
 {
+    static_assert(!P7 || (KS == 7 && NCO == 1 && REC == 32), "paired taps: the 7x7 / 16-channel / 32-cout instantiation");
     constexpr bool RES = EPI == 1, THIN = EPI == 2;
     constexpr bool REGW = THIN && KS == 3 && NCO == 1 && DEMFI_THIN_REGW != 0;
     // (kx, k-step) groups whose three ky fragments are register resident: all 6 of a 64-byte-record layer (18 fragments, 72 registers),
@@ -214,6 +220,16 @@ __global__ __launch_bounds__(NT + 64 * NDMA, 1) void conv3x3_narrow_persist_kern
             }
         };
         const uint4* wsrc = (const uint4*)d->wpack;
+        if constexpr (P7) {
+            // paired fragment (ky, j): lanes 0-31 = channels 0-7 of tap (ky, 2j), lanes 32-63 = channels 0-7 of tap (ky, 2j + 1) (kx = 7: zeros)
+            for (int i = dw; i < 7 * 4; i += NDMA) {
+                const int ky = i >> 2, j = i & 3;
+                const int kx = 2 * j + (lane >> 5);
+                const void* g = kx < 7 ? (const void*)(wsrc + (ky * 7 + kx) * 64 + (lane & 31)) : (const void*)zeros;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                                 (__attribute__((address_space(3))) void*)(wlds + i * 1024), 16, 0, 0);
+            }
+        } else
         if constexpr (WLDS) {
             for (int i = dw; i < NSTEP * NCO; i += NDMA)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + i * 64 + lane),
@@ -459,6 +475,36 @@ __global__ __launch_bounds__(NT + 64 * NDMA, 1) void conv3x3_narrow_persist_kern
                 mma_g(f[g % 3], G_);
                 groups(std::integral_constant<int, (g + 2 < NG) ? (g + 2 < RG ? 4 : 3 * NCO + 4) : 0>{});
             });
+        } else if constexpr (P7) {
+            struct PairFrag { uint4 a[7]; uint4 b[8]; };
+            auto load_j = [&](PairFrag& f, auto J_) {
+                constexpr int j = decltype(J_)::value;
+                const int col = lx + 2 * j + hi;                 // upper-half lanes: the next column's first 8 channels
+                const char* p0 = tb + col * REC + ((0 ^ Cfg::swz(col)) << 4);
+#pragma unroll
+                for (int ky = 0; ky < 7; ++ky) f.a[ky] = *(const uint4*)(wl + (ky * 4 + j) * 1024);
+#pragma unroll
+                for (int r = 0; r < 8; ++r) f.b[r] = *(const uint4*)(p0 + r * (P_LW * REC));
+            };
+            PairFrag f[2];
+            load_j(f[0], std::integral_constant<int, 0>{});
+            static_for<0, 4>([&](auto J_) {
+                constexpr int j = decltype(J_)::value;
+                if constexpr (j + 1 < 4) load_j(f[(j + 1) & 1], std::integral_constant<int, j + 1>{});
+                static_for<0, 7>([&](auto KY_) {
+                    constexpr int ky = decltype(KY_)::value;
+                    Mma<half_t>::run(acc[0][0], f[j & 1].a[ky], f[j & 1].b[ky]);
+                    Mma<half_t>::run(acc[0][1], f[j & 1].a[ky], f[j & 1].b[ky + 1]);
+                });
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // the next pair's 15 reads between this pair's 14 MFMAs
+                if constexpr (j + 1 < 4) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+                for (int q = 1; q < 14; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if constexpr (j + 1 < 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
         } else {
             auto load_step = [&](NarrowFrag& f, int g) {        // g = tap*NKS + ks
                 const int tap = g / NKS, ks = g % NKS;
@@ -674,8 +720,24 @@ int launch_narrow(const demfi_conv* h, const demfi_conv* dev, hipStream_t st, bo
             return demfi_set_error(DEMFI_ERR_ARG, "demfi_conv2d: thin epilogue needs nco == 1");
     } else if (h->segs[h->sub_seg[0]].res.ptr != nullptr)
         hipLaunchKernelGGL((conv3x3_narrow_persist_kernel<NCO, REC, 1, KS>), dim3(grid), dim3(NT + 64 * NarrowCfg<REC, KS>::NDMA), lds, st, dev);
-    else
+    else {
+        if constexpr (KS == 7 && NCO == 1 && REC == 32) {
+            // paired taps (P7): the chunk is one 8-channel NHWC piece + 8 zero channels; DEMFI_N7_PAIR=0: one tap per k-step (rounds 2-5)
+            static const bool pair_on = !(getenv("DEMFI_N7_PAIR") && atoi(getenv("DEMFI_N7_PAIR")) == 0);
+            const demfi_chunk& ch = h->chunks[0];
+            if (pair_on && ch.n_pieces == 2 && h->pieces[ch.first_piece].nch == 8 && h->pieces[ch.first_piece].v.ptr && h->pieces[ch.first_piece].lds_ch == 0 &&
+                h->pieces[ch.first_piece + 1].v.ptr == nullptr) {
+                // four DMA waves: with the matrix phase at 2 400 cycles the two of the unpaired form (4 000 cycles for their 9 instructions each:
+                // per-lane piece / bounds arithmetic beside an MFMA wave) would set the period
+                constexpr int ND = 4;
+                DEMFI_LDS_ATTR((conv3x3_narrow_persist_kernel<1, 32, 0, 7, ND, 4, false, true>));
+                hipLaunchKernelGGL((conv3x3_narrow_persist_kernel<1, 32, 0, 7, ND, 4, false, true>), dim3(grid), dim3(NT + 64 * ND), lds, st, dev);
+                DEMFI_HIP_CHECK(hipGetLastError());
+                return DEMFI_OK;
+            }
+        }
         hipLaunchKernelGGL((conv3x3_narrow_persist_kernel<NCO, REC, 0, KS>), dim3(grid), dim3(NT + 64 * NarrowCfg<REC, KS>::NDMA), lds, st, dev);
+    }
     DEMFI_HIP_CHECK(hipGetLastError());
     return DEMFI_OK;
 }

@@ -1476,8 +1476,10 @@ struct Builder {
                     for (int i = 0; i < 5; ++i) pl.push_back(delta_p(it, i));
                     pack(sg, pl, B["delta16"]);
                 }
+                // the first 8 channels of the record as the piece (5 planes + 3 unused), the other 8 of the k-step as zero padding: the shape
+                // the 7x7 kernel's paired-tap mode takes (conv_narrow.hip, P7); the fp32 plan (general kernel) is indifferent
                 std::vector<int32_t> m = range(0, 5);
-                m.insert(m.end(), 11, -1);
+                m.insert(m.end(), 3, -1);
                 conv(sg, p + "Mixer.conv_delta1", {fsrc_map(B["delta16"], m)}, {D(fview(B["de1"]), range(0, 32), R)}, H, W);
             }
             conv(sg, p + "Mixer.conv_delta2", {fsrc(B["de1"], 0)}, {D(fview(B["rd64"], 32), range(0, 32), R)}, H, W);

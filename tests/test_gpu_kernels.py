@@ -335,7 +335,9 @@ def test_narrow_persistent_conv(case, H, W, batch):
 @pytest.mark.parametrize('H,W', [(8, 32), (37, 75), (64, 96), (19, 130)])
 def test_narrow_persistent_conv_7x7(H, W):
     """Mixer.conv_delta1 (7x7, 5 -> 32, DeMFInet.py:800-812): the 7x7 instantiation of the narrow persistent kernel (49 taps of
-    resident weights, one 16-channel k-step per tap, 14x38-pixel tiles) instead of the general kernel's 49 per-tap barriers."""
+    resident weights, one 16-channel k-step per tap, 14x38-pixel tiles) instead of the general kernel's 49 per-tap barriers.  Round 6: the chunk
+    [8-channel piece | 8 zero channels] of this test (and of the plan) takes the PAIRED-TAP mode -- the upper-half lanes of the B operand read the next
+    column, one MFMA covers the taps (ky, 2j) and (ky, 2j + 1): 28 k-steps instead of 49, four DMA waves (DEMFI_N7_PAIR=0: one tap per k-step)."""
     torch.manual_seed(5)
     pl = Plan(H, W, torch.float16, DEV)
     b = pl._fat(H, W, 8)
