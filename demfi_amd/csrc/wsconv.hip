@@ -1,7 +1,8 @@
-// Streamed-weight convolution, second family (round 6): 64 output channels per work item over ANY number of 32-channel input units,
+// Streamed-weight convolution, second family (round 6): 64 (or 32) output channels per work item over ANY number of 32-channel input units,
 //   * 3x3 stride 1 (+ optional NHWC residual; units may be read through the x2 nearest-neighbour upsample of the UNet decoder,
-//     DeMFInet.py:592-601)                           -- layers whose K is not one 64-channel record;
-//   * 4x4 stride 2 as FOUR PHASES of 2x2 taps        -- the UNet encoders (Refine_Module.enc1/2/3, DeMFInet.py:575-577, 588-590).
+//     DeMFInet.py:592-601)                           -- layers whose K is not one 64-channel record: dec0 / dec1 / dec2, FGAC's w_gen;
+//   * 4x4 stride 2 as FOUR PHASES of 2x2 taps        -- the UNet encoders (Refine_Module.enc1/2/3, DeMFInet.py:575-577, 588-590);
+//   * NCH = 1: 32-cout blocks, four row groups of a 32 x 32-pixel tile -- the 48 RDB growth convolutions of the trunk (DeMFInet.py:266-281).
 // What it replaces: the general kernel (conv_kernel) ran the stride-2 layers at 0.09-0.16 of the matrix peak -- one workgroup per
 // 8 x 32 tile, a VGPR-staged gather of a 18 x 66-pixel window per chunk and one barrier per tap (16 per chunk).
 //
@@ -20,6 +21,10 @@
 // ky = l - p): per step 8 MFMAs, one or two ds_read_b128, one A load.
 // Epilogue: the accumulators START at bias + residual (the residual of the NEXT item is fetched in front of this item's stores), so
 // the end of an item is activation, conversion and 16-byte stores of 8 consecutive channels per lane (cout_perm packing).
+// What bounds it (profiles/r06_notes.md section 6, DEMFI_WS2_TRACE): the helpers' DMA runs at the CU's share of the memory system (~10 B/clk: the
+// 2x2 and the 32-cout forms are bound by it, the 3x3 / 64-cout form is balanced); the item's end (64 KiB of the MFMA waves' own stores [+ loads]) is
+// serial with the matrix phases -- staged whole-line stores by the helpers, lane-swapped store layouts and a one-instruction DMA address path
+// were each built and measured neutral.
 #include "common.h"
 #include <type_traits>
 #include <stdlib.h>
